@@ -1,0 +1,38 @@
+"""pytest configuration: markers, oracle / product library loaders.
+
+The oracle (oracle/*.so) is test infrastructure; the product library
+(linreg-mpc_amd/csrc/liblinreg_gc.so) is what is under test.  Nothing here
+reads /root/reference at run time.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _make(target_dir, target):
+    path = os.path.join(target_dir, target)
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", target_dir, target])
+    return path
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import orc
+    return orc.load()
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
