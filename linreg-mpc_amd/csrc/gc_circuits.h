@@ -1,0 +1,264 @@
+// gc_circuits.h -- wave-shaped boolean circuits for the fixed-point ops.
+//
+// One "word" W is one wire per lane of a 64-wide wavefront: lane l carries bit
+// l of a two's-complement value (w = 32 or 64 lanes used).  Circuits are
+// written once, against an abstract backend B, as sequences of whole-wave
+// steps; every B::AND call is one *gate step* (up to 64 AND gates, one per
+// active lane).  XOR / NOT / lane moves / public constants are free (free-XOR).
+//
+// Backends (all expose the same members):
+//   PlainBackend            W = uint64_t bit mask; used on the host to count
+//                           steps / gates and (tests) to check circuit logic
+//   GpuGarbler/GpuEvaluator W = one 128-bit label per lane  (gc_device.h)
+//   CpuGarbler/CpuEvaluator oracle/gc_cpu.cpp (CPU baseline, AES-NI)
+//
+// Semantics implemented (reference file:line):
+//   add/sub   src/fixed.oc:99-121      wrap_w(a +- b)
+//   abs       src/fixed.oc:90-97
+//   gt        src/fixed.oc:78-88       (unsigned for w=64, signed for w=32)
+//   mul       src/fixed.oc:149-162     wrap_w((a*b) >> p), exact product
+//   ip        src/fixed.oc:124-147     wrap_w((sum a_i*b_i) >> p)
+//   div       src/fixed.oc:164-188     wrap_w(tdiv(a << p, b))
+//   sqrt      src/fixed.oc:217-248
+// The bit-level structure (carry-save array multiplier, Kogge-Stone adders,
+// restoring divider) is this build's own; only the integer results are the
+// reference's.
+#pragma once
+#include <stdint.h>
+
+#ifndef GC_HD
+#if defined(__HIPCC__)
+#define GC_HD __host__ __device__ __forceinline__
+#else
+#define GC_HD inline
+#endif
+#endif
+
+namespace gc {
+
+GC_HD uint64_t lanes(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1)); }
+
+template <class B>
+struct Circ {
+    typedef typename B::W W;
+
+    // ---- Kogge-Stone adder over lanes [0, n): returns x + y + cin (mod 2^n).
+    // cinw: word whose lane 0 holds the carry-in (other lanes zero) or zero().
+    // cout (optional): carry out of lane n-1, broadcast to every lane.
+    static GC_HD W add(B &be, W x, W y, int n, W cinw, W *cout) {
+        const uint64_t act = lanes(n);
+        W P = be.XOR(x, y);
+        // lane 0: maj(x0, y0, cin) = ((x0^c)&(y0^c))^c ; other lanes: x&y
+        W G = be.XOR(be.AND(be.XOR(x, cinw), be.XOR(y, cinw), act), cinw);
+        W Pg = P;
+        for (int dist = 1; dist < n; dist <<= 1) {
+            const uint64_t hi = act & ~lanes(dist);
+            W Gs = be.shl(G, dist);
+            G = be.XOR(G, be.AND(Pg, Gs, hi));
+            if ((dist << 1) < n) Pg = be.AND(Pg, be.shl(Pg, dist), hi);
+        }
+        if (cout) *cout = be.bcast(G, n - 1);
+        W carries = be.XOR(be.sel(act, be.shl(G, 1), be.zero()), cinw);
+        return be.XOR(P, carries);
+    }
+    static GC_HD W add(B &be, W x, W y, int n) { return add(be, x, y, n, be.zero(), (W *)0); }
+    // x - y (mod 2^n); cout = 1 iff x >= y (unsigned)
+    static GC_HD W sub(B &be, W x, W y, int n, W *cout) {
+        return add(be, x, be.NOTm(y, lanes(n)), n, be.konst(1), cout);
+    }
+    static GC_HD W sub(B &be, W x, W y, int n) { return sub(be, x, y, n, (W *)0); }
+
+    // (x ^ s) + s with s a broadcast bit: conditional negate
+    static GC_HD W condneg(B &be, W x, W sb, int n) {
+        W xs = be.XOR(x, be.sel(lanes(n), sb, be.zero()));
+        return add(be, xs, be.zero(), n, be.sel(1ull, sb, be.zero()), (W *)0);
+    }
+    static GC_HD W vabs(B &be, W a, int w) { return condneg(be, a, be.bcast(a, w - 1), w); }
+
+    // sel ? a : b  (selb broadcast)
+    static GC_HD W mux(B &be, W selb, W a, W b, int n) {
+        return be.XOR(b, be.AND(selb, be.XOR(a, b), lanes(n)));
+    }
+    // a > b as a broadcast bit.  w = 64: unsigned (obig_cmp); w = 32: signed.
+    static GC_HD W gt(B &be, W a, W b, int w) {
+        if (w == 32) { a = be.NOTm(a, 1ull << 31); b = be.NOTm(b, 1ull << 31); }
+        W ge_ba;
+        (void)sub(be, b, a, w, &ge_ba);           // b >= a
+        return be.NOTm(ge_ba, ~0ull);
+    }
+    static GC_HD W vmax(B &be, W a, W b, int w) { return mux(be, gt(be, a, b, w), a, b, w); }
+
+    // carry-save step: (S, C) += X over n lanes (mod 2^n).  cin_lane0 is XORed
+    // into lane 0 of the new carry word (always free); cout gets the carry out
+    // of lane n-1 placed in lane 0 (others zero) when requested.
+    static GC_HD void csa(B &be, W &S, W &C, W X, int n, W cin_lane0, W *cout) {
+        const uint64_t act = lanes(n);
+        W t = be.AND(be.XOR(S, X), be.XOR(C, X), act);
+        W carry = be.XOR(t, be.sel(act, X, be.zero()));
+        S = be.XOR(be.XOR(S, C), X);
+        if (cout) *cout = be.sel(1ull, be.shr(carry, n - 1), be.zero());
+        C = be.XOR(be.sel(act, be.shl(carry, 1), be.zero()), cin_lane0);
+    }
+    static GC_HD void csa(B &be, W &S, W &C, W X, int n) { csa(be, S, C, X, n, be.zero(), (W *)0); }
+
+    // ---- signed w x w carry-save array multiplier, product kept mod 2^(w+p).
+    //   L      : product bits 0..w-1 (resolved)
+    //   S, C   : S + C = product bits w..w+p-1 (lanes 0..p-1, others zero)
+    // Baugh-Wooley sign handling: partial products of the last row / last lane
+    // are inverted and the constant 2^w is injected as an initial carry.
+    static GC_HD void mul_core(B &be, W a, W b, int w, int p, W &L, W &S, W &C) {
+        const int M = w + p;
+        S = be.zero();
+        L = be.zero();
+        C = (p >= 1) ? be.konst(1ull << (w - 1)) : be.zero();
+        for (int r = 0; r < w; r++) {
+            const int na = (M - r) < w ? (M - r) : w;
+            const uint64_t act = lanes(na);
+            W bb = be.bcast(b, r);
+            W pp = be.AND(a, bb, act);
+            uint64_t inv = (r == w - 1) ? lanes(w - 1) : (1ull << (w - 1));
+            pp = be.NOTm(pp, inv & act);
+            if (r == 0) {
+                S = pp;
+            } else {
+                W t = be.AND(be.XOR(S, pp), be.XOR(C, pp), act);
+                W Sn = be.XOR(be.XOR(S, C), pp);
+                C = be.XOR(t, pp);
+                S = Sn;
+            }
+            L = be.sel(1ull << r, be.bcast(S, 0), L);
+            S = be.shr(S, 1);
+        }
+        S = be.sel(lanes(p), S, be.zero());
+        C = be.sel(lanes(p), C, be.zero());
+    }
+    // X + Y = wrap_w((a*b) >> p)
+    static GC_HD void mul_xy(B &be, W a, W b, int w, int p, W &X, W &Y) {
+        W L, S, C;
+        mul_core(be, a, b, w, p, L, S, C);
+        const uint64_t act = lanes(w);
+        X = be.XOR(be.sel(act, be.shr(L, p), be.zero()), be.sel(act, be.shl(S, w - p), be.zero()));
+        Y = be.sel(act, be.shl(C, w - p), be.zero());
+    }
+    static GC_HD W mul(B &be, W a, W b, int w, int p) {
+        W X, Y;
+        mul_xy(be, a, b, w, p, X, Y);
+        return add(be, X, Y, w);
+    }
+    // (AS, AC) += wrap_w((a*b) >> p), carry-save, mod 2^w
+    static GC_HD void mac(B &be, W &AS, W &AC, W a, W b, int w, int p) {
+        W X, Y;
+        mul_xy(be, a, b, w, p, X, Y);
+        csa(be, AS, AC, X, w);
+        csa(be, AS, AC, Y, w);
+    }
+
+    // ---- wide inner-product accumulator: sum of exact products mod 2^(w+p)
+    struct IpAcc { W LS, LC, HS, HC; };
+    static GC_HD void ip_zero(B &be, IpAcc &A) { A.LS = A.LC = A.HS = A.HC = be.zero(); }
+    static GC_HD void ip_mac(B &be, IpAcc &A, W a, W b, int w, int p) {
+        W L, S, C, co;
+        mul_core(be, a, b, w, p, L, S, C);
+        csa(be, A.LS, A.LC, L, w, be.zero(), &co);
+        if (p > 0) {
+            csa(be, A.HS, A.HC, S, p, co, (W *)0);
+            csa(be, A.HS, A.HC, C, p);
+        }
+    }
+    static GC_HD void ip_merge(B &be, IpAcc &A, const IpAcc &O, int w, int p) {
+        W c1, c2;
+        csa(be, A.LS, A.LC, O.LS, w, be.zero(), &c1);
+        csa(be, A.LS, A.LC, O.LC, w, be.zero(), &c2);
+        if (p > 0) {
+            csa(be, A.HS, A.HC, O.HS, p, c1, (W *)0);
+            csa(be, A.HS, A.HC, O.HC, p, c2, (W *)0);
+        }
+    }
+    // wrap_w(sum >> p)
+    static GC_HD W ip_final(B &be, const IpAcc &A, int w, int p) {
+        W cl;
+        W lo = add(be, A.LS, A.LC, w, be.zero(), &cl);
+        W hi = (p > 0) ? add(be, A.HS, A.HC, p, be.sel(1ull, cl, be.zero()), (W *)0) : be.zero();
+        const uint64_t act = lanes(w);
+        return be.XOR(be.sel(act, be.shr(lo, p), be.zero()), be.sel(act, be.shl(hi, w - p), be.zero()));
+    }
+
+    // ---- restoring divider: wrap_w(tdiv(a << p, b)), truncation toward zero.
+    // b == 0 gives an all-ones magnitude (-1 for a >= 0, +1 for a < 0).
+    static GC_HD W div(B &be, W a, W b, int w, int p) {
+        const int M = w + p;
+        const uint64_t act = lanes(w);
+        W sa = be.bcast(a, w - 1), sb = be.bcast(b, w - 1);
+        W ua = condneg(be, a, sa, w), ub = condneg(be, b, sb, w);
+        W nub = be.NOTm(ub, act);
+        W one = be.konst(1);
+        W R = be.zero(), Q = be.zero();
+        for (int k = M - 1; k >= 0; k--) {
+            R = be.sel(act, be.shl(R, 1), be.zero());
+            if (k >= p) R = be.XOR(R, be.sel(1ull, be.bcast(ua, k - p), be.zero()));
+            W co;
+            W T = add(be, R, nub, w, one, &co);      // R - |b|, co = (R >= |b|)
+            R = mux(be, co, T, R, w);
+            if (k < w) Q = be.sel(1ull << k, co, Q);
+        }
+        return condneg(be, Q, be.XOR(sa, sb), w);
+    }
+
+    // ---- square root.  w = 64: floor(sqrt(a_u * 2^p)), digit-by-digit with a
+    // shifting remainder (needs w + p <= 124).  w = 32: the explicit loop of
+    // src/fixed.oc:228-240 on the low (32+p) bits, mirrored literally.
+    static GC_HD W vsqrt(B &be, W a, int w, int p) {
+        const int M = w + p;
+        if (w == 32) {
+            const uint64_t mk = lanes(M);
+            W x = be.sel(mk, be.shl(be.sel(lanes(32), a, be.zero()), p), be.zero());
+            W r = be.zero();
+            for (int t = M - 2; t >= 0; t -= 2) {
+                W re = be.NOTm(r, 1ull << t);            // r + e == r | e
+                W co;
+                W xs = sub(be, x, re, M, &co);           // co = (x >= r + e)
+                x = mux(be, co, xs, x, M);
+                r = be.sel(1ull << t, co, be.shr(r, 1)); // (r >> 1) + (co ? e : 0)
+            }
+            return be.sel(lanes(32), r, be.zero());
+        }
+        const int n = (M + 1) / 2;                       // root bits
+        const int rb = n + 2;                            // remainder / trial width
+        W R = be.zero(), Q = be.zero();
+        for (int i = n - 1; i >= 0; i--) {
+            // R = (R << 2) | V[2i+1 : 2i], V = a << p
+            R = be.sel(lanes(rb), be.shl(R, 2), be.zero());
+            int hi = 2 * i + 1 - p, lo = 2 * i - p;
+            if (hi >= 0 && hi < w) R = be.XOR(R, be.sel(2ull, be.bcast(a, hi), be.zero()));
+            if (lo >= 0 && lo < w) R = be.XOR(R, be.sel(1ull, be.bcast(a, lo), be.zero()));
+            W Tt = be.NOTm(be.sel(lanes(rb), be.shl(Q, 2), be.zero()), 1ull);  // 4Q + 1
+            W co;
+            W Rs = sub(be, R, Tt, rb, &co);
+            R = mux(be, co, Rs, R, rb);
+            Q = be.XOR(be.sel(lanes(rb), be.shl(Q, 1), be.zero()), be.sel(1ull, co, be.zero()));
+        }
+        return be.sel(lanes(w), Q, be.zero());
+    }
+};
+
+// ---- host-side plaintext backend: circuit logic checks + step/gate counting
+struct PlainBackend {
+    typedef uint64_t W;
+    uint64_t steps, gates;
+    PlainBackend() : steps(0), gates(0) {}
+    GC_HD W zero() const { return 0; }
+    GC_HD W konst(uint64_t bits) const { return bits; }
+    GC_HD W XOR(W a, W b) const { return a ^ b; }
+    GC_HD W NOTm(W a, uint64_t m) const { return a ^ m; }
+    GC_HD W AND(W a, W b, uint64_t act) {
+        steps++;
+        gates += (uint64_t)__builtin_popcountll(act);
+        return a & b & act;
+    }
+    GC_HD W shl(W a, int k) const { return k >= 64 ? 0 : a << k; }
+    GC_HD W shr(W a, int k) const { return k >= 64 ? 0 : a >> k; }
+    GC_HD W bcast(W a, int lane) const { return ((a >> lane) & 1) ? ~0ull : 0ull; }
+    GC_HD W sel(uint64_t m, W a, W b) const { return (a & m) | (b & ~m); }
+};
+
+}  // namespace gc

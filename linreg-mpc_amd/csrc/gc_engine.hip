@@ -1,0 +1,465 @@
+// gc_engine.hip -- host engine + C ABI (include/linreg_gc.h) of the MI355X
+// garbled-circuit path.  Device code: gc_device.h.  Circuits: gc_circuits.h.
+// Program lowering: gc_program.h.  No CPU fallback: without a HIP device every
+// compute entry point returns LGC_ENODEVICE.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/linreg_gc.h"
+#include "gc_device.h"
+#include "gc_program.h"
+
+using namespace gc;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(x)                                                                               \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) return fail(LGC_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *lgc_last_error(void) { return g_err; }
+extern "C" const char *lgc_version(void) { return "linreg-mpc_amd gc engine r1 (gfx950, half-gates, LDS T-table AES)"; }
+extern "C" int lgc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int need_device(int device) {
+    int n = lgc_device_count();
+    if (n <= 0) return fail(LGC_ENODEVICE, "no HIP device visible: the garbled-circuit engine has no CPU fallback");
+    if (device < 0 || device >= n) return fail(LGC_EINVAL, "device %d out of range (%d visible)", device, n);
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(LGC_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+    return LGC_OK;
+}
+
+// ---------------------------------------------------------------- constants
+static AesTables g_tabs;
+static bool g_tabs_built = false;
+static const AesTables &tables() {
+    if (!g_tabs_built) { aes_build_tables(g_tabs, kFixedKey); g_tabs_built = true; }
+    return g_tabs;
+}
+static int upload_constants() {
+    const AesTables &t = tables();
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rk), t.rk, sizeof(t.rk)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_te0), t.te0, sizeof(t.te0)));
+    return LGC_OK;
+}
+
+// host-side hash with the fixed key (used to derive R from the seed)
+static Lbl host_hash(Lbl x, uint64_t tweak) {
+    HostTab ht = {tables().te0};
+    Lbl out;
+    hash_n<1, HostTab>(ht, tables().rk, &x, &tweak, &out);
+    return out;
+}
+
+// ------------------------------------------------------------------ kernels
+// fresh input labels: zero-label from a seeded PRG, evaluator side gets the
+// label of the actual bit (what the OT / direct transfer would deliver)
+__global__ void __launch_bounds__(256)
+gc_input_kernel(Lbl *wordsG, Lbl *wordsE, const uint64_t *vals, uint32_t base, uint32_t n, Lbl R, Lbl seed, int w) {
+    __shared__ uint32_t lds_te0[kLdsTabWords];
+    lds_tab_fill(lds_te0);
+    const int lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= n) return;
+    LdsTab lt;
+    lt.base = lds_te0 + (lane & 31);
+    const uint32_t id = base + k;
+    uint64_t tw = 0x8000000000000000ull | ((uint64_t)id * 64 + (uint64_t)lane);
+    Lbl z;
+    hash_n<1, LdsTab>(lt, c_rk, &seed, &tw, &z);
+    if (lane >= w) z = lzero();
+    uint32_t bit = (uint32_t)(vals[k] >> lane) & 1u;
+    if (lane >= w) bit = 0;
+    st_lbl(wordsG + (size_t)id * 64 + lane, z);
+    st_lbl(wordsE + (size_t)id * 64 + lane, lxor(z, lmask(R, bit)));
+}
+
+__global__ void __launch_bounds__(256)
+gc_aes_bench_kernel(uint32_t *out, int blocks_per_lane) {
+    __shared__ uint32_t lds_te0[kLdsTabWords];
+    lds_tab_fill(lds_te0);
+    const int lane = threadIdx.x & 63;
+    LdsTab lt;
+    lt.base = lds_te0 + (lane & 31);
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s[4][4];
+    for (int b = 0; b < 4; b++) { s[b][0] = gid; s[b][1] = b; s[b][2] = gid * 2654435761u; s[b][3] = 0x9e3779b9u ^ b; }
+    for (int i = 0; i < blocks_per_lane; i += 4) aes_encrypt_n<4, LdsTab>(lt, c_rk, s);
+    uint32_t acc = 0;
+    for (int b = 0; b < 4; b++) acc ^= s[b][0] ^ s[b][1] ^ s[b][2] ^ s[b][3];
+    out[gid] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+gc_aes_encrypt_kernel(const uint4 *in, uint4 *out, uint32_t n) {
+    __shared__ uint32_t lds_te0[kLdsTabWords];
+    lds_tab_fill(lds_te0);
+    const int lane = threadIdx.x & 63;
+    LdsTab lt;
+    lt.base = lds_te0 + (lane & 31);
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 v = in[i];
+    uint32_t s[1][4] = {{v.x, v.y, v.z, v.w}};
+    aes_encrypt_n<1, LdsTab>(lt, c_rk, s);
+    out[i] = make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
+}
+
+// ------------------------------------------------------------------ program
+struct lgc_program {
+    Program P;
+};
+
+static int check_system(const lgc_system *sys) {
+    if (!sys) return fail(LGC_EINVAL, "null system");
+    if (sys->width != 32 && sys->width != 64) return fail(LGC_EINVAL, "width must be 32 or 64");
+    if (sys->precision < 0 || sys->precision >= sys->width)
+        return fail(LGC_EINVAL, "precision must satisfy 0 <= p < width (src/cmd/linreg.c:85-88)");
+    if (sys->d < 1 || sys->d > 4096) return fail(LGC_EINVAL, "d out of range");
+    if (sys->nshares < 1) return fail(LGC_EINVAL, "nshares must be >= 1");
+    if (sys->algorithm < 0 || sys->algorithm > 2) return fail(LGC_EINVAL, "Algorithm must be cholesky, ldlt, or cgd.");
+    if (sys->algorithm == LGC_ALG_CGD && sys->num_iterations < 0) return fail(LGC_EINVAL, "negative iteration count");
+    if (sys->algorithm == LGC_ALG_CHOLESKY && sys->width == 64 && sys->precision > 60)
+        return fail(LGC_EINVAL, "cholesky at width 64 supports precision <= 60 (square-root datapath is 64 lanes)");
+    return LGC_OK;
+}
+
+// (fixed_t)(lambda * (1ll << p)) -- src/fixed.c:3-5 via src/linear.oc:52
+static uint64_t lambda_to_fixed(double lambda, int p, int w) {
+    double t = lambda * (double)(1ll << p);
+    if (w == 32) {
+        if (!(t > -2147483649.0 && t < 2147483648.0)) return (uint64_t)(uint32_t)INT32_MIN;
+        return (uint64_t)(uint32_t)(int32_t)t;
+    }
+    if (!(t >= -9223372036854775808.0 && t < 9223372036854775808.0)) return (uint64_t)INT64_MIN;
+    return (uint64_t)(int64_t)t;
+}
+
+static void build(Program &P, const lgc_system *sys) {
+    int iters = sys->algorithm == LGC_ALG_CGD ? sys->num_iterations : 0;
+    build_program(P, sys->algorithm, sys->d, sys->width, sys->precision, iters, sys->nshares, sys->normalize,
+                  lambda_to_fixed(sys->lambda, sys->precision, sys->width), sys->reveal_inputs, sys->trace);
+}
+
+extern "C" int lgc_program_build(lgc_program **out, const lgc_system *sys) {
+    int rc = check_system(sys);
+    if (rc) return rc;
+    if (!out) return fail(LGC_EINVAL, "null out");
+    lgc_program *p = new lgc_program();
+    build(p->P, sys);
+    *out = p;
+    return LGC_OK;
+}
+extern "C" void lgc_program_destroy(lgc_program *p) { delete p; }
+extern "C" int lgc_program_info_get(const lgc_program *p, lgc_program_info *info) {
+    if (!p || !info) return fail(LGC_EINVAL, "null argument");
+    const Program &P = p->P;
+    info->n_records = P.recs.size();
+    info->n_launches = P.launches.size();
+    info->n_words = P.n_words;
+    info->n_reveal = P.n_reveal;
+    info->in_base = P.in_base;
+    info->rv_beta = P.rv_beta;
+    info->rv_trace = P.rv_trace;
+    info->rv_inputs = P.rv_ab;
+    info->total_steps = P.total_steps;
+    info->total_gates = P.total_gates;
+    info->max_launch_steps = P.max_launch_steps;
+    return LGC_OK;
+}
+static_assert(sizeof(lgc_record) == sizeof(Rec), "record layout");
+extern "C" const lgc_record *lgc_program_records(const lgc_program *p) {
+    return reinterpret_cast<const lgc_record *>(p->P.recs.data());
+}
+static std::vector<lgc_launch> g_launch_tmp;
+extern "C" const lgc_launch *lgc_program_launches(const lgc_program *p) {
+    g_launch_tmp.resize(p->P.launches.size());
+    for (size_t i = 0; i < g_launch_tmp.size(); i++) {
+        const Launch &L = p->P.launches[i];
+        lgc_launch o = {L.first_rec, L.nrec, L.step0, L.steps, L.gates, L.mac_only ? 1 : 0};
+        g_launch_tmp[i] = o;
+    }
+    return g_launch_tmp.data();
+}
+
+// ------------------------------------------------------------------- solver
+struct lgc_solver {
+    lgc_system sys;
+    Program P;
+    int device;
+    Lbl R, seed;
+    Lbl *wordsG, *wordsE, *tab;
+    uint64_t *decG, *decE, *vals;
+    Rec *recs;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    std::vector<hipEvent_t> evs;
+    std::vector<uint64_t> hG, hE;
+    bool have_shares, ran;
+    lgc_stats st;
+    lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), ev0(0), ev1(0),
+                   have_shares(false), ran(false) { memset(&st, 0, sizeof(st)); }
+};
+
+extern "C" void lgc_solver_destroy(lgc_solver *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->wordsG) (void)hipFree(s->wordsG);
+    if (s->wordsE) (void)hipFree(s->wordsE);
+    if (s->tab) (void)hipFree(s->tab);
+    if (s->decG) (void)hipFree(s->decG);
+    if (s->decE) (void)hipFree(s->decE);
+    if (s->vals) (void)hipFree(s->vals);
+    if (s->recs) (void)hipFree(s->recs);
+    for (size_t i = 0; i < s->evs.size(); i++) (void)hipEventDestroy(s->evs[i]);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" int lgc_solver_create(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16]) {
+    int rc = check_system(sys);
+    if (rc) return rc;
+    if (!out || !seed) return fail(LGC_EINVAL, "null argument");
+    rc = need_device(device);
+    if (rc) return rc;
+    rc = upload_constants();
+    if (rc) return rc;
+    lgc_solver *s = new lgc_solver();
+    s->sys = *sys;
+    s->device = device;
+    build(s->P, sys);
+    memcpy(&s->seed, seed, 16);
+    s->R = host_hash(s->seed, 0x52ull << 56);   // 'R'
+    s->R.x |= 1u;                               // point-and-permute: lsb(R) = 1
+    const Program &P = s->P;
+    size_t wbytes = (size_t)P.n_words * 64 * sizeof(Lbl);
+    size_t tbytes = (size_t)P.max_launch_steps * 128 * sizeof(Lbl);
+    size_t nin = P.nshares * (P.T + P.d);
+#define TRY(x)                                                                                   \
+    do {                                                                                         \
+        hipError_t e_ = (x);                                                                     \
+        if (e_ != hipSuccess) {                                                                  \
+            fail(e_ == hipErrorOutOfMemory ? LGC_ENOMEM : LGC_EHIP, "%s: %s", #x, hipGetErrorString(e_)); \
+            lgc_solver_destroy(s);                                                               \
+            return e_ == hipErrorOutOfMemory ? LGC_ENOMEM : LGC_EHIP;                            \
+        }                                                                                        \
+    } while (0)
+    TRY(hipStreamCreate(&s->stream));
+    TRY(hipEventCreate(&s->ev0));
+    TRY(hipEventCreate(&s->ev1));
+    TRY(hipMalloc(&s->wordsG, wbytes));
+    TRY(hipMalloc(&s->wordsE, wbytes));
+    TRY(hipMalloc(&s->tab, tbytes ? tbytes : 16));
+    TRY(hipMalloc(&s->decG, (P.n_reveal + 1) * sizeof(uint64_t)));
+    TRY(hipMalloc(&s->decE, (P.n_reveal + 1) * sizeof(uint64_t)));
+    TRY(hipMalloc(&s->vals, nin * sizeof(uint64_t)));
+    TRY(hipMalloc(&s->recs, P.recs.size() * sizeof(Rec)));
+    TRY(hipMemcpy(s->recs, P.recs.data(), P.recs.size() * sizeof(Rec), hipMemcpyHostToDevice));
+#undef TRY
+    s->hG.resize(P.n_reveal + 1);
+    s->hE.resize(P.n_reveal + 1);
+    *out = s;
+    return LGC_OK;
+}
+
+extern "C" int lgc_solver_set_shares(lgc_solver *s, const uint64_t *shares) {
+    if (!s || !shares) return fail(LGC_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(s->device));
+    size_t nin = s->P.nshares * (s->P.T + s->P.d);
+    HIPCHK(hipMemcpy(s->vals, shares, nin * sizeof(uint64_t), hipMemcpyHostToDevice));
+    s->have_shares = true;
+    return LGC_OK;
+}
+
+template <bool G, bool MAC>
+static void launch_exec(lgc_solver *s, const Launch &L, Lbl *words, uint64_t *dec) {
+    dim3 grid((L.nrec + 3) / 4), block(256);
+    hipLaunchKernelGGL((gc_exec_kernel<G, MAC>), grid, block, 0, s->stream, s->recs + L.first_rec, L.nrec, words,
+                       s->tab, dec, L.step0, s->R, s->P.w, s->P.p);
+}
+
+extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
+    if (!s) return fail(LGC_EINVAL, "null solver");
+    if (!s->have_shares) return fail(LGC_ESTATE, "lgc_solver_set_shares has not been called");
+    HIPCHK(hipSetDevice(s->device));
+    const Program &P = s->P;
+    size_t wbytes = (size_t)P.n_words * 64 * sizeof(Lbl);
+    size_t nin = P.nshares * (P.T + P.d);
+    const size_t nl = P.launches.size();
+    // events: 3 per launch (before garble, between, after evaluate) for MAC launches
+    // always; for every launch when profiling
+    size_t need_ev = 3 * nl;
+    while (s->evs.size() < need_ev) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        s->evs.push_back(e);
+    }
+    HIPCHK(hipEventRecord(s->ev0, s->stream));
+    HIPCHK(hipMemsetAsync(s->wordsG, 0, wbytes, s->stream));
+    HIPCHK(hipMemsetAsync(s->wordsE, 0, wbytes, s->stream));
+    HIPCHK(hipMemsetAsync(s->decG, 0, (P.n_reveal + 1) * sizeof(uint64_t), s->stream));
+    HIPCHK(hipMemsetAsync(s->decE, 0, (P.n_reveal + 1) * sizeof(uint64_t), s->stream));
+    {
+        dim3 grid((unsigned)((nin + 3) / 4)), block(256);
+        hipLaunchKernelGGL(gc_input_kernel, grid, block, 0, s->stream, s->wordsG, s->wordsE, s->vals, P.in_base,
+                           (uint32_t)nin, s->R, s->seed, P.w);
+    }
+    for (size_t i = 0; i < nl; i++) {
+        const Launch &L = P.launches[i];
+        bool timed = profile || L.mac_only;
+        if (timed) HIPCHK(hipEventRecord(s->evs[3 * i], s->stream));
+        if (L.mac_only) launch_exec<true, true>(s, L, s->wordsG, s->decG);
+        else launch_exec<true, false>(s, L, s->wordsG, s->decG);
+        if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], s->stream));
+        if (L.mac_only) launch_exec<false, true>(s, L, s->wordsE, s->decE);
+        else launch_exec<false, false>(s, L, s->wordsE, s->decE);
+        if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 2], s->stream));
+    }
+    HIPCHK(hipMemcpyAsync(s->hG.data(), s->decG, (P.n_reveal + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(s->hE.data(), s->decE, (P.n_reveal + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipEventRecord(s->ev1, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipGetLastError());
+    lgc_stats &st = s->st;
+    memset(&st, 0, sizeof(st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    st.seconds_total = ms * 1e-3;
+    st.and_gates = P.total_gates;
+    st.gate_steps = P.total_steps;
+    st.table_bytes = P.total_steps * 128 * sizeof(Lbl);
+    st.launches = nl;
+    for (size_t i = 0; i < nl; i++) {
+        const Launch &L = P.launches[i];
+        if (!(profile || L.mac_only)) continue;
+        float g = 0, e = 0;
+        HIPCHK(hipEventElapsedTime(&g, s->evs[3 * i], s->evs[3 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&e, s->evs[3 * i + 1], s->evs[3 * i + 2]));
+        st.seconds_garble += g * 1e-3;
+        st.seconds_eval += e * 1e-3;
+        if (L.mac_only) {
+            st.seconds_mac_garble += g * 1e-3;
+            st.seconds_mac_eval += e * 1e-3;
+            st.mac_gates += L.gates;
+            st.mac_launches++;
+        }
+    }
+    s->ran = true;
+    return LGC_OK;
+}
+
+static int64_t decode_word(const lgc_solver *s, uint32_t slot) {
+    uint64_t v = s->hG[slot] ^ s->hE[slot];
+    if (s->P.w == 32) return (int64_t)(int32_t)(uint32_t)v;
+    return (int64_t)v;
+}
+
+extern "C" int lgc_solver_get_beta(lgc_solver *s, int64_t *beta) {
+    if (!s || !beta) return fail(LGC_EINVAL, "null argument");
+    if (!s->ran) return fail(LGC_ESTATE, "solver has not run");
+    for (size_t i = 0; i < s->P.d; i++) beta[i] = decode_word(s, s->P.rv_beta + (uint32_t)i);
+    return LGC_OK;
+}
+extern "C" int lgc_solver_get_trace(lgc_solver *s, int64_t *trace) {
+    if (!s || !trace) return fail(LGC_EINVAL, "null argument");
+    if (!s->ran) return fail(LGC_ESTATE, "solver has not run");
+    if (s->P.rv_trace == ~0u) return fail(LGC_ESTATE, "trace was not requested");
+    size_t n = (size_t)s->sys.num_iterations * (s->P.d + 4);
+    for (size_t i = 0; i < n; i++) trace[i] = decode_word(s, s->P.rv_trace + (uint32_t)i);
+    return LGC_OK;
+}
+extern "C" int lgc_solver_get_inputs(lgc_solver *s, int64_t *ab) {
+    if (!s || !ab) return fail(LGC_EINVAL, "null argument");
+    if (!s->ran) return fail(LGC_ESTATE, "solver has not run");
+    if (s->P.rv_ab == ~0u) return fail(LGC_ESTATE, "input reveal was not requested");
+    for (size_t i = 0; i < s->P.T + s->P.d; i++) ab[i] = decode_word(s, s->P.rv_ab + (uint32_t)i);
+    return LGC_OK;
+}
+extern "C" int lgc_solver_get_stats(lgc_solver *s, lgc_stats *st) {
+    if (!s || !st) return fail(LGC_EINVAL, "null argument");
+    *st = s->st;
+    return LGC_OK;
+}
+
+extern "C" int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[16], const uint64_t *shares,
+                         int64_t *beta, int64_t *trace, lgc_stats *stats) {
+    lgc_solver *s = 0;
+    int rc = lgc_solver_create(&s, device, sys, seed);
+    if (rc) return rc;
+    rc = lgc_solver_set_shares(s, shares);
+    if (!rc) rc = lgc_solver_run(s, 0);
+    if (!rc && beta) rc = lgc_solver_get_beta(s, beta);
+    if (!rc && trace && sys->trace && sys->algorithm == LGC_ALG_CGD) rc = lgc_solver_get_trace(s, trace);
+    if (!rc && stats) rc = lgc_solver_get_stats(s, stats);
+    lgc_solver_destroy(s);
+    return rc;
+}
+
+// --------------------------------------------------------- micro-benchmarks
+extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double *rate, uint32_t *check) {
+    int rc = need_device(device);
+    if (rc) return rc;
+    rc = upload_constants();
+    if (rc) return rc;
+    if (waves < 4 || blocks_per_lane < 4) return fail(LGC_EINVAL, "waves >= 4 and blocks_per_lane >= 4 required");
+    blocks_per_lane &= ~3;
+    int nblk = waves / 4;
+    uint32_t *out = 0;
+    HIPCHK(hipMalloc(&out, (size_t)nblk * 256 * 4));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    hipLaunchKernelGGL(gc_aes_bench_kernel, dim3(nblk), dim3(256), 0, 0, out, 4);   // warm-up
+    HIPCHK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL(gc_aes_bench_kernel, dim3(nblk), dim3(256), 0, 0, out, blocks_per_lane);
+    HIPCHK(hipEventRecord(b, 0));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    std::vector<uint32_t> h((size_t)nblk * 256);
+    HIPCHK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
+    uint32_t c = 0;
+    for (size_t i = 0; i < h.size(); i++) c ^= h[i];
+    if (check) *check = c;
+    if (rate) *rate = (double)nblk * 256.0 * (double)blocks_per_lane / (ms * 1e-3);
+    (void)hipFree(out);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return LGC_OK;
+}
+
+extern "C" int lgc_aes_encrypt(int device, const uint8_t *in, uint8_t *out, size_t n) {
+    int rc = need_device(device);
+    if (rc) return rc;
+    rc = upload_constants();
+    if (rc) return rc;
+    uint4 *di = 0, *dout = 0;
+    HIPCHK(hipMalloc(&di, n * 16));
+    HIPCHK(hipMalloc(&dout, n * 16));
+    HIPCHK(hipMemcpy(di, in, n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(gc_aes_encrypt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, di, dout, (uint32_t)n);
+    HIPCHK(hipMemcpy(out, dout, n * 16, hipMemcpyDeviceToHost));
+    (void)hipFree(di);
+    (void)hipFree(dout);
+    return LGC_OK;
+}

@@ -1,0 +1,159 @@
+// gc_exec.h -- the record format of the garbled word machine and its
+// backend-generic interpreter.
+//
+// A *program* is a list of launches; a launch is an array of records; one
+// record is executed by one wavefront (lane = bit).  Records of one launch are
+// independent; launches run in order.  Garbler and evaluator execute the same
+// program; the garbler writes two 16-byte ciphertexts per active lane and
+// step into the launch's table buffer, the evaluator reads them back.
+//
+// Words live in a "word file": word id -> 64 labels (1 KiB, lane-major), so a
+// wave loads/stores a word as one coalesced 1 KiB access (global_load_dwordx4).
+#pragma once
+#include <stdint.h>
+
+#include "gc_circuits.h"
+
+namespace gc {
+
+enum Op : uint32_t {
+    OP_NOP = 0,
+    OP_MAC,     // (S,C) = sum_{k<cnt} mul(a+k*sa, b+k*sb), carry-save; S->dst, C->dst+1
+    OP_SUM,     // dst = sum_{k<cnt} words[a+k*sa]                      (mod 2^w)
+    OP_SUBSUM,  // dst = words[c] - sum_{k<cnt} words[a+k*sa]
+    OP_IPMAC,   // IpAcc = sum_{k<cnt} (a+k*sa)*(b+k*sb) exact; 4 words -> dst..dst+3
+    OP_IPFIN,   // dst = wrap((sum of cnt IpAcc at a+4k) >> p)
+    OP_MUL,     // dst = mul(a, b)
+    OP_MULSUB,  // dst = words[c] - mul(a, b)
+    OP_ADD,     // dst = a + b
+    OP_SUB,     // dst = a - b
+    OP_ABS,     // dst = |a|
+    OP_MAX,     // dst = max_{k<cnt} words[a+k*sa]   (ordering of Circ::gt)
+    OP_DIV,     // dst = div(a, b)
+    OP_SQRT,    // dst = sqrt(a)
+    OP_IDIVC,   // dst = tdiv(a, public constant c)   (linear.oc:52-65, normalizer)
+    OP_CONST,   // dst = public constant (a = low 32 bits, b = high 32 bits)
+    OP_COPY,    // dst = a
+    OP_REVEAL,  // decode[dst] = colour bits of word a (cnt unused)
+    OP_COUNT_
+};
+
+struct Rec {
+    uint32_t op, cnt;
+    uint32_t dst, a, b, c;
+    int32_t sa, sb;
+    uint64_t step0;   // global index of this record's first gate step
+};
+
+// number of gate steps / active AND gates of one record (host side)
+inline void rec_cost(const Rec &r, int w, int p, uint64_t &steps, uint64_t &gates);
+
+// Backend extras required here: load(id) / store(id, W) / reveal(slot, W).
+template <class B>
+GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
+    typedef Circ<B> C;
+    typedef typename B::W W;
+    switch (r.op) {
+    case OP_MAC: {
+        W S = be.zero(), Cc = be.zero();
+        for (uint32_t k = 0; k < r.cnt; k++)
+            C::mac(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
+        be.store(r.dst, S);
+        be.store(r.dst + 1, Cc);
+    } break;
+    case OP_SUM:
+    case OP_SUBSUM: {
+        W S = be.load(r.a), Cc = be.zero();
+        for (uint32_t k = 1; k < r.cnt; k++) C::csa(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), w);
+        W v = (r.cnt > 1) ? C::add(be, S, Cc, w) : S;
+        if (r.op == OP_SUBSUM) v = C::sub(be, be.load(r.c), v, w);
+        be.store(r.dst, v);
+    } break;
+    case OP_IPMAC: {
+        typename C::IpAcc A;
+        C::ip_zero(be, A);
+        for (uint32_t k = 0; k < r.cnt; k++)
+            C::ip_mac(be, A, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
+        be.store(r.dst, A.LS); be.store(r.dst + 1, A.LC);
+        be.store(r.dst + 2, A.HS); be.store(r.dst + 3, A.HC);
+    } break;
+    case OP_IPFIN: {
+        typename C::IpAcc A, O;
+        A.LS = be.load(r.a); A.LC = be.load(r.a + 1); A.HS = be.load(r.a + 2); A.HC = be.load(r.a + 3);
+        for (uint32_t k = 1; k < r.cnt; k++) {
+            uint32_t o = r.a + 4 * k;
+            O.LS = be.load(o); O.LC = be.load(o + 1); O.HS = be.load(o + 2); O.HC = be.load(o + 3);
+            C::ip_merge(be, A, O, w, p);
+        }
+        be.store(r.dst, C::ip_final(be, A, w, p));
+    } break;
+    case OP_MUL:
+        be.store(r.dst, C::mul(be, be.load(r.a), be.load(r.b), w, p));
+        break;
+    case OP_MULSUB: {
+        W X, Y;
+        C::mul_xy(be, be.load(r.a), be.load(r.b), w, p, X, Y);
+        W v = C::add(be, X, Y, w);
+        be.store(r.dst, C::sub(be, be.load(r.c), v, w));
+    } break;
+    case OP_ADD:
+        be.store(r.dst, C::add(be, be.load(r.a), be.load(r.b), w));
+        break;
+    case OP_SUB:
+        be.store(r.dst, C::sub(be, be.load(r.a), be.load(r.b), w));
+        break;
+    case OP_ABS:
+        be.store(r.dst, C::vabs(be, be.load(r.a), w));
+        break;
+    case OP_MAX: {
+        W m = be.load(r.a);
+        for (uint32_t k = 1; k < r.cnt; k++) m = C::vmax(be, be.load(r.a + (int32_t)k * r.sa), m, w);
+        be.store(r.dst, m);
+    } break;
+    case OP_DIV:
+        be.store(r.dst, C::div(be, be.load(r.a), be.load(r.b), w, p));
+        break;
+    case OP_SQRT:
+        be.store(r.dst, C::vsqrt(be, be.load(r.a), w, p));
+        break;
+    case OP_IDIVC:
+        be.store(r.dst, C::div(be, be.load(r.a), be.konst((uint64_t)r.c), w, 0));
+        break;
+    case OP_CONST:
+        be.store(r.dst, be.sel(lanes(w), be.konst((uint64_t)r.a | ((uint64_t)r.b << 32)), be.zero()));
+        break;
+    case OP_COPY:
+        be.store(r.dst, be.load(r.a));
+        break;
+    case OP_REVEAL:
+        be.reveal(r.dst, be.load(r.a));
+        break;
+    default:
+        break;
+    }
+}
+
+// PlainBackend with a word file: host-side cost model and plaintext checks
+struct PlainMachine : PlainBackend {
+    uint64_t *words;
+    uint64_t *decode;
+    PlainMachine(uint64_t *w_, uint64_t *d_) : words(w_), decode(d_) {}
+    W load(uint32_t id) const { return words[id]; }
+    void store(uint32_t id, W v) { words[id] = v; }
+    void reveal(uint32_t slot, W v) { if (decode) decode[slot] = v; }
+};
+
+// cost of a record: run it on a scratch plaintext machine (the circuits'
+// control flow is data-independent, so any operand values give the counts)
+inline void rec_cost(const Rec &r, int w, int p, uint64_t &steps, uint64_t &gates) {
+    struct CostMachine : PlainBackend {
+        W load(uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
+        void store(uint32_t, W) {}
+        void reveal(uint32_t, W) {}
+    } m;
+    exec_record(m, r, w, p);
+    steps = m.steps;
+    gates = m.gates;
+}
+
+}  // namespace gc

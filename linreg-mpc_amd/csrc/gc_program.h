@@ -1,0 +1,388 @@
+// gc_program.h -- host-side lowering of the phase-2 solvers to launches of
+// word-machine records (no device code here).
+//
+// Follows, statement by statement:
+//   input assembly  src/linear.oc:10-94 (data providers) / :96-135 (two-party)
+//   cgd             src/cgd.oc:96-212
+//   cholesky        src/cholesky.oc:51-93
+//   ldlt            src/ldlt.oc:50-90
+// Wrap-around additions are re-associated freely (tree / carry-save sums):
+// addition mod 2^w is associative, so results are identical.
+#pragma once
+#include <stdint.h>
+
+#include <map>
+#include <utility>
+#include <vector>
+
+#include "gc_exec.h"
+
+namespace gc {
+
+struct Launch {
+    uint32_t first_rec, nrec;   // slice of Program::recs
+    uint64_t step0, steps;      // gate steps covered
+    uint64_t gates;             // active AND gates
+    bool mac_only;
+};
+
+enum Alg { ALG_CHOLESKY = 0, ALG_LDLT = 1, ALG_CGD = 2 };
+
+struct Program {
+    int w, p;
+    size_t d, T, nshares;
+    std::vector<Rec> recs;
+    std::vector<Launch> launches;
+    uint32_t n_words;            // word file size
+    uint32_t n_reveal;           // decode slots
+    uint32_t in_base;            // first input word: nshares x (T + d), share-major
+    uint32_t rv_beta;            // decode slot of beta[0]
+    uint32_t rv_trace;           // decode slot of trace[0] (cgd: iters x (d+4)), or ~0u
+    uint32_t rv_ab;              // decode slot of the debug reveal of a, b (T + d), or ~0u
+    uint64_t total_steps, total_gates;
+    uint64_t max_launch_steps;
+
+    // ---- builder state
+    uint64_t cap_steps;          // split launches above this many steps
+    uint64_t step_cursor;
+    std::map<std::pair<uint32_t, uint32_t>, std::pair<uint64_t, uint64_t>> cost_cache;
+    bool open;
+
+    Program() : w(64), p(56), d(0), T(0), nshares(0), n_words(1), n_reveal(0), in_base(0), rv_beta(0),
+                rv_trace(~0u), rv_ab(~0u), total_steps(0), total_gates(0), max_launch_steps(0),
+                cap_steps(1ull << 21), step_cursor(0), open(false) {}
+
+    uint32_t alloc(size_t n) { uint32_t r = n_words; n_words += (uint32_t)n; return r; }
+    uint32_t alloc_reveal(size_t n) { uint32_t r = n_reveal; n_reveal += (uint32_t)n; return r; }
+
+    void cost(const Rec &r, uint64_t &steps, uint64_t &gates) {
+        // cost depends on (op, cnt) only (and on c for nothing: IDIVC uses a constant word)
+        std::pair<uint32_t, uint32_t> key(r.op, r.cnt);
+        auto it = cost_cache.find(key);
+        if (it == cost_cache.end()) {
+            uint64_t s, g;
+            rec_cost(r, w, p, s, g);
+            it = cost_cache.insert(std::make_pair(key, std::make_pair(s, g))).first;
+        }
+        steps = it->second.first;
+        gates = it->second.second;
+    }
+
+    void new_launch() { open = false; }
+
+    void emit(Rec r) {
+        uint64_t s, g;
+        cost(r, s, g);
+        bool mac = (r.op == OP_MAC);
+        if (!open || launches.back().steps + s > cap_steps || launches.back().mac_only != mac) {
+            Launch L;
+            L.first_rec = (uint32_t)recs.size();
+            L.nrec = 0;
+            L.step0 = step_cursor;
+            L.steps = 0;
+            L.gates = 0;
+            L.mac_only = mac;
+            launches.push_back(L);
+            open = true;
+        }
+        Launch &L = launches.back();
+        r.step0 = step_cursor;
+        recs.push_back(r);
+        L.nrec++;
+        L.steps += s;
+        L.gates += g;
+        step_cursor += s;
+        total_steps += s;
+        total_gates += g;
+        if (L.steps > max_launch_steps) max_launch_steps = L.steps;
+    }
+
+    static Rec mk(uint32_t op, uint32_t dst, uint32_t a = 0, uint32_t b = 0, uint32_t c = 0, uint32_t cnt = 1,
+                  int32_t sa = 1, int32_t sb = 1) {
+        Rec r;
+        r.op = op; r.cnt = cnt; r.dst = dst; r.a = a; r.b = b; r.c = c; r.sa = sa; r.sb = sb; r.step0 = 0;
+        return r;
+    }
+
+    // dst = max over n words at src (stride 1) and the constant-zero word; tree of OP_MAX
+    void max_tree(uint32_t dst, uint32_t src, size_t n, uint32_t scratch) {
+        const size_t fan = 8;
+        uint32_t cur = src;
+        size_t cnt = n;
+        uint32_t buf = scratch;
+        new_launch();
+        while (cnt > fan) {
+            size_t groups = (cnt + fan - 1) / fan;
+            for (size_t g = 0; g < groups; g++) {
+                size_t len = (g + 1) * fan <= cnt ? fan : cnt - g * fan;
+                emit(mk(OP_MAX, buf + (uint32_t)g, cur + (uint32_t)(g * fan), 0, 0, (uint32_t)len));
+            }
+            new_launch();
+            cur = buf;
+            buf += (uint32_t)groups;
+            cnt = groups;
+        }
+        // last level also folds in the initial ng = 0 (cgd.oc:98-101,140)
+        uint32_t tmp = buf;
+        emit(mk(OP_MAX, tmp, cur, 0, 0, (uint32_t)cnt));
+        new_launch();
+        emit(mk(OP_MAX, dst, tmp, 0, 0, 2, -(int32_t)tmp));  // words[tmp], words[0] (= const zero)
+        new_launch();
+    }
+    static size_t max_tree_scratch(size_t n) { return n / 4 + 16; }
+
+    // dot products in carry-save form, chunked so that a launch has enough waves.
+    // result words: dst[i] = base[i] - sum_k A[i][k]*B[k]  (subtract) or  = sum (no base)
+    struct DotJob { uint32_t dst, base, a, b; uint32_t len; bool has_base; };
+    void dots(const std::vector<DotJob> &jobs, uint32_t scratch, size_t target_waves) {
+        size_t total = 0;
+        for (size_t i = 0; i < jobs.size(); i++) total += jobs[i].len;
+        if (total == 0) return;
+        size_t chunk = (total + target_waves - 1) / target_waves;
+        if (chunk < 1) chunk = 1;
+        new_launch();
+        std::vector<std::pair<uint32_t, uint32_t>> parts(jobs.size());  // (first partial word, count of words)
+        uint32_t cur = scratch;
+        for (size_t i = 0; i < jobs.size(); i++) {
+            const DotJob &J = jobs[i];
+            parts[i].first = cur;
+            uint32_t nparts = 0;
+            for (uint32_t k0 = 0; k0 < J.len; k0 += (uint32_t)chunk) {
+                uint32_t len = J.len - k0 < chunk ? J.len - k0 : (uint32_t)chunk;
+                emit(mk(OP_MAC, cur, J.a + k0, J.b + k0, 0, len));
+                cur += 2;
+                nparts += 2;
+            }
+            parts[i].second = nparts;
+        }
+        new_launch();
+        for (size_t i = 0; i < jobs.size(); i++) {
+            const DotJob &J = jobs[i];
+            if (J.len == 0) continue;
+            if (J.has_base) emit(mk(OP_SUBSUM, J.dst, parts[i].first, 0, J.base, parts[i].second));
+            else emit(mk(OP_SUM, J.dst, parts[i].first, 0, 0, parts[i].second));
+        }
+        new_launch();
+    }
+    static size_t dots_scratch(size_t total_products, size_t njobs, size_t target_waves) {
+        size_t chunk = (total_products + target_waves - 1) / target_waves;
+        if (chunk < 1) chunk = 1;
+        return 2 * (total_products / chunk + njobs + 2) + 16;
+    }
+
+    // wide inner product (fixed.oc:124-147)
+    void inner(uint32_t dst, uint32_t a, uint32_t b, size_t n, uint32_t scratch) {
+        size_t chunk = n >= 256 ? 8 : (n >= 32 ? 4 : 1);
+        uint32_t cur = scratch;
+        uint32_t nparts = 0;
+        new_launch();
+        for (size_t k0 = 0; k0 < n; k0 += chunk) {
+            uint32_t len = (uint32_t)(n - k0 < chunk ? n - k0 : chunk);
+            emit(mk(OP_IPMAC, cur, a + (uint32_t)k0, b + (uint32_t)k0, 0, len));
+            cur += 4;
+            nparts++;
+        }
+        new_launch();
+        emit(mk(OP_IPFIN, dst, scratch, 0, 0, nparts));
+        new_launch();
+    }
+    static size_t inner_scratch(size_t n) { return 4 * n + 16; }
+};
+
+// target number of concurrent waves for the big dot-product launches
+static const size_t kTargetWaves = 12288;
+
+// Build the whole phase-2 program.
+//   normalize = 1: data-provider path (linear.oc:52-65): diag += lambda, off-diag and b divided by d
+//   normalize = 0: two-party benchmark path (linear.oc:96-135): a = in1 + in2, nothing else
+//   reveal_ab: debug reveal of a and b (linear.oc:68-84)
+inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters, size_t nshares,
+                          int normalize, uint64_t lambda_fixed, int reveal_ab, int trace) {
+    P.w = w; P.p = p; P.d = d; P.nshares = nshares;
+    const size_t T = d * (d + 1) / 2;
+    P.T = T;
+    const uint32_t D = (uint32_t)d;
+    // word 0 is the constant zero (the word file starts zeroed on both sides)
+    P.in_base = P.alloc(nshares * (T + d));
+    const uint32_t M = P.alloc(d * d);       // full symmetric storage, M[i*d+j] == M[j*d+i]
+    const uint32_t bv = P.alloc(d);
+    auto Mi = [&](size_t i, size_t j) { return M + (uint32_t)(i * d + j); };
+    auto idx = [](size_t i, size_t j) { return (uint32_t)(i * (i + 1) / 2 + j); };
+
+    // ---- a[ij] = sum of shares (linear.oc:31-49 / :116-127)
+    P.new_launch();
+    for (size_t i = 0; i < d; i++)
+        for (size_t j = 0; j <= i; j++)
+            P.emit(Program::mk(OP_SUM, Mi(i, j), P.in_base + idx(i, j), 0, 0, (uint32_t)nshares, (int32_t)(T + d)));
+    for (size_t i = 0; i < d; i++)
+        P.emit(Program::mk(OP_SUM, bv + (uint32_t)i, P.in_base + (uint32_t)(T + i), 0, 0, (uint32_t)nshares,
+                           (int32_t)(T + d)));
+    P.new_launch();
+    if (normalize) {
+        const uint32_t lam = P.alloc(1);
+        P.emit(Program::mk(OP_CONST, lam, (uint32_t)lambda_fixed, (uint32_t)(lambda_fixed >> 32)));
+        P.new_launch();
+        for (size_t i = 0; i < d; i++)
+            for (size_t j = 0; j <= i; j++) {
+                if (i == j) P.emit(Program::mk(OP_ADD, Mi(i, j), Mi(i, j), lam));
+                else P.emit(Program::mk(OP_IDIVC, Mi(i, j), Mi(i, j), 0, D));
+            }
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_IDIVC, bv + (uint32_t)i, bv + (uint32_t)i, 0, D));
+        P.new_launch();
+    }
+    // mirror the lower triangle
+    for (size_t i = 0; i < d; i++)
+        for (size_t j = 0; j < i; j++) P.emit(Program::mk(OP_COPY, Mi(j, i), Mi(i, j)));
+    P.new_launch();
+    if (reveal_ab) {
+        P.rv_ab = P.alloc_reveal(T + d);
+        for (size_t i = 0; i < d; i++)
+            for (size_t j = 0; j <= i; j++) P.emit(Program::mk(OP_REVEAL, P.rv_ab + idx(i, j), Mi(i, j)));
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_REVEAL, P.rv_ab + (uint32_t)(T + i), bv + (uint32_t)i));
+        P.new_launch();
+    }
+
+    if (alg == ALG_CGD) {
+        const uint32_t x = P.alloc(d), g = P.alloc(d), pv = P.alloc(d), gscl = P.alloc(d), pA = P.alloc(d),
+                       tabs = P.alloc(d);
+        const uint32_t ng = P.alloc(1), q = P.alloc(1), gp = P.alloc(1), eta = P.alloc(1), gamma = P.alloc(1),
+                       gAp = P.alloc(1);
+        const uint32_t sc_max = P.alloc(Program::max_tree_scratch(d));
+        const uint32_t sc_ip = P.alloc(Program::inner_scratch(d));
+        const uint32_t sc_dot = P.alloc(Program::dots_scratch(d * d, d, kTargetWaves));
+        if (trace) P.rv_trace = P.alloc_reveal((size_t)iters * (d + 4));
+        // cgd.oc:96-106
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_SUB, g + (uint32_t)i, 0, bv + (uint32_t)i));
+        P.new_launch();
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_ABS, tabs + (uint32_t)i, g + (uint32_t)i));
+        P.max_tree(ng, tabs, d, sc_max);
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_DIV, pv + (uint32_t)i, g + (uint32_t)i, ng));
+        P.new_launch();
+        for (int it = 0; it < iters; it++) {
+            // pA = A p  (cgd.oc:119-125)
+            std::vector<Program::DotJob> jobs(d);
+            for (size_t i = 0; i < d; i++) {
+                Program::DotJob J = {pA + (uint32_t)i, 0, Mi(i, 0), pv, D, false};
+                jobs[i] = J;
+            }
+            P.dots(jobs, sc_dot, kTargetWaves);
+            P.inner(q, pA, pv, d, sc_ip);            // :128
+            P.inner(gp, g, pv, d, sc_ip);            // :130
+            P.emit(Program::mk(OP_DIV, eta, gp, q)); // :133
+            P.new_launch();
+            for (size_t i = 0; i < d; i++) {         // :141-145
+                P.emit(Program::mk(OP_MULSUB, x + (uint32_t)i, pv + (uint32_t)i, eta, x + (uint32_t)i));
+                P.emit(Program::mk(OP_MULSUB, g + (uint32_t)i, eta, pA + (uint32_t)i, g + (uint32_t)i));
+            }
+            P.new_launch();
+            for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_ABS, tabs + (uint32_t)i, g + (uint32_t)i));
+            P.max_tree(ng, tabs, d, sc_max);         // :140,146-149
+            for (size_t i = 0; i < d; i++)           // :153-155
+                P.emit(Program::mk(OP_DIV, gscl + (uint32_t)i, g + (uint32_t)i, ng));
+            P.new_launch();
+            P.inner(gAp, pA, gscl, d, sc_ip);        // :157
+            P.emit(Program::mk(OP_DIV, gamma, gAp, q));  // :159
+            P.new_launch();
+            for (size_t i = 0; i < d; i++)           // :162-165
+                P.emit(Program::mk(OP_MULSUB, pv + (uint32_t)i, pv + (uint32_t)i, gamma, gscl + (uint32_t)i));
+            P.new_launch();
+            if (trace) {                             // reveals at :167-189
+                uint32_t base = P.rv_trace + (uint32_t)((size_t)it * (d + 4));
+                for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_REVEAL, base + (uint32_t)i, x + (uint32_t)i));
+                P.emit(Program::mk(OP_REVEAL, base + D, gamma));
+                P.emit(Program::mk(OP_REVEAL, base + D + 1, eta));
+                P.emit(Program::mk(OP_REVEAL, base + D + 2, q));
+                P.emit(Program::mk(OP_REVEAL, base + D + 3, ng));
+                P.new_launch();
+            }
+        }
+        P.rv_beta = P.alloc_reveal(d);
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_REVEAL, P.rv_beta + (uint32_t)i, x + (uint32_t)i));
+        P.new_launch();
+    } else if (alg == ALG_CHOLESKY) {
+        const uint32_t y = P.alloc(d), beta = P.alloc(d);
+        const uint32_t sc_dot = P.alloc(Program::dots_scratch(d * d, d, 4096) + 4 * d);
+        for (size_t j = 0; j < d; j++) {             // cholesky.oc:51-65
+            if (j > 0) {
+                std::vector<Program::DotJob> jobs;
+                for (size_t i = j; i < d; i++) {
+                    Program::DotJob J = {Mi(i, j), Mi(i, j), Mi(i, 0), Mi(j, 0), (uint32_t)j, true};
+                    jobs.push_back(J);
+                }
+                P.dots(jobs, sc_dot, 4096);
+            }
+            P.emit(Program::mk(OP_SQRT, Mi(j, j), Mi(j, j)));
+            P.new_launch();
+            for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_DIV, Mi(k, j), Mi(k, j), Mi(j, j)));
+            P.new_launch();
+            for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_COPY, Mi(j, k), Mi(k, j)));
+            P.new_launch();
+        }
+        for (size_t i = 0; i < d; i++) {             // :68-76
+            if (i > 0) {
+                std::vector<Program::DotJob> jobs(1);
+                Program::DotJob J = {bv + (uint32_t)i, bv + (uint32_t)i, Mi(i, 0), y, (uint32_t)i, true};
+                jobs[0] = J;
+                P.dots(jobs, sc_dot, 64);
+            }
+            P.emit(Program::mk(OP_DIV, y + (uint32_t)i, bv + (uint32_t)i, Mi(i, i)));
+            P.new_launch();
+        }
+        for (size_t ii = d; ii-- > 0;) {             // :79-87
+            if (ii + 1 < d) {
+                std::vector<Program::DotJob> jobs(1);
+                Program::DotJob J = {y + (uint32_t)ii, y + (uint32_t)ii, Mi(ii, ii + 1), beta + (uint32_t)(ii + 1),
+                                     (uint32_t)(d - 1 - ii), true};
+                jobs[0] = J;
+                P.dots(jobs, sc_dot, 64);
+            }
+            P.emit(Program::mk(OP_DIV, beta + (uint32_t)ii, y + (uint32_t)ii, Mi(ii, ii)));
+            P.new_launch();
+        }
+        P.rv_beta = P.alloc_reveal(d);
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_REVEAL, P.rv_beta + (uint32_t)i, beta + (uint32_t)i));
+        P.new_launch();
+    } else {  // ALG_LDLT
+        const uint32_t tv = P.alloc(d);
+        const uint32_t sc_dot = P.alloc(Program::dots_scratch(d * d, d, 4096) + 4 * d);
+        for (size_t j = 0; j < d; j++) {             // ldlt.oc:50-64
+            if (j > 0) {
+                for (size_t k = 0; k < j; k++) P.emit(Program::mk(OP_MUL, tv + (uint32_t)k, Mi(j, k), Mi(k, k)));
+                P.new_launch();
+                std::vector<Program::DotJob> jobs;
+                for (size_t i = j; i < d; i++) {
+                    Program::DotJob J = {Mi(i, j), Mi(i, j), Mi(i, 0), tv, (uint32_t)j, true};
+                    jobs.push_back(J);
+                }
+                P.dots(jobs, sc_dot, 4096);
+            }
+            for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_DIV, Mi(k, j), Mi(k, j), Mi(j, j)));
+            P.new_launch();
+            for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_COPY, Mi(j, k), Mi(k, j)));
+            P.new_launch();
+        }
+        for (size_t i = 1; i < d; i++) {             // :67-73
+            std::vector<Program::DotJob> jobs(1);
+            Program::DotJob J = {bv + (uint32_t)i, bv + (uint32_t)i, Mi(i, 0), bv, (uint32_t)i, true};
+            jobs[0] = J;
+            P.dots(jobs, sc_dot, 64);
+        }
+        for (size_t i = 0; i < d; i++)               // :76-79
+            P.emit(Program::mk(OP_DIV, bv + (uint32_t)i, bv + (uint32_t)i, Mi(i, i)));
+        P.new_launch();
+        for (size_t ii = d; ii-- > 0;) {             // :82-90
+            if (ii + 1 < d) {
+                std::vector<Program::DotJob> jobs(1);
+                Program::DotJob J = {bv + (uint32_t)ii, bv + (uint32_t)ii, Mi(ii, ii + 1), bv + (uint32_t)(ii + 1),
+                                     (uint32_t)(d - 1 - ii), true};
+                jobs[0] = J;
+                P.dots(jobs, sc_dot, 64);
+            }
+        }
+        P.rv_beta = P.alloc_reveal(d);
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_REVEAL, P.rv_beta + (uint32_t)i, bv + (uint32_t)i));
+        P.new_launch();
+    }
+}
+
+}  // namespace gc

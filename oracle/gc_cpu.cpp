@@ -1,0 +1,335 @@
+// gc_cpu.cpp -- CPU checker / baseline for the garbled word machine.
+// TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's
+// cpu_baseline leg).  The product (linreg-mpc_amd/) never links this.
+//
+// It runs the very same records (gc_exec.h) and circuits (gc_circuits.h) as
+// the GPU kernels, but on host cores:
+//   * gcc_plain_run   : plaintext bits, no crypto -- checks the lowering
+//                       (gc_program.h) against the semantic oracle
+//   * gcc_garble_run / gcc_eval_run : half-gates with AES-NI, gate for gate the
+//                       protocol of gc_device.h (same hash, tweaks, table
+//                       layout), so tables and labels are comparable bit for
+//                       bit with the GPU's; this is also the "port" CPU
+//                       baseline: one thread per role processes gates in
+//                       program order, the execution structure of the
+//                       reference's Obliv-C runtime.
+// The reference's own runtime (Obliv-C + absentminded-crypto-kit) cannot be
+// built here: gate-level parity with it is "unpinned".
+#include <immintrin.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <wmmintrin.h>
+
+#include <vector>
+
+#include "../linreg-mpc_amd/csrc/gc_aes.h"
+#include "../linreg-mpc_amd/csrc/gc_exec.h"
+
+using namespace gc;
+
+static AesTables g_t;
+static __m128i g_rk[11];
+static bool g_init = false;
+static void init() {
+    if (g_init) return;
+    aes_build_tables(g_t, kFixedKey);
+    for (int i = 0; i < 11; i++) g_rk[i] = _mm_loadu_si128((const __m128i *)&g_t.rk[4 * i]);
+    g_init = true;
+}
+
+template <int N>
+static inline void aesni_n(__m128i s[N]) {
+    for (int b = 0; b < N; b++) s[b] = _mm_xor_si128(s[b], g_rk[0]);
+    for (int r = 1; r < 10; r++)
+        for (int b = 0; b < N; b++) s[b] = _mm_aesenc_si128(s[b], g_rk[r]);
+    for (int b = 0; b < N; b++) s[b] = _mm_aesenclast_si128(s[b], g_rk[10]);
+}
+// sigma(x) ^ tweak  (gc_aes.h: hash_prep)
+static inline __m128i hprep(__m128i x, uint64_t tw) {
+    __m128i sw = _mm_shuffle_epi32(x, 0x4E);                          // (x2,x3,x0,x1)
+    __m128i hi = _mm_and_si128(x, _mm_set_epi32(-1, -1, 0, 0));       // (0,0,x2,x3)
+    __m128i s = _mm_xor_si128(sw, hi);                                // (x2,x3,x0^x2,x1^x3)
+    return _mm_xor_si128(s, _mm_set_epi64x(0, (long long)tw));
+}
+
+struct W64 {
+    __m128i l[64];
+};
+
+template <bool GARBLER>
+struct CpuBackend {
+    typedef W64 W;
+    __m128i R;
+    __m128i *words;
+    __m128i *tab;
+    uint64_t *decode;
+    uint64_t step, launch_step0;
+    uint64_t gates;
+
+    W zero() const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_setzero_si128(); return r; }
+    W konst(uint64_t bits) const {
+        W r;
+        for (int i = 0; i < 64; i++) r.l[i] = (GARBLER && ((bits >> i) & 1)) ? R : _mm_setzero_si128();
+        return r;
+    }
+    W XOR(const W &a, const W &b) const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_xor_si128(a.l[i], b.l[i]); return r; }
+    W NOTm(const W &a, uint64_t m) const {
+        if (!GARBLER) return a;
+        W r;
+        for (int i = 0; i < 64; i++) r.l[i] = ((m >> i) & 1) ? _mm_xor_si128(a.l[i], R) : a.l[i];
+        return r;
+    }
+    W sel(uint64_t m, const W &a, const W &b) const { W r; for (int i = 0; i < 64; i++) r.l[i] = ((m >> i) & 1) ? a.l[i] : b.l[i]; return r; }
+    W bcast(const W &a, int src) const { W r; for (int i = 0; i < 64; i++) r.l[i] = a.l[src]; return r; }
+    W shl(const W &a, int k) const { W r; for (int i = 0; i < 64; i++) r.l[i] = (i - k >= 0 && k < 64) ? a.l[i - k] : _mm_setzero_si128(); return r; }
+    W shr(const W &a, int k) const { W r; for (int i = 0; i < 64; i++) r.l[i] = (i + k < 64 && k < 64) ? a.l[i + k] : _mm_setzero_si128(); return r; }
+    W AND(const W &a, const W &b, uint64_t act) {
+        W c;
+        __m128i *slot = tab + (step - launch_step0) * 128;
+        for (int lane = 0; lane < 64; lane++) {
+            if (!((act >> lane) & 1)) { c.l[lane] = _mm_setzero_si128(); continue; }
+            const uint64_t gid = step * 64 + (uint64_t)lane;
+            gates++;
+            if (GARBLER) {
+                __m128i a0 = a.l[lane], b0 = b.l[lane];
+                __m128i k[4] = {hprep(a0, 2 * gid), hprep(_mm_xor_si128(a0, R), 2 * gid),
+                                hprep(b0, 2 * gid + 1), hprep(_mm_xor_si128(b0, R), 2 * gid + 1)};
+                __m128i h[4] = {k[0], k[1], k[2], k[3]};
+                aesni_n<4>(h);
+                for (int i = 0; i < 4; i++) h[i] = _mm_xor_si128(h[i], k[i]);
+                const int pa = _mm_cvtsi128_si32(a0) & 1, pb = _mm_cvtsi128_si32(b0) & 1;
+                __m128i TG = _mm_xor_si128(_mm_xor_si128(h[0], h[1]), pb ? R : _mm_setzero_si128());
+                __m128i WG = _mm_xor_si128(h[0], pa ? TG : _mm_setzero_si128());
+                __m128i TE = _mm_xor_si128(_mm_xor_si128(h[2], h[3]), a0);
+                __m128i WE = _mm_xor_si128(h[2], pb ? _mm_xor_si128(TE, a0) : _mm_setzero_si128());
+                _mm_storeu_si128(slot + lane, TG);
+                _mm_storeu_si128(slot + 64 + lane, TE);
+                c.l[lane] = _mm_xor_si128(WG, WE);
+            } else {
+                __m128i av = a.l[lane], bv = b.l[lane];
+                __m128i TG = _mm_loadu_si128(slot + lane), TE = _mm_loadu_si128(slot + 64 + lane);
+                __m128i k[2] = {hprep(av, 2 * gid), hprep(bv, 2 * gid + 1)};
+                __m128i h[2] = {k[0], k[1]};
+                aesni_n<2>(h);
+                h[0] = _mm_xor_si128(h[0], k[0]);
+                h[1] = _mm_xor_si128(h[1], k[1]);
+                const int sa = _mm_cvtsi128_si32(av) & 1, sb = _mm_cvtsi128_si32(bv) & 1;
+                __m128i WG = _mm_xor_si128(h[0], sa ? TG : _mm_setzero_si128());
+                __m128i WE = _mm_xor_si128(h[1], sb ? _mm_xor_si128(TE, av) : _mm_setzero_si128());
+                c.l[lane] = _mm_xor_si128(WG, WE);
+            }
+        }
+        step++;
+        return c;
+    }
+    W load(uint32_t id) const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_loadu_si128(words + (size_t)id * 64 + i); return r; }
+    void store(uint32_t id, const W &v) { for (int i = 0; i < 64; i++) _mm_storeu_si128(words + (size_t)id * 64 + i, v.l[i]); }
+    void reveal(uint32_t slot, const W &v) {
+        uint64_t m = 0;
+        for (int i = 0; i < 64; i++) m |= (uint64_t)(_mm_cvtsi128_si32(v.l[i]) & 1) << i;
+        if (decode) decode[slot] = m;
+    }
+};
+
+extern "C" {
+
+// ---- plaintext execution of records (checks the program lowering)
+int gcc_plain_run(const Rec *recs, size_t nrec, int w, int p, uint64_t *words, uint64_t *decode,
+                  uint64_t *steps, uint64_t *gates) {
+    PlainMachine m(words, decode);
+    for (size_t i = 0; i < nrec; i++) {
+        if (recs[i].step0 != m.steps) return 1;   // the builder's step accounting must match execution
+        exec_record(m, recs[i], w, p);
+    }
+    if (steps) *steps = m.steps;
+    if (gates) *gates = m.gates;
+    return 0;
+}
+
+void gcc_derive_R(const uint8_t seed[16], uint8_t out[16]) {
+    init();
+    __m128i s = _mm_loadu_si128((const __m128i *)seed);
+    __m128i k = hprep(s, 0x52ull << 56);
+    __m128i h[1] = {k};
+    aesni_n<1>(h);
+    h[0] = _mm_xor_si128(h[0], k);
+    h[0] = _mm_or_si128(h[0], _mm_set_epi32(0, 0, 0, 1));
+    _mm_storeu_si128((__m128i *)out, h[0]);
+}
+
+// mirror of gc_input_kernel (gc_engine.hip)
+void gcc_input_labels(const uint8_t seed[16], const uint8_t R[16], const uint64_t *vals, uint32_t base, uint32_t n,
+                      int w, uint8_t *wordsG, uint8_t *wordsE) {
+    init();
+    __m128i s = _mm_loadu_si128((const __m128i *)seed), r = _mm_loadu_si128((const __m128i *)R);
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t id = base + k;
+        for (int lane = 0; lane < 64; lane++) {
+            uint64_t tw = 0x8000000000000000ull | ((uint64_t)id * 64 + (uint64_t)lane);
+            __m128i kk = hprep(s, tw);
+            __m128i h[1] = {kk};
+            aesni_n<1>(h);
+            __m128i z = _mm_xor_si128(h[0], kk);
+            int bit = (int)((vals[k] >> lane) & 1);
+            if (lane >= w) { z = _mm_setzero_si128(); bit = 0; }
+            _mm_storeu_si128((__m128i *)wordsG + (size_t)id * 64 + lane, z);
+            if (wordsE) _mm_storeu_si128((__m128i *)wordsE + (size_t)id * 64 + lane, bit ? _mm_xor_si128(z, r) : z);
+        }
+    }
+}
+
+// run records [0, nrec) of one or more launches on one thread
+uint64_t gcc_garble_run(const Rec *recs, size_t nrec, int w, int p, const uint8_t R[16], uint8_t *words,
+                        uint8_t *tab, uint64_t *decode, uint64_t launch_step0) {
+    init();
+    CpuBackend<true> be;
+    be.R = _mm_loadu_si128((const __m128i *)R);
+    be.words = (__m128i *)words;
+    be.tab = (__m128i *)tab;
+    be.decode = decode;
+    be.launch_step0 = launch_step0;
+    be.gates = 0;
+    for (size_t i = 0; i < nrec; i++) {
+        be.step = recs[i].step0;
+        exec_record(be, recs[i], w, p);
+    }
+    return be.gates;
+}
+uint64_t gcc_eval_run(const Rec *recs, size_t nrec, int w, int p, uint8_t *words, uint8_t *tab, uint64_t *decode,
+                      uint64_t launch_step0) {
+    init();
+    CpuBackend<false> be;
+    be.R = _mm_setzero_si128();
+    be.words = (__m128i *)words;
+    be.tab = (__m128i *)tab;
+    be.decode = decode;
+    be.launch_step0 = launch_step0;
+    be.gates = 0;
+    for (size_t i = 0; i < nrec; i++) {
+        be.step = recs[i].step0;
+        exec_record(be, recs[i], w, p);
+    }
+    return be.gates;
+}
+
+void gcc_aes_encrypt(const uint8_t *in, uint8_t *out, size_t n) {
+    init();
+    for (size_t i = 0; i < n; i++) {
+        __m128i s[1] = {_mm_loadu_si128((const __m128i *)in + i)};
+        aesni_n<1>(s);
+        _mm_storeu_si128((__m128i *)out + i, s[0]);
+    }
+}
+// portable T-table path of gc_aes.h on the host (the algorithm the GPU runs)
+void gcc_aes_encrypt_ttable(const uint8_t *in, uint8_t *out, size_t n) {
+    init();
+    HostTab ht = {g_t.te0};
+    for (size_t i = 0; i < n; i++) {
+        uint32_t s[1][4];
+        memcpy(s[0], in + 16 * i, 16);
+        aes_encrypt_n<1, HostTab>(ht, g_t.rk, s);
+        memcpy(out + 16 * i, s[0], 16);
+    }
+}
+void gcc_hash(const uint8_t x[16], uint64_t tweak, uint8_t out[16]) {
+    init();
+    Lbl l;
+    memcpy(&l, x, 16);
+    HostTab ht = {g_t.te0};
+    Lbl o;
+    hash_n<1, HostTab>(ht, g_t.rk, &l, &tweak, &o);
+    memcpy(out, &o, 16);
+}
+
+// ---- CPU baseline: garbler thread + evaluator thread over `nprod` products of
+// the dominant unit (one OP_MAC record of `chunk` products each), evaluator
+// following the garbler record by record (in-process hand-off of the table
+// chunk).  Returns AND gates per second (garble + evaluate, wall clock).
+struct BaseCtx {
+    std::vector<Rec> recs;
+    int w, p;
+    uint8_t R[16];
+    uint8_t *wordsG, *wordsE, *tab;
+    volatile size_t garbled;   // records finished by the garbler
+    volatile size_t evaluated; // records finished by the evaluator
+    uint64_t rec_steps;        // gate steps per record
+    uint64_t gatesG, gatesE;
+};
+static const size_t kRing = 8;  // table hand-off ring: the garbler runs at most kRing records ahead
+static void *base_garbler(void *v) {
+    BaseCtx *c = (BaseCtx *)v;
+    uint64_t g = 0;
+    for (size_t i = 0; i < c->recs.size(); i++) {
+        while (i >= c->evaluated + kRing) _mm_pause();
+        g += gcc_garble_run(&c->recs[i], 1, c->w, c->p, c->R, c->wordsG,
+                            c->tab + (i % kRing) * c->rec_steps * 2048, 0, c->recs[i].step0);
+        __sync_synchronize();
+        c->garbled = i + 1;
+    }
+    c->gatesG = g;
+    return 0;
+}
+static void *base_evaluator(void *v) {
+    BaseCtx *c = (BaseCtx *)v;
+    uint64_t g = 0;
+    for (size_t i = 0; i < c->recs.size(); i++) {
+        while (c->garbled <= i) _mm_pause();
+        __sync_synchronize();
+        g += gcc_eval_run(&c->recs[i], 1, c->w, c->p, c->wordsE, c->tab + (i % kRing) * c->rec_steps * 2048, 0,
+                          c->recs[i].step0);
+        __sync_synchronize();
+        c->evaluated = i + 1;
+    }
+    c->gatesE = g;
+    return 0;
+}
+double gcc_baseline_mac(int w, int p, uint32_t nrec, uint32_t chunk, uint64_t *and_gates, double *seconds) {
+    init();
+    BaseCtx c;
+    c.w = w; c.p = p;
+    c.garbled = 0;
+    c.evaluated = 0;
+    for (int i = 0; i < 16; i++) c.R[i] = (uint8_t)(0x3d * (i + 7));
+    c.R[0] |= 1;
+    // word file: word 0 zero, a-words 1..chunk, b-words chunk+1..2chunk, outputs after
+    uint32_t nwords = 1 + 2 * chunk + 2 * nrec;
+    c.wordsG = (uint8_t *)aligned_alloc(64, (size_t)nwords * 1024);
+    c.wordsE = (uint8_t *)aligned_alloc(64, (size_t)nwords * 1024);
+    std::vector<uint64_t> vals(2 * chunk);
+    uint64_t x = 0x9e3779b97f4a7c15ull;
+    for (size_t i = 0; i < vals.size(); i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; vals[i] = x; }
+    memset(c.wordsG, 0, (size_t)nwords * 1024);
+    memset(c.wordsE, 0, (size_t)nwords * 1024);
+    uint8_t seed[16] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+    gcc_input_labels(seed, c.R, vals.data(), 1, 2 * chunk, w, c.wordsG, c.wordsE);
+    uint64_t steps = 0, gates = 0, step_cursor = 0;
+    for (uint32_t i = 0; i < nrec; i++) {
+        Rec r;
+        r.op = OP_MAC; r.cnt = chunk; r.dst = 1 + 2 * chunk + 2 * i; r.a = 1; r.b = 1 + chunk; r.c = 0;
+        r.sa = 1; r.sb = 1; r.step0 = step_cursor;
+        if (i == 0) rec_cost(r, w, p, steps, gates);
+        step_cursor += steps;
+        c.recs.push_back(r);
+    }
+    c.rec_steps = steps;
+    c.tab = (uint8_t *)aligned_alloc(64, (size_t)steps * 2048 * kRing);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    pthread_t tg, te;
+    pthread_create(&tg, 0, base_garbler, &c);
+    pthread_create(&te, 0, base_evaluator, &c);
+    pthread_join(tg, 0);
+    pthread_join(te, 0);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    double sec = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    // self-check: decoded accumulators agree between the roles up to R (colour bits)
+    free(c.wordsG); free(c.wordsE); free(c.tab);
+    if (and_gates) *and_gates = c.gatesG;
+    if (seconds) *seconds = sec;
+    return (double)c.gatesG / sec;
+}
+
+}  // extern "C"

@@ -14,6 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python"))
 
 
 def pytest_configure(config):
@@ -31,6 +32,22 @@ def _make(target_dir, target):
 def oracle():
     import orc
     return orc.load()
+
+
+@pytest.fixture(scope="session")
+def gccpu():
+    import gccpu as g
+    return g.load()
+
+
+@pytest.fixture(scope="session")
+def lgc():
+    """the product binding; builds liblinreg_gc.so in-tree if it is missing"""
+    so = os.path.join(ROOT, "linreg-mpc_amd", "csrc", "liblinreg_gc.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.dirname(so)])
+    import linreg_gc
+    return linreg_gc
 
 
 @pytest.fixture(scope="session")

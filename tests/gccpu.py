@@ -1,0 +1,89 @@
+"""ctypes binding of oracle/libgc_cpu.so (CPU checker; test infrastructure)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class GcCpu:
+    def __init__(self, lib):
+        self.lib = L = lib
+        vp, ci, sz, u64, u32 = C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.c_uint32
+        L.gcc_plain_run.restype = ci
+        L.gcc_plain_run.argtypes = [vp, sz, ci, ci, vp, vp, C.POINTER(u64), C.POINTER(u64)]
+        L.gcc_derive_R.argtypes = [C.c_char_p, vp]
+        L.gcc_input_labels.argtypes = [C.c_char_p, vp, vp, u32, u32, ci, vp, vp]
+        L.gcc_garble_run.restype = u64
+        L.gcc_garble_run.argtypes = [vp, sz, ci, ci, vp, vp, vp, vp, u64]
+        L.gcc_eval_run.restype = u64
+        L.gcc_eval_run.argtypes = [vp, sz, ci, ci, vp, vp, vp, u64]
+        L.gcc_aes_encrypt.argtypes = [vp, vp, sz]
+        L.gcc_aes_encrypt_ttable.argtypes = [vp, vp, sz]
+        L.gcc_hash.argtypes = [vp, u64, vp]
+        L.gcc_baseline_mac.restype = C.c_double
+        L.gcc_baseline_mac.argtypes = [ci, ci, u32, u32, C.POINTER(u64), C.POINTER(C.c_double)]
+
+    def plain_run(self, recs_bytes, nrec, w, p, words, decode):
+        steps, gates = C.c_uint64(), C.c_uint64()
+        rc = self.lib.gcc_plain_run(_p(recs_bytes), nrec, w, p, _p(words), _p(decode), C.byref(steps), C.byref(gates))
+        if rc:
+            raise RuntimeError("step accounting mismatch between builder and execution")
+        return steps.value, gates.value
+
+    def derive_R(self, seed):
+        out = np.zeros(16, dtype=np.uint8)
+        self.lib.gcc_derive_R(seed, _p(out))
+        return out
+
+    def aes(self, blocks, ttable=False):
+        blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, 16)
+        out = np.empty_like(blocks)
+        (self.lib.gcc_aes_encrypt_ttable if ttable else self.lib.gcc_aes_encrypt)(_p(blocks), _p(out), len(blocks))
+        return out
+
+    def garble_eval(self, prog, shares, seed=b"\x01" * 16):
+        """Run a whole program (linreg_gc.Program) through CPU garbler + evaluator.
+        Returns the decoded reveal slots (uint64) and the gate count."""
+        info = prog.info
+        sysm = prog.system
+        w, p = sysm.width, sysm.precision
+        recs = prog.records()
+        R = self.derive_R(seed)
+        wordsG = np.zeros(info.n_words * 1024, dtype=np.uint8)
+        wordsE = np.zeros(info.n_words * 1024, dtype=np.uint8)
+        shares = np.ascontiguousarray(shares, dtype=np.uint64).ravel()
+        self.lib.gcc_input_labels(seed, _p(R), _p(shares), info.in_base, shares.size, w, _p(wordsG), _p(wordsE))
+        decG = np.zeros(info.n_reveal + 1, dtype=np.uint64)
+        decE = np.zeros(info.n_reveal + 1, dtype=np.uint64)
+        tab = np.zeros(max(1, info.max_launch_steps) * 2048, dtype=np.uint8)
+        gates = 0
+        rsz = 40
+        for L in prog.launches():
+            sl = recs[L["first_rec"] * rsz:(L["first_rec"] + L["nrec"]) * rsz]
+            g = self.lib.gcc_garble_run(_p(sl), L["nrec"], w, p, _p(R), _p(wordsG), _p(tab), _p(decG), L["step0"])
+            e = self.lib.gcc_eval_run(_p(sl), L["nrec"], w, p, _p(wordsE), _p(tab), _p(decE), L["step0"])
+            assert g == e == L["gates"], (g, e, L)
+            gates += g
+        return decG ^ decE, gates, dict(R=R, wordsG=wordsG, wordsE=wordsE)
+
+    def baseline_mac(self, w, p, nrec, chunk):
+        g, s = C.c_uint64(), C.c_double()
+        rate = self.lib.gcc_baseline_mac(w, p, nrec, chunk, C.byref(g), C.byref(s))
+        return rate, g.value, s.value
+
+
+def load():
+    so = os.path.join(ODIR, "libgc_cpu.so")
+    csrc = os.path.join(ROOT, "linreg-mpc_amd", "csrc")
+    src = [os.path.join(ODIR, "gc_cpu.cpp")] + [os.path.join(csrc, f) for f in ("gc_aes.h", "gc_circuits.h", "gc_exec.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", ODIR, "libgc_cpu.so"])
+    return GcCpu(C.CDLL(so))

@@ -1,0 +1,121 @@
+"""CPU suite for the host logic: the lowered program of the product library
+(gc_program.h via the C ABI) is executed record by record on the CPU checker
+and compared with the semantic oracle.  No GPU needed."""
+import numpy as np
+import pytest
+
+from helpers import oracle_solve, split_shares, sx, synth_system
+
+FIPS_KEY_PT = bytes.fromhex("3243f6a8885a308d313198a2e0370734")   # FIPS-197 Appendix B
+FIPS_KEY_CT = bytes.fromhex("3925841d02dc09fbdc118597196a0b32")
+
+
+def test_aes_known_answer(gccpu):
+    pt = np.frombuffer(FIPS_KEY_PT, dtype=np.uint8)
+    assert bytes(gccpu.aes(pt)[0]) == FIPS_KEY_CT            # AES-NI
+    assert bytes(gccpu.aes(pt, ttable=True)[0]) == FIPS_KEY_CT  # the T-table algorithm the GPU runs
+    rnd = np.random.default_rng(0).integers(0, 256, size=(257, 16), dtype=np.uint8)
+    assert np.array_equal(gccpu.aes(rnd), gccpu.aes(rnd, ttable=True))
+
+
+def _plain(lgc, gccpu, sysm, shares):
+    prog = lgc.Program(sysm)
+    info = prog.info
+    words = np.zeros(info.n_words, dtype=np.uint64)
+    m = (1 << sysm.width) - 1
+    words[info.in_base:info.in_base + shares.size] = shares.ravel() & np.uint64(m)
+    dec = np.zeros(info.n_reveal + 1, dtype=np.uint64)
+    steps, gates = gccpu.plain_run(prog.records(), info.n_records, sysm.width, sysm.precision, words, dec)
+    assert steps == info.total_steps and gates == info.total_gates
+    return prog, dec
+
+
+CASES = [(64, 56, 5, 40), (64, 54, 7, 60), (32, 30, 6, 50), (32, 28, 4, 30), (64, 30, 3, 20)]
+
+
+@pytest.mark.parametrize("w,p,d,n", CASES)
+@pytest.mark.parametrize("alg", ["cgd", "cholesky", "ldlt"])
+@pytest.mark.parametrize("normalize", [0, 1])
+def test_program_plain_matches_oracle(lgc, gccpu, oracle, w, p, d, n, alg, normalize):
+    rng = np.random.default_rng(w * 1000 + p * 10 + d + normalize)
+    A, b = synth_system(oracle, rng, n, d, w, p)
+    nsh = 3 if normalize else 2
+    shares = split_shares(rng, A, b, nsh, w)
+    iters = 6
+    lam = 0.001
+    sysm = lgc.make_system(d, w, p, alg, iters, lam, nsh, normalize, reveal_inputs=1, trace=1)
+    prog, dec = _plain(lgc, gccpu, sysm, shares)
+    info = prog.info
+    exp, a, bb = oracle_solve(oracle, A, b, d, w, p, alg, iters, lam, normalize, trace=(alg == "cgd"))
+    T = d * (d + 1) // 2
+    got_ab = sx(dec[info.rv_inputs:info.rv_inputs + T + d], w)
+    assert got_ab.tolist() == np.concatenate([a, bb]).tolist()
+    got = sx(dec[info.rv_beta:info.rv_beta + d], w)
+    if alg == "cgd":
+        beta, tr = exp
+        got_tr = sx(dec[info.rv_trace:info.rv_trace + iters * (d + 4)], w).reshape(iters, d + 4)
+        assert got_tr.tolist() == tr.tolist()
+    else:
+        beta = exp
+    assert got.tolist() == beta.tolist()
+
+
+def test_program_readme_example(lgc, gccpu, oracle, golden_dir):
+    """the reference's only known answer, through the lowered circuit (plaintext run)"""
+    import json, os
+    kat = json.load(open(os.path.join(golden_dir, "readme_kat.json")))
+    d = 5
+    A = np.array(kat["A"], dtype=np.uint64); b = np.array(kat["b"], dtype=np.uint64)
+    shares = split_shares(np.random.default_rng(1), A, b, 3, 64)
+    sysm = lgc.make_system(d, 64, 56, "cgd", 10, 0.001, 3, 1, 0, 1)
+    prog, dec = _plain(lgc, gccpu, sysm, shares)
+    got = sx(dec[prog.info.rv_beta:prog.info.rv_beta + d], 64)
+    assert got.tolist() == kat["beta_cgd"]
+    assert ["%.15f" % (int(v) / 2.0 ** 56) for v in got] == kat["printed"]
+
+
+def test_program_medium_dimension(lgc, gccpu, oracle):
+    """chunked dot products (several MAC records per row) and a deeper max tree"""
+    rng = np.random.default_rng(5)
+    w, p, d, n = 64, 56, 40, 300
+    A, b = synth_system(oracle, rng, n, d, w, p)
+    shares = split_shares(rng, A, b, 2, w)
+    for alg, iters in (("cgd", 3), ("cholesky", 0), ("ldlt", 0)):
+        sysm = lgc.make_system(d, w, p, alg, iters, 0.0, 2, 0, 0, 0)
+        prog, dec = _plain(lgc, gccpu, sysm, shares)
+        exp, _, _ = oracle_solve(oracle, A, b, d, w, p, alg, iters, 0.0, 0)
+        assert sx(dec[prog.info.rv_beta:prog.info.rv_beta + d], w).tolist() == exp.tolist()
+
+
+@pytest.mark.parametrize("w,p", [(64, 56), (32, 30)])
+def test_cpu_garble_eval_matches_oracle(lgc, gccpu, oracle, w, p):
+    """the half-gates protocol itself (CPU mirror of the GPU kernels)"""
+    rng = np.random.default_rng(11 + w)
+    d, n = 3, 25
+    A, b = synth_system(oracle, rng, n, d, w, p)
+    shares = split_shares(rng, A, b, 2, w)
+    for alg, iters in (("cgd", 2), ("cholesky", 0)):
+        sysm = lgc.make_system(d, w, p, alg, iters, 0.001, 2, 1, 0, 0)
+        prog = lgc.Program(sysm)
+        dec, gates, _ = gccpu.garble_eval(prog, shares, seed=bytes(range(16)))
+        assert gates == prog.info.total_gates
+        exp, _, _ = oracle_solve(oracle, A, b, d, w, p, alg, iters, 0.001, 1)
+        assert sx(dec[prog.info.rv_beta:prog.info.rv_beta + d], w).tolist() == exp.tolist()
+
+
+def test_library_exports_and_fails_loudly_without_gpu(lgc):
+    import ctypes, re, os
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "linreg_gc.h")).read()
+    names = set(re.findall(r"\b(lgc_[a-z_]+)\s*\(", hdr))
+    assert len(names) >= 15
+    L = lgc.lib()
+    for nme in names:
+        assert hasattr(L, nme), nme
+    if lgc.device_count() == 0:
+        with pytest.raises(lgc.LgcError) as e:
+            lgc.Solver(lgc.make_system(3))
+        assert e.value.code == -2     # LGC_ENODEVICE: no CPU fallback
+    with pytest.raises(lgc.LgcError):
+        lgc.Program(lgc.make_system(3, width=48))
+    with pytest.raises(lgc.LgcError):
+        lgc.Program(lgc.make_system(3, width=32, precision=32))
