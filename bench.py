@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the garbled-circuit hot path on MI355X.
+
+Metric (BASELINE.json): AND-gates/s, garble + evaluate, on the d=500 CGD-15
+circuit (64-bit fixed point, precision 56) -- the circuit behind the
+reference's published 4.63e6 gates/s (BASELINE.md 1.1,
+experiments/results/phase2_64/test_LS_100000x500_0.1_0_cgd_64_20_p2.out:18).
+
+A "step" is one complete solve: fresh input labels, garbling and evaluation of
+the whole CGD-15 circuit, decode of beta.  Input shares are resident in HBM
+before the timed region.  With N GPUs every rank solves its own independent
+system (bootstrap-style sharding: no data-path collective), so scaling is weak.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--d D] [--iters I]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+REF_RATE = 4.63e6                # reference gates/s on this circuit
+
+
+def ref_equiv_gates(d, iters):
+    """reference's own AND count for CGD at 64 bit (exact fit):
+    per iteration 19300 d^2 + 221432 d + 206191; setup = 20-iteration total minus 20 iterations"""
+    per_it = 19300 * d * d + 221432 * d + 206191
+    total20 = 386233 * d * d + 4534169 * d + 4123635
+    return (total20 - 20 * per_it) + iters * per_it
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--d", type=int, default=500)
+    ap.add_argument("--iters", type=int, default=15)
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--precision", type=int, default=56)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    import numpy as np
+    import torch                       # first: one HIP runtime per process (shared SONAME)
+    import linreg_gc as lgc
+
+    if not torch.cuda.is_available() or lgc.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible; there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    d, iters, w, p = args.d, args.iters, args.width, args.precision
+    T = d * (d + 1) // 2
+    # synthetic two-party input (masked A, b as in test_linear_system.c:34-44): a well-conditioned
+    # SPD system in fixed point, split into two additive shares; one system per rank
+    rng = np.random.default_rng(1000 + rank)
+    n = 4 * d
+    X = rng.standard_normal((n, d)); X /= np.abs(X).max(axis=0)
+    beta = rng.random(d)
+    y = X @ beta + 0.1 * rng.standard_normal(n)
+    Af = X.T @ X / (n * d) + np.eye(d) * 1e-3
+    bf = X.T @ y / (n * d)
+    scale = float(1 << p)
+    tot = np.concatenate([[int(Af[i, j] * scale) for i in range(d) for j in range(i + 1)],
+                          [int(v * scale) for v in bf]]).astype(np.int64).astype(np.uint64)
+    mask = rng.integers(0, 2 ** 63, size=tot.size, dtype=np.uint64)
+    if w == 32:
+        tot &= np.uint64(0xffffffff); mask &= np.uint64(0xffffffff)
+    with np.errstate(over="ignore"):
+        shares = np.stack([tot - mask, mask])
+    if w == 32:
+        shares &= np.uint64(0xffffffff)
+
+    sysm = lgc.make_system(d, w, p, "cgd", iters, 0.0, 2, 0, 0, 0)
+    solver = lgc.Solver(sysm, seed=bytes((rank + i) & 0xff for i in range(16)), device=local_rank)
+    solver.set_shares(shares)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.run()
+    barrier()
+    t0 = time.perf_counter()
+    mac_g = mac_e = 0.0
+    mac_launches = 0
+    for _ in range(args.steps):
+        solver.run()
+        st = solver.stats()
+        mac_g += st["seconds_mac_garble"]; mac_e += st["seconds_mac_eval"]; mac_launches += st["mac_launches"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    st = solver.stats()
+    beta_fixed = solver.beta()
+    gates = st["and_gates"]
+    total_gates = gates * args.steps * world
+    value = total_gates / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (garbling of the MAC launches), HIP events on its stream
+        prog = lgc.Program(sysm)
+        macL = [L for L in prog.launches() if L["mac_only"]]
+        recs = np.frombuffer(prog.records().tobytes(), dtype=np.dtype([
+            ("op", "<u4"), ("cnt", "<u4"), ("dst", "<u4"), ("a", "<u4"), ("b", "<u4"), ("c", "<u4"),
+            ("sa", "<i4"), ("sb", "<i4"), ("step0", "<u8")]))
+        mac_gates = sum(L["gates"] for L in macL)
+        mac_products = int(sum(int(recs["cnt"][L["first_rec"]:L["first_rec"] + L["nrec"]].sum()) for L in macL))
+        mac_recs = sum(L["nrec"] for L in macL)
+        # algorithmic HBM bytes of the garbling MAC kernel: 32 B of garbled table per AND gate written,
+        # 2 operand words (1 KiB each) read per product, 2 words written per record
+        alg_bytes_per_solve = 32 * mac_gates + 2048 * mac_products + 2048 * mac_recs
+        n_launch_per_solve = max(1, len(macL))
+        avg_dur = mac_g / max(1, mac_launches)
+        alg_bytes_per_launch = alg_bytes_per_solve / n_launch_per_solve
+        achieved = alg_bytes_per_launch / avg_dur / 1e9 if avg_dur > 0 else 0.0
+        aes_rate, _ = lgc.aes_bench(65536, 256, device=local_rank)
+        aes_achieved = 4.0 * mac_gates * args.steps / mac_g if mac_g > 0 else 0.0
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs of this same command, gfx950 correction applied); only valid for the profiled workload
+        traffic = None
+        try:
+            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc_hbm.json"))
+            if pmcs and (d, iters, w, p) == (500, 15, 64, 56):
+                pm = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
+                traffic = pm["kernels"]["void gc::gc_exec_kernel<true, true>"]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            traffic = None
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "kernel": "gc_exec_kernel<garbler, MAC>", "avg_launch_ms": avg_dur * 1e3,
+                    "alg_bytes_per_launch": alg_bytes_per_launch,
+                    "note": "integer/bitwise kernel bound by LDS T-table AES issue, not HBM: see aes_roofline"}
+        aes_roofline = {"achieved": aes_achieved, "peak": aes_rate, "unit": "AES-128 blocks/s",
+                        "frac": aes_achieved / aes_rate if aes_rate else None,
+                        "peak_source": "lgc_aes_bench micro-kernel measured in this run"}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            import gccpu
+            g = gccpu.load()
+            # bounded sample of the same workload: OP_MAC records (the 90+ % unit of the circuit)
+            rate1, _, s1 = g.baseline_mac(w, p, 40, 4)
+            nrec = max(40, int(40 * args.cpu_seconds / max(s1, 1e-3)))
+            rate, cg, cs = g.baseline_mac(w, p, nrec, 4)
+            cpu = {"value": rate, "unit": "AND-gates/s", "cores": 2, "kind": "port",
+                   "sample": "%d OP_MAC records x 4 products (%d AND gates, %.1f s): AES-NI half-gates, one "
+                             "garbler thread + one evaluator thread, gates in program order" % (nrec, cg, cs)}
+        refg = ref_equiv_gates(d, iters) if w == 64 else None
+        out = {
+            "metric": "AND-gates/sec (garble+eval) d=500 CGD-15; phase1+2 wall-clock",
+            "value": value, "unit": "AND-gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": value / REF_RATE if (d == 500 and iters == 15 and w == 64) else None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "phase-2 CGD solve, d=%d, %d iterations, %d-bit fixed point, precision %d, "
+                                   "two-party masked input (test_linear_system path), garbler+evaluator co-located; "
+                                   "one independent system per GPU" % (d, iters, w, p),
+                       "d": d, "iterations": iters, "width": w, "precision": p, "sharding": "circuits x%d" % world},
+            "and_gates_per_solve": gates, "gate_steps_per_solve": st["gate_steps"],
+            "table_bytes_per_solve": st["table_bytes"], "launches_per_solve": st["launches"],
+            "ref_equiv_gates_per_solve": refg,
+            "ref_equiv_gates_per_s": (refg * args.steps * world / elapsed) if refg else None,
+            "seconds_mac_garble_per_solve": mac_g / args.steps, "seconds_mac_eval_per_solve": mac_e / args.steps,
+            "roofline": roofline, "aes_roofline": aes_roofline, "cpu_baseline": cpu,
+            "beta0": float(int(beta_fixed[0]) / scale),
+        }
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
