@@ -101,6 +101,8 @@ int lgc_solver_get_beta(lgc_solver *s, int64_t *beta);
 int lgc_solver_get_trace(lgc_solver *s, int64_t *trace);
 int lgc_solver_get_inputs(lgc_solver *s, int64_t *ab);
 int lgc_solver_get_stats(lgc_solver *s, lgc_stats *st);
+/* per-launch kernel times of the last profiled run (seconds; n = number of launches) */
+int lgc_solver_get_profile(lgc_solver *s, double *garble_s, double *eval_s, size_t n);
 
 /* Introspection (host only, no GPU needed): the lowered program.  Used by the
  * CPU test-suite to run the very same records on the CPU checker. */

@@ -1,10 +1,15 @@
 // gc_aes.h -- fixed-key AES-128 and the garbling hash, host + device.
 //
 // CDNA4 has no AES instruction: the device path is a T-table AES whose single
-// 256-entry table Te0 is staged in LDS, replicated 32x so that lane l always
-// reads bank (l mod 32) -- conflict-free ds_read_b32 regardless of the data
-// (MI355X_MICROARCH.md, LDS: ds_read_b32 bank = (addr/4) mod 32).  The three
-// other classic tables are rotations of Te0 (v_alignbit).
+// 256-entry table Te0 is staged in LDS, replicated 64x (one 256-byte row per
+// entry) so that lane l always reads bank (l mod 32) -- conflict-free
+// ds_read_b32 regardless of the data (MI355X_MICROARCH.md, LDS: ds_read_b32
+// bank = (addr/4) mod 32) -- and so that the LDS byte address (x << 8 | l << 2)
+// is formed by ONE v_perm_b32 from the state word and a per-lane constant.
+// The three other classic tables are rotations of Te0 (v_alignbit); XORs are
+// fused with v_bitop3_b32.  Integer VALU issue is 16 lanes/clk/SIMD on CDNA4,
+// so instruction count per block (about 370) is what bounds the cipher until
+// the LDS roof (160 lookups x 2 clk per wave) takes over.
 //
 // Conventions: a 128-bit block / label is 4 little-endian u32 words; word c
 // is AES state column c, byte r of the word is state row r -- the byte order
@@ -88,9 +93,33 @@ GC_HD uint32_t rotl32(uint32_t v, int k) {
     return (v << k) | (v >> (32 - k));
 #endif
 }
+// three-input XOR: one v_bitop3_b32 on gfx950 (there is no v_xor3 on gfx9)
+GC_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+// last round: Te0[x] = (2s, s, s, 3s) holds S[x] in bytes 1 and 2; build the
+// output column from four lookups with two byte permutes
+GC_HD uint32_t last_lo(uint32_t v1, uint32_t v0) {   // byte0 <- S[i0], byte1 <- S[i1]
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(v1, v0, 0x0c0c0501);
+#else
+    return ((v0 >> 8) & 0xffu) | (v1 & 0xff00u);
+#endif
+}
+GC_HD uint32_t last_hi(uint32_t v3, uint32_t v2) {   // byte2 <- S[i2], byte3 <- S[i3]
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(v3, v2, 0x05020c0c);
+#else
+    return (v2 & 0xff0000u) | ((v3 << 16) & 0xff000000u);
+#endif
+}
 
 // N independent blocks, interleaved round by round (ILP hides LDS latency).
-// T: table accessor, T::get(i) returns Te0[i].
+// T: table accessor, T::lk(word, k) returns Te0[byte k of word].
 template <int N, class T>
 GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4]) {
 #pragma unroll
@@ -104,18 +133,18 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4]) {
         for (int b = 0; b < N; b++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                v[b][4 * j + 0] = tab.get(s[b][j] & 0xff);
-                v[b][4 * j + 1] = tab.get((s[b][(j + 1) & 3] >> 8) & 0xff);
-                v[b][4 * j + 2] = tab.get((s[b][(j + 2) & 3] >> 16) & 0xff);
-                v[b][4 * j + 3] = tab.get(s[b][(j + 3) & 3] >> 24);
+                v[b][4 * j + 0] = tab.lk(s[b][j], 0);
+                v[b][4 * j + 1] = tab.lk(s[b][(j + 1) & 3], 1);
+                v[b][4 * j + 2] = tab.lk(s[b][(j + 2) & 3], 2);
+                v[b][4 * j + 3] = tab.lk(s[b][(j + 3) & 3], 3);
             }
         }
 #pragma unroll
         for (int b = 0; b < N; b++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                s[b][j] = v[b][4 * j] ^ rotl32(v[b][4 * j + 1], 8) ^ rotl32(v[b][4 * j + 2], 16) ^
-                          rotl32(v[b][4 * j + 3], 24) ^ rk[4 * rnd + j];
+                uint32_t t = xor3(v[b][4 * j], rotl32(v[b][4 * j + 2], 16), rk[4 * rnd + j]);
+                s[b][j] = xor3(t, rotl32(v[b][4 * j + 1], 8), rotl32(v[b][4 * j + 3], 24));
             }
         }
     }
@@ -125,21 +154,17 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4]) {
         for (int b = 0; b < N; b++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                v[b][4 * j + 0] = tab.get(s[b][j] & 0xff);
-                v[b][4 * j + 1] = tab.get((s[b][(j + 1) & 3] >> 8) & 0xff);
-                v[b][4 * j + 2] = tab.get((s[b][(j + 2) & 3] >> 16) & 0xff);
-                v[b][4 * j + 3] = tab.get(s[b][(j + 3) & 3] >> 24);
+                v[b][4 * j + 0] = tab.lk(s[b][j], 0);
+                v[b][4 * j + 1] = tab.lk(s[b][(j + 1) & 3], 1);
+                v[b][4 * j + 2] = tab.lk(s[b][(j + 2) & 3], 2);
+                v[b][4 * j + 3] = tab.lk(s[b][(j + 3) & 3], 3);
             }
         }
 #pragma unroll
         for (int b = 0; b < N; b++) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                // bytes 1 and 2 of Te0[x] both hold S[x]
-                s[b][j] = (((v[b][4 * j] >> 8) & 0xffu) | (v[b][4 * j + 1] & 0xff00u) |
-                           (v[b][4 * j + 2] & 0xff0000u) | ((v[b][4 * j + 3] << 8) & 0xff000000u)) ^
-                          rk[40 + j];
-            }
+            for (int j = 0; j < 4; j++)
+                s[b][j] = xor3(last_lo(v[b][4 * j + 1], v[b][4 * j]), last_hi(v[b][4 * j + 3], v[b][4 * j + 2]), rk[40 + j]);
         }
     }
 }
@@ -172,7 +197,7 @@ GC_HD void hash_n(const T &tab, const uint32_t *rk, const Lbl *x, const uint64_t
 // host table accessor (plain array)
 struct HostTab {
     const uint32_t *te0;
-    inline uint32_t get(uint32_t i) const { return te0[i]; }
+    inline uint32_t lk(uint32_t word, int k) const { return te0[(word >> (8 * k)) & 0xffu]; }
 };
 
 // ---- half-gates, one AND gate (lane-local).  gid: unique gate id.

@@ -4,7 +4,7 @@
 // l of a two's-complement value (w = 32 or 64 lanes used).  Circuits are
 // written once, against an abstract backend B, as sequences of whole-wave
 // steps; every B::AND call is one *gate step* (up to 64 AND gates, one per
-// active lane).  XOR / NOT / lane moves / public constants are free (free-XOR).
+// active lane); B::AND2 is two independent gate steps issued together.  XOR / NOT / lane moves / public constants are free (free-XOR).
 //
 // Backends (all expose the same members):
 //   PlainBackend            W = uint64_t bit mask; used on the host to count
@@ -54,8 +54,15 @@ struct Circ {
         for (int dist = 1; dist < n; dist <<= 1) {
             const uint64_t hi = act & ~lanes(dist);
             W Gs = be.shl(G, dist);
-            G = be.XOR(G, be.AND(Pg, Gs, hi));
-            if ((dist << 1) < n) Pg = be.AND(Pg, be.shl(Pg, dist), hi);
+            if ((dist << 1) < n) {
+                // the two ANDs of a prefix level are independent: one dual step
+                W t1, t2;
+                be.AND2(Pg, Gs, hi, Pg, be.shl(Pg, dist), hi, t1, t2);
+                G = be.XOR(G, t1);
+                Pg = t2;
+            } else {
+                G = be.XOR(G, be.AND(Pg, Gs, hi));
+            }
         }
         if (cout) *cout = be.bcast(G, n - 1);
         W carries = be.XOR(be.sel(act, be.shl(G, 1), be.zero()), cinw);
@@ -254,6 +261,11 @@ struct PlainBackend {
         steps++;
         gates += (uint64_t)__builtin_popcountll(act);
         return a & b & act;
+    }
+    // two independent gate steps (numbered step, step+1) that a backend may run concurrently
+    GC_HD void AND2(W a1, W b1, uint64_t act1, W a2, W b2, uint64_t act2, W &c1, W &c2) {
+        c1 = AND(a1, b1, act1);
+        c2 = AND(a2, b2, act2);
     }
     GC_HD W shl(W a, int k) const { return k >= 64 ? 0 : a << k; }
     GC_HD W shr(W a, int k) const { return k >= 64 ? 0 : a >> k; }

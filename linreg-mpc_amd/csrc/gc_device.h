@@ -3,10 +3,11 @@
 // One wavefront executes one record; lane l holds the 128-bit label of bit l.
 //   * labels move HBM <-> VGPR as one global_load/store_dwordx4 per lane
 //     (1 KiB contiguous per word per wave)
-//   * the AES T-table is staged once per workgroup in LDS, 32x replicated so
-//     that every ds_read_b32 is bank-conflict-free
+//   * the AES T-table is staged once per workgroup in LDS, 64x replicated so
+//     that every ds_read_b32 is bank-conflict-free and addressed by one v_perm
 //   * garbled tables are written/read as two 1 KiB coalesced rows per step
 //   * lane moves are ds_bpermute / v_readlane; public lane masks are SGPRs
+//   * narrow launches run one record per 4-wave workgroup, the waves splitting the AES work
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,16 +20,27 @@ namespace gc {
 __constant__ uint32_t c_rk[44];
 __constant__ uint32_t c_te0[256];
 
-static constexpr int kLdsTabWords = 256 * 32;   // 32 KiB
+static constexpr int kLdsTabWords = 256 * 64;   // 64 KiB: entry x occupies the 256-byte row x
 
 struct LdsTab {
-    const uint32_t *base;   // LDS, already offset by (lane & 31)
-    __device__ __forceinline__ uint32_t get(uint32_t i) const { return base[i << 5]; }
+    const char *base;    // LDS byte address of the table
+    uint32_t lane4;      // (lane << 2): fits one byte, merged into the address by v_perm_b32
+    // Te0[byte k of word]: address = (byte << 8) | (lane << 2)
+    __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const {
+        uint32_t off = __builtin_amdgcn_perm(word, lane4, 0x0c0c0400u + ((uint32_t)k << 8));
+        return *reinterpret_cast<const uint32_t *>(base + off);
+    }
 };
 
 __device__ __forceinline__ void lds_tab_fill(uint32_t *lds) {
-    for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) lds[i] = c_te0[i >> 5];
+    for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) lds[i] = c_te0[i >> 6];
     __syncthreads();
+}
+__device__ __forceinline__ LdsTab lds_tab_make(const uint32_t *lds) {
+    LdsTab t;
+    t.base = reinterpret_cast<const char *>(lds);
+    t.lane4 = (threadIdx.x & 63u) << 2;
+    return t;
 }
 
 __device__ __forceinline__ Lbl ld_lbl(const Lbl *p) {
@@ -40,9 +52,22 @@ __device__ __forceinline__ void st_lbl(Lbl *p, Lbl v) {
     *reinterpret_cast<uint4 *>(p) = make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <bool GARBLER, bool INLINE_AND>
+// MODE_MAC : one wave does all AES of its gate step, gate body inlined (MAC kernel).
+// MODE_SOLO: the same with one out-of-line gate body: generic records in WIDE launches
+//            (thousands of records: throughput matters, not latency).
+// MODE_QUAD: the 4 waves of a workgroup run the same record redundantly and split the
+//            4 (garbler) / 2 (evaluator) hashes of every gate step between them, exchanging
+//            the results through LDS: the latency of a dependent chain of steps drops from
+//            4 sequential AES to 1 AES + one barrier.  Used for the narrow, latency-bound
+//            launches (dividers, adders, max trees).
+enum { MODE_MAC = 0, MODE_SOLO = 1, MODE_QUAD = 2 };
+
+template <bool GARBLER, int MODE>
 struct GpuBackend {
     typedef Lbl W;
+    int wave;            // MODE_QUAD: wave index inside the workgroup (wave-uniform)
+    Lbl *xch;            // MODE_QUAD: LDS exchange area, 2 buffers x 512 labels (16 KiB)
+    int xsel;            // MODE_QUAD: buffer used by the next step (adjacent steps alternate)
     Lbl R;               // garbler's global offset (lsb = 1); unused by the evaluator
     Lbl *words;          // word file
     Lbl *tab;            // this launch's table buffer
@@ -90,8 +115,23 @@ struct GpuBackend {
         const uint64_t gid = step * 64 + (uint64_t)lane;
         Lbl *slot = tab + (step - launch_step0) * 128 + lane;
         step++;
-        if (INLINE_AND) return and_impl(lt, R, a, b, gid, slot, on);
-        return and_outlined(lt, R, a, b, gid, slot, on);
+        if (MODE == MODE_SOLO) return and_outlined(lt, R, a, b, gid, slot, on);
+        if (MODE == MODE_MAC) return and_impl(lt, R, a, b, gid, slot, on);
+        xsel ^= 1;
+        return and_quad(lt, R, a, b, gid, slot, on, wave, xch + xsel * 512, lane);
+    }
+    __device__ __forceinline__ void AND2(W a1, W b1, uint64_t act1, W a2, W b2, uint64_t act2, W &c1, W &c2) {
+        if (MODE != MODE_QUAD) {
+            c1 = AND(a1, b1, act1);
+            c2 = AND(a2, b2, act2);
+            return;
+        }
+        const bool on1 = bit(act1), on2 = bit(act2);
+        const uint64_t gid = step * 64 + (uint64_t)lane;
+        Lbl *slot = tab + (step - launch_step0) * 128 + lane;
+        step += 2;
+        xsel ^= 1;
+        and2_quad(lt, R, a1, b1, a2, b2, gid, slot, on1, on2, wave, xch + xsel * 512, lane, c1, c2);
     }
     static __device__ __forceinline__ W and_impl(LdsTab lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on) {
         W c = lzero();
@@ -108,38 +148,189 @@ struct GpuBackend {
         }
         return c;
     }
-    // the generic (non-MAC) kernel keeps one copy of the gate body: code size, compile time
     static __device__ __noinline__ W and_outlined(LdsTab lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on) {
         return and_impl(lt, R, a, b, gid, slot, on);
     }
+    // cooperative gate step (one out-of-line copy: code size, compile time).  Every wave of
+    // the workgroup calls this with identical operands; exactly one barrier per step, the
+    // exchange area is double-buffered by step parity.
+    static __device__ __noinline__ W and_quad(LdsTab lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on,
+                                              int wave, Lbl *xbuf, int lane) {
+        const int nh = GARBLER ? 4 : 2;
+        Lbl TGe = lzero(), TEe = lzero();
+        if (!GARBLER && on) { TGe = ld_lbl(slot); TEe = ld_lbl(slot + 64); }   // in flight during the hash
+        if (wave < nh) {
+            Lbl h = lzero();
+            if (on) {
+                Lbl x = (wave < (nh >> 1)) ? a : b;
+                if (GARBLER && (wave & 1)) x = lxor(x, R);
+                uint64_t tw = 2 * gid + (uint64_t)(wave >= (nh >> 1));
+                hash_n<1, LdsTab>(lt, c_rk, &x, &tw, &h);
+            }
+            xbuf[wave * 64 + lane] = h;
+        }
+        __syncthreads();
+        W c = lzero();
+        if (on) {
+            if (GARBLER) {
+                Lbl h0 = xbuf[lane], h1 = xbuf[64 + lane], h2 = xbuf[128 + lane], h3 = xbuf[192 + lane];
+                uint32_t pa = a.x & 1u, pb = b.x & 1u;
+                Lbl TG = lxor(lxor(h0, h1), lmask(R, pb));
+                Lbl WG = lxor(h0, lmask(TG, pa));
+                Lbl TE = lxor(lxor(h2, h3), a);
+                Lbl WE = lxor(h2, lmask(lxor(TE, a), pb));
+                if (wave == 0) {
+                    st_lbl(slot, TG);
+                    st_lbl(slot + 64, TE);
+                }
+                c = lxor(WG, WE);
+            } else {
+                Lbl h0 = xbuf[lane], h1 = xbuf[64 + lane];
+                uint32_t sa = a.x & 1u, sb = b.x & 1u;
+                Lbl WG = lxor(h0, lmask(TGe, sa));
+                Lbl WE = lxor(h1, lmask(lxor(TEe, a), sb));
+                c = lxor(WG, WE);
+            }
+        }
+        return c;
+    }
+    // two gate steps (gid, gid + 64) at once: 8 (garbler) / 4 (evaluator) hashes over 4 waves
+    static __device__ __noinline__ void and2_quad(LdsTab lt, Lbl R, W a1, W b1, W a2, W b2, uint64_t gid, Lbl *slot,
+                                                  bool on1, bool on2, int wave, Lbl *xbuf, int lane, W &c1, W &c2) {
+        const uint64_t gid2 = gid + 64;
+        Lbl *slot2 = slot + 128;
+        Lbl TG1 = lzero(), TE1 = lzero(), TG2 = lzero(), TE2 = lzero();
+        if (!GARBLER) {
+            if (on1) { TG1 = ld_lbl(slot); TE1 = ld_lbl(slot + 64); }
+            if (on2) { TG2 = ld_lbl(slot2); TE2 = ld_lbl(slot2 + 64); }
+        }
+        if (GARBLER) {
+            // wave q: hash q of gate 1 and hash q of gate 2 (q = 0: a0, 1: a0^R, 2: b0, 3: b0^R)
+            Lbl x[2] = {(wave < 2) ? a1 : b1, (wave < 2) ? a2 : b2};
+            if (wave & 1) { x[0] = lxor(x[0], R); x[1] = lxor(x[1], R); }
+            uint64_t tw[2] = {2 * gid + (uint64_t)(wave >= 2), 2 * gid2 + (uint64_t)(wave >= 2)};
+            Lbl h[2] = {lzero(), lzero()};
+            if (on1 || on2) hash_n<2, LdsTab>(lt, c_rk, x, tw, h);
+            xbuf[wave * 64 + lane] = h[0];
+            xbuf[256 + wave * 64 + lane] = h[1];
+        } else {
+            // waves 0,1: gate 1 (a, b); waves 2,3: gate 2 (a, b)
+            Lbl x = (wave & 1) ? ((wave < 2) ? b1 : b2) : ((wave < 2) ? a1 : a2);
+            uint64_t tw = 2 * ((wave < 2) ? gid : gid2) + (uint64_t)(wave & 1);
+            Lbl h = lzero();
+            if ((wave < 2) ? on1 : on2) hash_n<1, LdsTab>(lt, c_rk, &x, &tw, &h);
+            xbuf[(wave >> 1) * 256 + (wave & 1) * 64 + lane] = h;
+        }
+        __syncthreads();
+        c1 = lzero();
+        c2 = lzero();
+        if (GARBLER) {
+            if (on1) {
+                Lbl h0 = xbuf[lane], h1 = xbuf[64 + lane], h2 = xbuf[128 + lane], h3 = xbuf[192 + lane];
+                uint32_t pa = a1.x & 1u, pb = b1.x & 1u;
+                Lbl TG = lxor(lxor(h0, h1), lmask(R, pb));
+                Lbl WG = lxor(h0, lmask(TG, pa));
+                Lbl TE = lxor(lxor(h2, h3), a1);
+                Lbl WE = lxor(h2, lmask(lxor(TE, a1), pb));
+                if (wave == 0) { st_lbl(slot, TG); st_lbl(slot + 64, TE); }
+                c1 = lxor(WG, WE);
+            }
+            if (on2) {
+                Lbl h0 = xbuf[256 + lane], h1 = xbuf[320 + lane], h2 = xbuf[384 + lane], h3 = xbuf[448 + lane];
+                uint32_t pa = a2.x & 1u, pb = b2.x & 1u;
+                Lbl TG = lxor(lxor(h0, h1), lmask(R, pb));
+                Lbl WG = lxor(h0, lmask(TG, pa));
+                Lbl TE = lxor(lxor(h2, h3), a2);
+                Lbl WE = lxor(h2, lmask(lxor(TE, a2), pb));
+                if (wave == 1) { st_lbl(slot2, TG); st_lbl(slot2 + 64, TE); }
+                c2 = lxor(WG, WE);
+            }
+        } else {
+            if (on1) {
+                Lbl h0 = xbuf[lane], h1 = xbuf[64 + lane];
+                uint32_t sa = a1.x & 1u, sb = b1.x & 1u;
+                c1 = lxor(lxor(h0, lmask(TG1, sa)), lxor(h1, lmask(lxor(TE1, a1), sb)));
+            }
+            if (on2) {
+                Lbl h0 = xbuf[256 + lane], h1 = xbuf[320 + lane];
+                uint32_t sa = a2.x & 1u, sb = b2.x & 1u;
+                c2 = lxor(lxor(h0, lmask(TG2, sa)), lxor(h1, lmask(lxor(TE2, a2), sb)));
+            }
+        }
+    }
     __device__ __forceinline__ W load(uint32_t id) const { return ld_lbl(words + (size_t)id * 64 + lane); }
-    __device__ __forceinline__ void store(uint32_t id, W v) { st_lbl(words + (size_t)id * 64 + lane, v); }
+    __device__ __forceinline__ void store(uint32_t id, W v) {
+        if (MODE != MODE_QUAD || wave == 0) st_lbl(words + (size_t)id * 64 + lane, v);
+    }
     __device__ __forceinline__ void reveal(uint32_t slot, W v) {
         uint64_t m = __ballot(v.x & 1u);
-        if (lane == 0) decode[slot] = m;
+        if (lane == 0 && (MODE != MODE_QUAD || wave == 0)) decode[slot] = m;
     }
 };
 
-// one wavefront per record; 4 waves per workgroup share the LDS table
-template <bool GARBLER, bool MAC_ONLY>
-__global__ void __launch_bounds__(256)
-gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *decode,
-               uint64_t launch_step0, Lbl R, int w, int p) {
+// MAC launches: one wavefront per record; the TPB/64 waves of a workgroup share the LDS table
+template <bool GARBLER, int TPB>
+__global__ void __launch_bounds__(TPB)
+gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
     __shared__ uint32_t lds_te0[kLdsTabWords];
     lds_tab_fill(lds_te0);
     const int lane = threadIdx.x & 63;
     const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wid >= nrec) return;
-    GpuBackend<GARBLER, MAC_ONLY> be;
+    typedef GpuBackend<GARBLER, MODE_MAC> B;
+    B be;
+    be.R = R;
+    be.words = words;
+    be.tab = tab;
+    be.decode = 0;
+    be.xsel = 0;
+    be.launch_step0 = launch_step0;
+    be.lane = lane;
+    be.wave = 0;
+    be.xch = 0;
+    be.lt = lds_tab_make(lds_te0);
+    Rec r = recs[wid];
+    r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);
+    r.dst = __builtin_amdgcn_readfirstlane(r.dst);
+    r.a = __builtin_amdgcn_readfirstlane(r.a);
+    r.b = __builtin_amdgcn_readfirstlane(r.b);
+    r.sa = __builtin_amdgcn_readfirstlane(r.sa);
+    r.sb = __builtin_amdgcn_readfirstlane(r.sb);
+    uint32_t s_lo = __builtin_amdgcn_readfirstlane((uint32_t)r.step0);
+    uint32_t s_hi = __builtin_amdgcn_readfirstlane((uint32_t)(r.step0 >> 32));
+    be.step = ((uint64_t)s_hi << 32) | s_lo;
+    typedef Circ<B> C;
+    Lbl S = lzero(), Cc = lzero();
+    for (uint32_t k = 0; k < r.cnt; k++)
+        C::mac(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
+    be.store(r.dst, S);
+    be.store(r.dst + 1, Cc);
+}
+
+// every other record type.  QUAD = true: one 4-wave workgroup per record (narrow, latency-bound
+// launches); QUAD = false: one wave per record, 4 records per workgroup (wide launches).
+template <bool GARBLER, bool QUAD>
+__global__ void __launch_bounds__(256)
+gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *decode,
+               uint64_t launch_step0, Lbl R, int w, int p) {
+    __shared__ uint32_t lds_te0[kLdsTabWords];
+    __shared__ Lbl lds_xch[QUAD ? 2 * 512 : 1];   // 16 KiB: 80 KiB per workgroup, two workgroups per CU
+    lds_tab_fill(lds_te0);
+    const uint32_t wid = QUAD ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nrec) return;
+    typedef GpuBackend<GARBLER, QUAD ? MODE_QUAD : MODE_SOLO> B;
+    B be;
     be.R = R;
     be.words = words;
     be.tab = tab;
     be.decode = decode;
     be.launch_step0 = launch_step0;
-    be.lane = lane;
-    be.lt.base = lds_te0 + (lane & 31);
+    be.lane = threadIdx.x & 63;
+    be.wave = QUAD ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    be.xch = lds_xch;
+    be.xsel = 0;
+    be.lt = lds_tab_make(lds_te0);
     Rec r = recs[wid];
-    // make the record wave-uniform for the compiler (SGPRs)
     r.op = __builtin_amdgcn_readfirstlane(r.op);
     r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);
     r.dst = __builtin_amdgcn_readfirstlane(r.dst);
@@ -151,18 +342,7 @@ gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *d
     uint32_t s_lo = __builtin_amdgcn_readfirstlane((uint32_t)r.step0);
     uint32_t s_hi = __builtin_amdgcn_readfirstlane((uint32_t)(r.step0 >> 32));
     be.step = ((uint64_t)s_hi << 32) | s_lo;
-    if (MAC_ONLY) {
-        if (r.op == OP_MAC) {
-            typedef Circ<GpuBackend<GARBLER, MAC_ONLY>> C;
-            Lbl S = lzero(), Cc = lzero();
-            for (uint32_t k = 0; k < r.cnt; k++)
-                C::mac(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
-            be.store(r.dst, S);
-            be.store(r.dst + 1, Cc);
-        }
-    } else {
-        exec_record(be, r, w, p);
-    }
+    exec_record(be, r, w, p);
 }
 
 }  // namespace gc

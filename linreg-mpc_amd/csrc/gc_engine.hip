@@ -79,8 +79,7 @@ gc_input_kernel(Lbl *wordsG, Lbl *wordsE, const uint64_t *vals, uint32_t base, u
     const int lane = threadIdx.x & 63;
     const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (k >= n) return;
-    LdsTab lt;
-    lt.base = lds_te0 + (lane & 31);
+    LdsTab lt = lds_tab_make(lds_te0);
     const uint32_t id = base + k;
     uint64_t tw = 0x8000000000000000ull | ((uint64_t)id * 64 + (uint64_t)lane);
     Lbl z;
@@ -92,13 +91,11 @@ gc_input_kernel(Lbl *wordsG, Lbl *wordsE, const uint64_t *vals, uint32_t base, u
     st_lbl(wordsE + (size_t)id * 64 + lane, lxor(z, lmask(R, bit)));
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 gc_aes_bench_kernel(uint32_t *out, int blocks_per_lane) {
     __shared__ uint32_t lds_te0[kLdsTabWords];
     lds_tab_fill(lds_te0);
-    const int lane = threadIdx.x & 63;
-    LdsTab lt;
-    lt.base = lds_te0 + (lane & 31);
+    LdsTab lt = lds_tab_make(lds_te0);
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s[4][4];
     for (int b = 0; b < 4; b++) { s[b][0] = gid; s[b][1] = b; s[b][2] = gid * 2654435761u; s[b][3] = 0x9e3779b9u ^ b; }
@@ -112,9 +109,7 @@ __global__ void __launch_bounds__(256)
 gc_aes_encrypt_kernel(const uint4 *in, uint4 *out, uint32_t n) {
     __shared__ uint32_t lds_te0[kLdsTabWords];
     lds_tab_fill(lds_te0);
-    const int lane = threadIdx.x & 63;
-    LdsTab lt;
-    lt.base = lds_te0 + (lane & 31);
+    LdsTab lt = lds_tab_make(lds_te0);
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint4 v = in[i];
@@ -209,14 +204,17 @@ struct lgc_solver {
     Lbl *wordsG, *wordsE, *tab;
     uint64_t *decG, *decE, *vals;
     Rec *recs;
-    hipStream_t stream;
-    hipEvent_t ev0, ev1;
+    hipStream_t stream, streamE;
+    hipEvent_t ev0, ev1, evG[2], evE[2];
+    size_t slot_bytes;
+    int nslots;
     std::vector<hipEvent_t> evs;
     std::vector<uint64_t> hG, hE;
+    std::vector<double> tG, tE;
     bool have_shares, ran;
     lgc_stats st;
-    lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), ev0(0), ev1(0),
-                   have_shares(false), ran(false) { memset(&st, 0, sizeof(st)); }
+    lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), streamE(0), ev0(0), ev1(0), slot_bytes(0), nslots(1),
+                   have_shares(false), ran(false) { memset(&st, 0, sizeof(st)); evG[0] = evG[1] = evE[0] = evE[1] = 0; }
 };
 
 extern "C" void lgc_solver_destroy(lgc_solver *s) {
@@ -232,7 +230,9 @@ extern "C" void lgc_solver_destroy(lgc_solver *s) {
     for (size_t i = 0; i < s->evs.size(); i++) (void)hipEventDestroy(s->evs[i]);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (int i = 0; i < 2; i++) { if (s->evG[i]) (void)hipEventDestroy(s->evG[i]); if (s->evE[i]) (void)hipEventDestroy(s->evE[i]); }
     if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->streamE) (void)hipStreamDestroy(s->streamE);
     delete s;
 }
 
@@ -265,11 +265,19 @@ extern "C" int lgc_solver_create(lgc_solver **out, int device, const lgc_system 
         }                                                                                        \
     } while (0)
     TRY(hipStreamCreate(&s->stream));
+    TRY(hipStreamCreate(&s->streamE));
     TRY(hipEventCreate(&s->ev0));
     TRY(hipEventCreate(&s->ev1));
+    for (int i = 0; i < 2; i++) {
+        TRY(hipEventCreateWithFlags(&s->evG[i], hipEventDisableTiming));
+        TRY(hipEventCreateWithFlags(&s->evE[i], hipEventDisableTiming));
+    }
+    // two table slots: the garbler of launch k+1 overlaps the evaluator of launch k
+    s->slot_bytes = tbytes ? tbytes : 16;
+    s->nslots = 2;
     TRY(hipMalloc(&s->wordsG, wbytes));
     TRY(hipMalloc(&s->wordsE, wbytes));
-    TRY(hipMalloc(&s->tab, tbytes ? tbytes : 16));
+    TRY(hipMalloc(&s->tab, s->slot_bytes * s->nslots));
     TRY(hipMalloc(&s->decG, (P.n_reveal + 1) * sizeof(uint64_t)));
     TRY(hipMalloc(&s->decE, (P.n_reveal + 1) * sizeof(uint64_t)));
     TRY(hipMalloc(&s->vals, nin * sizeof(uint64_t)));
@@ -291,11 +299,29 @@ extern "C" int lgc_solver_set_shares(lgc_solver *s, const uint64_t *shares) {
     return LGC_OK;
 }
 
-template <bool G, bool MAC>
-static void launch_exec(lgc_solver *s, const Launch &L, Lbl *words, uint64_t *dec) {
-    dim3 grid((L.nrec + 3) / 4), block(256);
-    hipLaunchKernelGGL((gc_exec_kernel<G, MAC>), grid, block, 0, s->stream, s->recs + L.first_rec, L.nrec, words,
-                       s->tab, dec, L.step0, s->R, s->P.w, s->P.p);
+// workgroup sizes: the 64 KiB table allows one workgroup per CU for the big MAC launches
+// (12 / 16 waves = 3 / 4 per SIMD, matching the kernels' VGPR use)
+static constexpr int kTpbMacG = 768, kTpbMacE = 1024;
+// generic launches with at least this many records run one wave per record (throughput);
+// narrower ones run one 4-wave workgroup per record (latency)
+static constexpr uint32_t kWideLaunch = 2048;
+template <bool G>
+static void launch_exec(lgc_solver *s, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, hipStream_t st) {
+    if (L.mac_only) {
+        constexpr int TPB = G ? kTpbMacG : kTpbMacE;
+        const unsigned per = TPB / 64;
+        dim3 grid((L.nrec + per - 1) / per), block(TPB);
+        hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
+                           tab, L.step0, s->R, s->P.w, s->P.p);
+    } else if (L.nrec >= kWideLaunch) {
+        dim3 grid((L.nrec + 3) / 4), block(256);
+        hipLaunchKernelGGL((gc_exec_kernel<G, false>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
+                           tab, dec, L.step0, s->R, s->P.w, s->P.p);
+    } else {
+        dim3 grid(L.nrec), block(256);
+        hipLaunchKernelGGL((gc_exec_kernel<G, true>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
+                           tab, dec, L.step0, s->R, s->P.w, s->P.p);
+    }
 }
 
 extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
@@ -314,31 +340,55 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
         HIPCHK(hipEventCreate(&e));
         s->evs.push_back(e);
     }
-    HIPCHK(hipEventRecord(s->ev0, s->stream));
-    HIPCHK(hipMemsetAsync(s->wordsG, 0, wbytes, s->stream));
-    HIPCHK(hipMemsetAsync(s->wordsE, 0, wbytes, s->stream));
-    HIPCHK(hipMemsetAsync(s->decG, 0, (P.n_reveal + 1) * sizeof(uint64_t), s->stream));
-    HIPCHK(hipMemsetAsync(s->decE, 0, (P.n_reveal + 1) * sizeof(uint64_t), s->stream));
+    // Garbler chain on `stream`, evaluator chain on `streamE`.  Evaluate(k) waits for garble(k);
+    // garble(k + nslots) waits for evaluate(k) (table slot reuse).  With profile != 0 the two
+    // chains are serialised so that per-kernel times are exclusive.
+    hipStream_t sG = s->stream, sE = profile ? s->stream : s->streamE;
+    HIPCHK(hipEventRecord(s->ev0, sG));
+    HIPCHK(hipMemsetAsync(s->wordsG, 0, wbytes, sG));
+    HIPCHK(hipMemsetAsync(s->wordsE, 0, wbytes, sG));
+    HIPCHK(hipMemsetAsync(s->decG, 0, (P.n_reveal + 1) * sizeof(uint64_t), sG));
+    HIPCHK(hipMemsetAsync(s->decE, 0, (P.n_reveal + 1) * sizeof(uint64_t), sG));
     {
         dim3 grid((unsigned)((nin + 3) / 4)), block(256);
-        hipLaunchKernelGGL(gc_input_kernel, grid, block, 0, s->stream, s->wordsG, s->wordsE, s->vals, P.in_base,
+        hipLaunchKernelGGL(gc_input_kernel, grid, block, 0, sG, s->wordsG, s->wordsE, s->vals, P.in_base,
                            (uint32_t)nin, s->R, s->seed, P.w);
+    }
+    if (!profile) {   // the evaluator chain starts after the input labels are in place
+        HIPCHK(hipEventRecord(s->evG[0], sG));
+        HIPCHK(hipStreamWaitEvent(sE, s->evG[0], 0));
     }
     for (size_t i = 0; i < nl; i++) {
         const Launch &L = P.launches[i];
+        const int slot = (int)(i % (size_t)s->nslots);
+        Lbl *tab = reinterpret_cast<Lbl *>(reinterpret_cast<char *>(s->tab) + (size_t)slot * s->slot_bytes);
         bool timed = profile || L.mac_only;
-        if (timed) HIPCHK(hipEventRecord(s->evs[3 * i], s->stream));
-        if (L.mac_only) launch_exec<true, true>(s, L, s->wordsG, s->decG);
-        else launch_exec<true, false>(s, L, s->wordsG, s->decG);
-        if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], s->stream));
-        if (L.mac_only) launch_exec<false, true>(s, L, s->wordsE, s->decE);
-        else launch_exec<false, false>(s, L, s->wordsE, s->decE);
-        if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 2], s->stream));
+        if (!profile && i >= (size_t)s->nslots) HIPCHK(hipStreamWaitEvent(sG, s->evE[slot], 0));
+        if (timed) HIPCHK(hipEventRecord(s->evs[3 * i], sG));
+        launch_exec<true>(s, L, s->wordsG, s->decG, tab, sG);
+        if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
+        if (!profile) {
+            HIPCHK(hipEventRecord(s->evG[slot], sG));
+            HIPCHK(hipStreamWaitEvent(sE, s->evG[slot], 0));
+        }
+        if (profile) {
+            launch_exec<false>(s, L, s->wordsE, s->decE, tab, sE);
+            HIPCHK(hipEventRecord(s->evs[3 * i + 2], sE));
+        } else {
+            if (L.mac_only) HIPCHK(hipEventRecord(s->evs[3 * i + 2], sE));   // start of the evaluate kernel
+            launch_exec<false>(s, L, s->wordsE, s->decE, tab, sE);
+            HIPCHK(hipEventRecord(s->evE[slot], sE));
+        }
     }
-    HIPCHK(hipMemcpyAsync(s->hG.data(), s->decG, (P.n_reveal + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipMemcpyAsync(s->hE.data(), s->decE, (P.n_reveal + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(hipEventRecord(s->ev1, s->stream));
-    HIPCHK(hipStreamSynchronize(s->stream));
+    if (!profile) {   // join the evaluator chain back into the main stream
+        hipEvent_t last = s->evE[(nl - 1) % (size_t)s->nslots];
+        if (nl > 0) HIPCHK(hipStreamWaitEvent(sG, last, 0));
+    }
+    HIPCHK(hipMemcpyAsync(s->hG.data(), s->decG, (P.n_reveal + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, sG));
+    HIPCHK(hipMemcpyAsync(s->hE.data(), s->decE, (P.n_reveal + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, sG));
+    HIPCHK(hipEventRecord(s->ev1, sG));
+    HIPCHK(hipStreamSynchronize(sG));
+    HIPCHK(hipStreamSynchronize(s->streamE));
     HIPCHK(hipGetLastError());
     lgc_stats &st = s->st;
     memset(&st, 0, sizeof(st));
@@ -349,14 +399,18 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
     st.gate_steps = P.total_steps;
     st.table_bytes = P.total_steps * 128 * sizeof(Lbl);
     st.launches = nl;
+    s->tG.assign(nl, 0.0);
+    s->tE.assign(nl, 0.0);
     for (size_t i = 0; i < nl; i++) {
         const Launch &L = P.launches[i];
         if (!(profile || L.mac_only)) continue;
         float g = 0, e = 0;
         HIPCHK(hipEventElapsedTime(&g, s->evs[3 * i], s->evs[3 * i + 1]));
-        HIPCHK(hipEventElapsedTime(&e, s->evs[3 * i + 1], s->evs[3 * i + 2]));
+        if (profile) HIPCHK(hipEventElapsedTime(&e, s->evs[3 * i + 1], s->evs[3 * i + 2]));
         st.seconds_garble += g * 1e-3;
         st.seconds_eval += e * 1e-3;
+        s->tG[i] = g * 1e-3;
+        s->tE[i] = e * 1e-3;
         if (L.mac_only) {
             st.seconds_mac_garble += g * 1e-3;
             st.seconds_mac_eval += e * 1e-3;
@@ -401,6 +455,13 @@ extern "C" int lgc_solver_get_stats(lgc_solver *s, lgc_stats *st) {
     return LGC_OK;
 }
 
+extern "C" int lgc_solver_get_profile(lgc_solver *s, double *garble_s, double *eval_s, size_t n) {
+    if (!s || !garble_s || !eval_s) return fail(LGC_EINVAL, "null argument");
+    if (n != s->tG.size()) return fail(LGC_EINVAL, "n must equal the number of launches (%zu)", s->tG.size());
+    for (size_t i = 0; i < n; i++) { garble_s[i] = s->tG[i]; eval_s[i] = s->tE[i]; }
+    return LGC_OK;
+}
+
 extern "C" int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[16], const uint64_t *shares,
                          int64_t *beta, int64_t *trace, lgc_stats *stats) {
     lgc_solver *s = 0;
@@ -421,27 +482,27 @@ extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double 
     if (rc) return rc;
     rc = upload_constants();
     if (rc) return rc;
-    if (waves < 4 || blocks_per_lane < 4) return fail(LGC_EINVAL, "waves >= 4 and blocks_per_lane >= 4 required");
+    if (waves < 16 || blocks_per_lane < 4) return fail(LGC_EINVAL, "waves >= 16 and blocks_per_lane >= 4 required");
     blocks_per_lane &= ~3;
-    int nblk = waves / 4;
+    int nblk = waves / 16;
     uint32_t *out = 0;
-    HIPCHK(hipMalloc(&out, (size_t)nblk * 256 * 4));
+    HIPCHK(hipMalloc(&out, (size_t)nblk * 1024 * 4));
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a));
     HIPCHK(hipEventCreate(&b));
-    hipLaunchKernelGGL(gc_aes_bench_kernel, dim3(nblk), dim3(256), 0, 0, out, 4);   // warm-up
+    hipLaunchKernelGGL(gc_aes_bench_kernel, dim3(nblk), dim3(1024), 0, 0, out, 4);   // warm-up
     HIPCHK(hipEventRecord(a, 0));
-    hipLaunchKernelGGL(gc_aes_bench_kernel, dim3(nblk), dim3(256), 0, 0, out, blocks_per_lane);
+    hipLaunchKernelGGL(gc_aes_bench_kernel, dim3(nblk), dim3(1024), 0, 0, out, blocks_per_lane);
     HIPCHK(hipEventRecord(b, 0));
     HIPCHK(hipEventSynchronize(b));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, a, b));
-    std::vector<uint32_t> h((size_t)nblk * 256);
+    std::vector<uint32_t> h((size_t)nblk * 1024);
     HIPCHK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
     uint32_t c = 0;
     for (size_t i = 0; i < h.size(); i++) c ^= h[i];
     if (check) *check = c;
-    if (rate) *rate = (double)nblk * 256.0 * (double)blocks_per_lane / (ms * 1e-3);
+    if (rate) *rate = (double)nblk * 1024.0 * (double)blocks_per_lane / (ms * 1e-3);
     (void)hipFree(out);
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);

@@ -23,6 +23,7 @@ enum Op : uint32_t {
     OP_SUBSUM,  // dst = words[c] - sum_{k<cnt} words[a+k*sa]
     OP_IPMAC,   // IpAcc = sum_{k<cnt} (a+k*sa)*(b+k*sb) exact; 4 words -> dst..dst+3
     OP_IPFIN,   // dst = wrap((sum of cnt IpAcc at a+4k) >> p)
+    OP_IPMERGE, // IpAcc at dst..dst+3 = sum of cnt IpAcc at a+4k
     OP_MUL,     // dst = mul(a, b)
     OP_MULSUB,  // dst = words[c] - mul(a, b)
     OP_ADD,     // dst = a + b
@@ -77,7 +78,8 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
         be.store(r.dst, A.LS); be.store(r.dst + 1, A.LC);
         be.store(r.dst + 2, A.HS); be.store(r.dst + 3, A.HC);
     } break;
-    case OP_IPFIN: {
+    case OP_IPFIN:
+    case OP_IPMERGE: {
         typename C::IpAcc A, O;
         A.LS = be.load(r.a); A.LC = be.load(r.a + 1); A.HS = be.load(r.a + 2); A.HC = be.load(r.a + 3);
         for (uint32_t k = 1; k < r.cnt; k++) {
@@ -85,7 +87,12 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
             O.LS = be.load(o); O.LC = be.load(o + 1); O.HS = be.load(o + 2); O.HC = be.load(o + 3);
             C::ip_merge(be, A, O, w, p);
         }
-        be.store(r.dst, C::ip_final(be, A, w, p));
+        if (r.op == OP_IPFIN) {
+            be.store(r.dst, C::ip_final(be, A, w, p));
+        } else {
+            be.store(r.dst, A.LS); be.store(r.dst + 1, A.LC);
+            be.store(r.dst + 2, A.HS); be.store(r.dst + 3, A.HC);
+        }
     } break;
     case OP_MUL:
         be.store(r.dst, C::mul(be, be.load(r.a), be.load(r.b), w, p));

@@ -19,6 +19,8 @@
 
 namespace gc {
 
+static const size_t kMinRecsPerLaunch = 8192;   // >= 2x the chip's resident waves (256 CUs x 12-16)
+
 struct Launch {
     uint32_t first_rec, nrec;   // slice of Program::recs
     uint64_t step0, steps;      // gate steps covered
@@ -50,7 +52,7 @@ struct Program {
 
     Program() : w(64), p(56), d(0), T(0), nshares(0), n_words(1), n_reveal(0), in_base(0), rv_beta(0),
                 rv_trace(~0u), rv_ab(~0u), total_steps(0), total_gates(0), max_launch_steps(0),
-                cap_steps(1ull << 21), step_cursor(0), open(false) {}
+                cap_steps(1ull << 22), step_cursor(0), open(false) {}
 
     uint32_t alloc(size_t n) { uint32_t r = n_words; n_words += (uint32_t)n; return r; }
     uint32_t alloc_reveal(size_t n) { uint32_t r = n_reveal; n_reveal += (uint32_t)n; return r; }
@@ -138,8 +140,7 @@ struct Program {
         size_t total = 0;
         for (size_t i = 0; i < jobs.size(); i++) total += jobs[i].len;
         if (total == 0) return;
-        size_t chunk = (total + target_waves - 1) / target_waves;
-        if (chunk < 1) chunk = 1;
+        size_t chunk = dots_chunk(total, target_waves);
         new_launch();
         std::vector<std::pair<uint32_t, uint32_t>> parts(jobs.size());  // (first partial word, count of words)
         uint32_t cur = scratch;
@@ -164,29 +165,66 @@ struct Program {
         }
         new_launch();
     }
-    static size_t dots_scratch(size_t total_products, size_t njobs, size_t target_waves) {
-        size_t chunk = (total_products + target_waves - 1) / target_waves;
+    // products per OP_MAC record: enough records to fill the chip (target_waves), and
+    // short enough that one table slot (cap_steps gate steps) still holds >= kMinRecsPerLaunch
+    // records -- a launch with fewer waves than the GPU has wave slots idles most CUs
+    size_t dots_chunk(size_t total, size_t target_waves) {
+        size_t chunk = (total + target_waves - 1) / target_waves;
+        uint64_t s1, g1;
+        cost(mk(OP_MAC, 0, 0, 0, 0, 1), s1, g1);
+        size_t by_slot = (size_t)(cap_steps / ((uint64_t)kMinRecsPerLaunch * s1));
+        if (chunk > by_slot) chunk = by_slot;
         if (chunk < 1) chunk = 1;
+        return chunk;
+    }
+    size_t dots_scratch(size_t total_products, size_t njobs, size_t target_waves) {
+        size_t chunk = dots_chunk(total_products, target_waves);
         return 2 * (total_products / chunk + njobs + 2) + 16;
     }
 
-    // wide inner product (fixed.oc:124-147)
-    void inner(uint32_t dst, uint32_t a, uint32_t b, size_t n, uint32_t scratch) {
-        size_t chunk = n >= 256 ? 8 : (n >= 32 ? 4 : 1);
-        uint32_t cur = scratch;
-        uint32_t nparts = 0;
+    // wide inner products (fixed.oc:124-147), several independent ones level-synchronously:
+    // one product per record, then a fan-in-4 merge tree of carry-save accumulators
+    struct IpJob { uint32_t dst, a, b; };
+    void inners(const std::vector<IpJob> &jobs, size_t n, uint32_t scratch) {
+        const size_t fan = 4;
+        const size_t per = inner_scratch(n) / 1;   // words reserved per job
         new_launch();
-        for (size_t k0 = 0; k0 < n; k0 += chunk) {
-            uint32_t len = (uint32_t)(n - k0 < chunk ? n - k0 : chunk);
-            emit(mk(OP_IPMAC, cur, a + (uint32_t)k0, b + (uint32_t)k0, 0, len));
-            cur += 4;
-            nparts++;
+        for (size_t j = 0; j < jobs.size(); j++) {
+            uint32_t base = scratch + (uint32_t)(j * per);
+            for (size_t k = 0; k < n; k++)
+                emit(mk(OP_IPMAC, base + (uint32_t)(4 * k), jobs[j].a + (uint32_t)k, jobs[j].b + (uint32_t)k, 0, 1));
         }
         new_launch();
-        emit(mk(OP_IPFIN, dst, scratch, 0, 0, nparts));
+        size_t cnt = n;
+        uint32_t off_cur = 0, off_next = (uint32_t)(4 * n);
+        while (cnt > fan) {
+            size_t groups = (cnt + fan - 1) / fan;
+            for (size_t j = 0; j < jobs.size(); j++) {
+                uint32_t base = scratch + (uint32_t)(j * per);
+                for (size_t g = 0; g < groups; g++) {
+                    size_t len = (g + 1) * fan <= cnt ? fan : cnt - g * fan;
+                    emit(mk(OP_IPMERGE, base + off_next + (uint32_t)(4 * g), base + off_cur + (uint32_t)(4 * g * fan), 0, 0,
+                            (uint32_t)len));
+                }
+            }
+            new_launch();
+            off_cur = off_next;
+            off_next += (uint32_t)(4 * groups);
+            cnt = groups;
+        }
+        for (size_t j = 0; j < jobs.size(); j++) {
+            uint32_t base = scratch + (uint32_t)(j * per);
+            emit(mk(OP_IPFIN, jobs[j].dst, base + off_cur, 0, 0, (uint32_t)cnt));
+        }
         new_launch();
     }
-    static size_t inner_scratch(size_t n) { return 4 * n + 16; }
+    void inner(uint32_t dst, uint32_t a, uint32_t b, size_t n, uint32_t scratch) {
+        std::vector<IpJob> jobs(1);
+        IpJob J = {dst, a, b};
+        jobs[0] = J;
+        inners(jobs, n, scratch);
+    }
+    static size_t inner_scratch(size_t n) { return 4 * n + 4 * (n / 3 + 8) + 16; }   // per job
 };
 
 // target number of concurrent waves for the big dot-product launches
@@ -248,8 +286,8 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         const uint32_t ng = P.alloc(1), q = P.alloc(1), gp = P.alloc(1), eta = P.alloc(1), gamma = P.alloc(1),
                        gAp = P.alloc(1);
         const uint32_t sc_max = P.alloc(Program::max_tree_scratch(d));
-        const uint32_t sc_ip = P.alloc(Program::inner_scratch(d));
-        const uint32_t sc_dot = P.alloc(Program::dots_scratch(d * d, d, kTargetWaves));
+        const uint32_t sc_ip = P.alloc(2 * Program::inner_scratch(d));
+        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d, d, kTargetWaves));
         if (trace) P.rv_trace = P.alloc_reveal((size_t)iters * (d + 4));
         // cgd.oc:96-106
         for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_SUB, g + (uint32_t)i, 0, bv + (uint32_t)i));
@@ -266,8 +304,12 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
                 jobs[i] = J;
             }
             P.dots(jobs, sc_dot, kTargetWaves);
-            P.inner(q, pA, pv, d, sc_ip);            // :128
-            P.inner(gp, g, pv, d, sc_ip);            // :130
+            {                                        // q = <pA,p> (:128), gp = <g,p> (:130)
+                std::vector<Program::IpJob> ij(2);
+                Program::IpJob j0 = {q, pA, pv}, j1 = {gp, g, pv};
+                ij[0] = j0; ij[1] = j1;
+                P.inners(ij, d, sc_ip);
+            }
             P.emit(Program::mk(OP_DIV, eta, gp, q)); // :133
             P.new_launch();
             for (size_t i = 0; i < d; i++) {         // :141-145
@@ -301,7 +343,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.new_launch();
     } else if (alg == ALG_CHOLESKY) {
         const uint32_t y = P.alloc(d), beta = P.alloc(d);
-        const uint32_t sc_dot = P.alloc(Program::dots_scratch(d * d, d, 4096) + 4 * d);
+        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d, d, 4096) + 4 * d);
         for (size_t j = 0; j < d; j++) {             // cholesky.oc:51-65
             if (j > 0) {
                 std::vector<Program::DotJob> jobs;
@@ -344,7 +386,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.new_launch();
     } else {  // ALG_LDLT
         const uint32_t tv = P.alloc(d);
-        const uint32_t sc_dot = P.alloc(Program::dots_scratch(d * d, d, 4096) + 4 * d);
+        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d, d, 4096) + 4 * d);
         for (size_t j = 0; j < d; j++) {             // ldlt.oc:50-64
             if (j > 0) {
                 for (size_t k = 0; k < j; k++) P.emit(Program::mk(OP_MUL, tv + (uint32_t)k, Mi(j, k), Mi(k, k)));

@@ -74,6 +74,7 @@ def lib():
             ("lgc_solver_set_shares", [vp, vp]), ("lgc_solver_run", [vp, ci]),
             ("lgc_solver_get_beta", [vp, vp]), ("lgc_solver_get_trace", [vp, vp]),
             ("lgc_solver_get_inputs", [vp, vp]), ("lgc_solver_get_stats", [vp, C.POINTER(Stats)]),
+            ("lgc_solver_get_profile", [vp, vp, vp, sz]),
             ("lgc_program_build", [C.POINTER(vp), C.POINTER(System)]),
             ("lgc_program_info_get", [vp, C.POINTER(ProgramInfo)]),
             ("lgc_aes_bench", [ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
@@ -173,6 +174,11 @@ class Solver:
         st = Stats()
         _chk(lib().lgc_solver_get_stats(self._h, C.byref(st)))
         return st.asdict()
+
+    def profile(self, nlaunches):
+        g = np.zeros(nlaunches); e = np.zeros(nlaunches)
+        _chk(lib().lgc_solver_get_profile(self._h, g.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p), nlaunches))
+        return g, e
 
     def close(self):
         if self._h:

@@ -125,6 +125,10 @@ struct CpuBackend {
         step++;
         return c;
     }
+    void AND2(const W &a1, const W &b1, uint64_t act1, const W &a2, const W &b2, uint64_t act2, W &c1, W &c2) {
+        c1 = AND(a1, b1, act1);
+        c2 = AND(a2, b2, act2);
+    }
     W load(uint32_t id) const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_loadu_si128(words + (size_t)id * 64 + i); return r; }
     void store(uint32_t id, const W &v) { for (int i = 0; i < 64; i++) _mm_storeu_si128(words + (size_t)id * 64 + i, v.l[i]); }
     void reveal(uint32_t slot, const W &v) {
