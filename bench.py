@@ -154,12 +154,13 @@ def main():
             pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc_hbm.json"))
             if pmcs and (d, iters, w, p) == (500, 15, 64, 56):
                 pm = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
-                traffic = pm["kernels"]["void gc::gc_exec_kernel<true, true>"]["hbm_bytes_per_launch_corrected"]
+                key = [k for k in pm["kernels"] if "gc_mac_kernel<true" in k][0]
+                traffic = pm["kernels"][key]["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": "gc_exec_kernel<garbler, MAC>", "avg_launch_ms": avg_dur * 1e3,
+                    "kernel": "gc_mac_kernel<garbler>", "avg_launch_ms": avg_dur * 1e3,
                     "alg_bytes_per_launch": alg_bytes_per_launch,
                     "achieved_exclusive": achieved_excl, "avg_launch_ms_exclusive": xg / n_launch_per_solve * 1e3,
                     "timing": "achieved: HIP events on the garbler stream over the timed region, evaluator kernels "
