@@ -132,6 +132,30 @@ const lgc_launch *lgc_program_launches(const lgc_program *p);
 int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[16], const uint64_t *shares,
               int64_t *beta, int64_t *trace, lgc_stats *stats);
 
+/* ------------------------------------------------------------------ phase 1 */
+/* Quantised data of one data provider, resident on the device (src/phase1.c:473-476 result). */
+typedef struct lgc_p1 lgc_p1;
+int lgc_p1_create(lgc_p1 **out, int device, size_t n, size_t d, int width, int precision);
+void lgc_p1_destroy(lgc_p1 *h);
+/* Xq: n x d row-major fixed point (sign-extended when width == 32); yq: n or NULL. */
+int lgc_p1_set_data(lgc_p1 *h, const int64_t *Xq, const int64_t *yq);
+/* Shares a data provider computes alone for its own columns [c0, c1): out_A is the packed lower
+ * triangle of that block (local idx(i,j), (c1-c0)(c1-c0+1)/2 words): inner_product_local off the
+ * diagonal (src/phase1.c:14-20, 569-571), the double-precision special case on it (562-567).
+ * with_y: also out_b[i] = <column c0+i, y> (the last data provider, phase1.c:376-381). */
+int lgc_p1_local(lgc_p1 *h, size_t c0, size_t c1, int with_y, uint64_t *out_A, uint64_t *out_b);
+/* inner_product_ti arithmetic, batched over pairs (src/phase1.c:148-236); column index d means y.
+ * lgc_p1_mask: out[q][k] = column cols[q] + sign * V[q][k]      (b + x: sign +1; a - y: sign -1)
+ * lgc_p1_dot : out[q] = <A[q], B[q]> (colsB NULL) or <A[q], column colsB[q]>, minus sub[q] */
+int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const uint64_t *V, int sign, uint64_t *out);
+int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const uint32_t *colsB, size_t npairs,
+               const uint64_t *sub, uint64_t *out);
+/* Trusted initializer (src/phase1.c:241-287): pairs [first_pair, first_pair + npairs) of the
+ * cross-party (i, j) enumeration; x, y: npairs x n words, r, xy_minus_r: npairs words, drawn in the
+ * order x, y, r from one AES-128-CTR stream keyed by seed (newBCipherRandomGen / randomizeBuffer). */
+int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t first_pair, size_t npairs, size_t n, int width,
+                    uint64_t *x, uint64_t *y, uint64_t *r, uint64_t *xy_minus_r);
+
 /* ------------------------------------------------------- micro-benchmarks */
 /* Stand-alone LDS T-table AES throughput (the "AES roofline" of the north
  * star): blocks_per_lane AES-128 encryptions in every lane of `waves` waves.

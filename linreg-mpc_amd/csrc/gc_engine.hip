@@ -17,7 +17,7 @@
 using namespace gc;
 
 static thread_local char g_err[512] = "";
-static int fail(int code, const char *fmt, ...) {
+int lgc_fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -27,7 +27,7 @@ static int fail(int code, const char *fmt, ...) {
 #define HIPCHK(x)                                                                               \
     do {                                                                                        \
         hipError_t e_ = (x);                                                                    \
-        if (e_ != hipSuccess) return fail(LGC_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+        if (e_ != hipSuccess) return lgc_fail(LGC_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
 extern "C" const char *lgc_last_error(void) { return g_err; }
@@ -38,12 +38,12 @@ extern "C" int lgc_device_count(void) {
     return n;
 }
 
-static int need_device(int device) {
+int lgc_need_device(int device) {
     int n = lgc_device_count();
-    if (n <= 0) return fail(LGC_ENODEVICE, "no HIP device visible: the garbled-circuit engine has no CPU fallback");
-    if (device < 0 || device >= n) return fail(LGC_EINVAL, "device %d out of range (%d visible)", device, n);
+    if (n <= 0) return lgc_fail(LGC_ENODEVICE, "no HIP device visible: the garbled-circuit engine has no CPU fallback");
+    if (device < 0 || device >= n) return lgc_fail(LGC_EINVAL, "device %d out of range (%d visible)", device, n);
     hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) return fail(LGC_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return lgc_fail(LGC_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
     return LGC_OK;
 }
 
@@ -54,7 +54,7 @@ static const AesTables &tables() {
     if (!g_tabs_built) { aes_build_tables(g_tabs, kFixedKey); g_tabs_built = true; }
     return g_tabs;
 }
-static int upload_constants() {
+int lgc_upload_constants() {
     const AesTables &t = tables();
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rk), t.rk, sizeof(t.rk)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_te0), t.te0, sizeof(t.te0)));
@@ -124,16 +124,16 @@ struct lgc_program {
 };
 
 static int check_system(const lgc_system *sys) {
-    if (!sys) return fail(LGC_EINVAL, "null system");
-    if (sys->width != 32 && sys->width != 64) return fail(LGC_EINVAL, "width must be 32 or 64");
+    if (!sys) return lgc_fail(LGC_EINVAL, "null system");
+    if (sys->width != 32 && sys->width != 64) return lgc_fail(LGC_EINVAL, "width must be 32 or 64");
     if (sys->precision < 0 || sys->precision >= sys->width)
-        return fail(LGC_EINVAL, "precision must satisfy 0 <= p < width (src/cmd/linreg.c:85-88)");
-    if (sys->d < 1 || sys->d > 4096) return fail(LGC_EINVAL, "d out of range");
-    if (sys->nshares < 1) return fail(LGC_EINVAL, "nshares must be >= 1");
-    if (sys->algorithm < 0 || sys->algorithm > 2) return fail(LGC_EINVAL, "Algorithm must be cholesky, ldlt, or cgd.");
-    if (sys->algorithm == LGC_ALG_CGD && sys->num_iterations < 0) return fail(LGC_EINVAL, "negative iteration count");
+        return lgc_fail(LGC_EINVAL, "precision must satisfy 0 <= p < width (src/cmd/linreg.c:85-88)");
+    if (sys->d < 1 || sys->d > 4096) return lgc_fail(LGC_EINVAL, "d out of range");
+    if (sys->nshares < 1) return lgc_fail(LGC_EINVAL, "nshares must be >= 1");
+    if (sys->algorithm < 0 || sys->algorithm > 2) return lgc_fail(LGC_EINVAL, "Algorithm must be cholesky, ldlt, or cgd.");
+    if (sys->algorithm == LGC_ALG_CGD && sys->num_iterations < 0) return lgc_fail(LGC_EINVAL, "negative iteration count");
     if (sys->algorithm == LGC_ALG_CHOLESKY && sys->width == 64 && sys->precision > 60)
-        return fail(LGC_EINVAL, "cholesky at width 64 supports precision <= 60 (square-root datapath is 64 lanes)");
+        return lgc_fail(LGC_EINVAL, "cholesky at width 64 supports precision <= 60 (square-root datapath is 64 lanes)");
     return LGC_OK;
 }
 
@@ -157,7 +157,7 @@ static void build(Program &P, const lgc_system *sys) {
 extern "C" int lgc_program_build(lgc_program **out, const lgc_system *sys) {
     int rc = check_system(sys);
     if (rc) return rc;
-    if (!out) return fail(LGC_EINVAL, "null out");
+    if (!out) return lgc_fail(LGC_EINVAL, "null out");
     lgc_program *p = new lgc_program();
     build(p->P, sys);
     *out = p;
@@ -165,7 +165,7 @@ extern "C" int lgc_program_build(lgc_program **out, const lgc_system *sys) {
 }
 extern "C" void lgc_program_destroy(lgc_program *p) { delete p; }
 extern "C" int lgc_program_info_get(const lgc_program *p, lgc_program_info *info) {
-    if (!p || !info) return fail(LGC_EINVAL, "null argument");
+    if (!p || !info) return lgc_fail(LGC_EINVAL, "null argument");
     const Program &P = p->P;
     info->n_records = P.recs.size();
     info->n_launches = P.launches.size();
@@ -239,10 +239,10 @@ extern "C" void lgc_solver_destroy(lgc_solver *s) {
 extern "C" int lgc_solver_create(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16]) {
     int rc = check_system(sys);
     if (rc) return rc;
-    if (!out || !seed) return fail(LGC_EINVAL, "null argument");
-    rc = need_device(device);
+    if (!out || !seed) return lgc_fail(LGC_EINVAL, "null argument");
+    rc = lgc_need_device(device);
     if (rc) return rc;
-    rc = upload_constants();
+    rc = lgc_upload_constants();
     if (rc) return rc;
     lgc_solver *s = new lgc_solver();
     s->sys = *sys;
@@ -259,7 +259,7 @@ extern "C" int lgc_solver_create(lgc_solver **out, int device, const lgc_system 
     do {                                                                                         \
         hipError_t e_ = (x);                                                                     \
         if (e_ != hipSuccess) {                                                                  \
-            fail(e_ == hipErrorOutOfMemory ? LGC_ENOMEM : LGC_EHIP, "%s: %s", #x, hipGetErrorString(e_)); \
+            lgc_fail(e_ == hipErrorOutOfMemory ? LGC_ENOMEM : LGC_EHIP, "%s: %s", #x, hipGetErrorString(e_)); \
             lgc_solver_destroy(s);                                                               \
             return e_ == hipErrorOutOfMemory ? LGC_ENOMEM : LGC_EHIP;                            \
         }                                                                                        \
@@ -291,7 +291,7 @@ extern "C" int lgc_solver_create(lgc_solver **out, int device, const lgc_system 
 }
 
 extern "C" int lgc_solver_set_shares(lgc_solver *s, const uint64_t *shares) {
-    if (!s || !shares) return fail(LGC_EINVAL, "null argument");
+    if (!s || !shares) return lgc_fail(LGC_EINVAL, "null argument");
     HIPCHK(hipSetDevice(s->device));
     size_t nin = s->P.nshares * (s->P.T + s->P.d);
     HIPCHK(hipMemcpy(s->vals, shares, nin * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -325,8 +325,8 @@ static void launch_exec(lgc_solver *s, const Launch &L, Lbl *words, uint64_t *de
 }
 
 extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
-    if (!s) return fail(LGC_EINVAL, "null solver");
-    if (!s->have_shares) return fail(LGC_ESTATE, "lgc_solver_set_shares has not been called");
+    if (!s) return lgc_fail(LGC_EINVAL, "null solver");
+    if (!s->have_shares) return lgc_fail(LGC_ESTATE, "lgc_solver_set_shares has not been called");
     HIPCHK(hipSetDevice(s->device));
     const Program &P = s->P;
     size_t wbytes = (size_t)P.n_words * 64 * sizeof(Lbl);
@@ -429,35 +429,35 @@ static int64_t decode_word(const lgc_solver *s, uint32_t slot) {
 }
 
 extern "C" int lgc_solver_get_beta(lgc_solver *s, int64_t *beta) {
-    if (!s || !beta) return fail(LGC_EINVAL, "null argument");
-    if (!s->ran) return fail(LGC_ESTATE, "solver has not run");
+    if (!s || !beta) return lgc_fail(LGC_EINVAL, "null argument");
+    if (!s->ran) return lgc_fail(LGC_ESTATE, "solver has not run");
     for (size_t i = 0; i < s->P.d; i++) beta[i] = decode_word(s, s->P.rv_beta + (uint32_t)i);
     return LGC_OK;
 }
 extern "C" int lgc_solver_get_trace(lgc_solver *s, int64_t *trace) {
-    if (!s || !trace) return fail(LGC_EINVAL, "null argument");
-    if (!s->ran) return fail(LGC_ESTATE, "solver has not run");
-    if (s->P.rv_trace == ~0u) return fail(LGC_ESTATE, "trace was not requested");
+    if (!s || !trace) return lgc_fail(LGC_EINVAL, "null argument");
+    if (!s->ran) return lgc_fail(LGC_ESTATE, "solver has not run");
+    if (s->P.rv_trace == ~0u) return lgc_fail(LGC_ESTATE, "trace was not requested");
     size_t n = (size_t)s->sys.num_iterations * (s->P.d + 4);
     for (size_t i = 0; i < n; i++) trace[i] = decode_word(s, s->P.rv_trace + (uint32_t)i);
     return LGC_OK;
 }
 extern "C" int lgc_solver_get_inputs(lgc_solver *s, int64_t *ab) {
-    if (!s || !ab) return fail(LGC_EINVAL, "null argument");
-    if (!s->ran) return fail(LGC_ESTATE, "solver has not run");
-    if (s->P.rv_ab == ~0u) return fail(LGC_ESTATE, "input reveal was not requested");
+    if (!s || !ab) return lgc_fail(LGC_EINVAL, "null argument");
+    if (!s->ran) return lgc_fail(LGC_ESTATE, "solver has not run");
+    if (s->P.rv_ab == ~0u) return lgc_fail(LGC_ESTATE, "input reveal was not requested");
     for (size_t i = 0; i < s->P.T + s->P.d; i++) ab[i] = decode_word(s, s->P.rv_ab + (uint32_t)i);
     return LGC_OK;
 }
 extern "C" int lgc_solver_get_stats(lgc_solver *s, lgc_stats *st) {
-    if (!s || !st) return fail(LGC_EINVAL, "null argument");
+    if (!s || !st) return lgc_fail(LGC_EINVAL, "null argument");
     *st = s->st;
     return LGC_OK;
 }
 
 extern "C" int lgc_solver_get_profile(lgc_solver *s, double *garble_s, double *eval_s, size_t n) {
-    if (!s || !garble_s || !eval_s) return fail(LGC_EINVAL, "null argument");
-    if (n != s->tG.size()) return fail(LGC_EINVAL, "n must equal the number of launches (%zu)", s->tG.size());
+    if (!s || !garble_s || !eval_s) return lgc_fail(LGC_EINVAL, "null argument");
+    if (n != s->tG.size()) return lgc_fail(LGC_EINVAL, "n must equal the number of launches (%zu)", s->tG.size());
     for (size_t i = 0; i < n; i++) { garble_s[i] = s->tG[i]; eval_s[i] = s->tE[i]; }
     return LGC_OK;
 }
@@ -478,11 +478,11 @@ extern "C" int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[1
 
 // --------------------------------------------------------- micro-benchmarks
 extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double *rate, uint32_t *check) {
-    int rc = need_device(device);
+    int rc = lgc_need_device(device);
     if (rc) return rc;
-    rc = upload_constants();
+    rc = lgc_upload_constants();
     if (rc) return rc;
-    if (waves < 16 || blocks_per_lane < 4) return fail(LGC_EINVAL, "waves >= 16 and blocks_per_lane >= 4 required");
+    if (waves < 16 || blocks_per_lane < 4) return lgc_fail(LGC_EINVAL, "waves >= 16 and blocks_per_lane >= 4 required");
     blocks_per_lane &= ~3;
     int nblk = waves / 16;
     uint32_t *out = 0;
@@ -510,9 +510,9 @@ extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double 
 }
 
 extern "C" int lgc_aes_encrypt(int device, const uint8_t *in, uint8_t *out, size_t n) {
-    int rc = need_device(device);
+    int rc = lgc_need_device(device);
     if (rc) return rc;
-    rc = upload_constants();
+    rc = lgc_upload_constants();
     if (rc) return rc;
     uint4 *di = 0, *dout = 0;
     HIPCHK(hipMalloc(&di, n * 16));

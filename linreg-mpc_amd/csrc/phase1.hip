@@ -1,0 +1,338 @@
+// phase1.hip -- phase-1 aggregation on the MI355X: additive shares of X^T X and
+// X^T y in the ring Z_2^w (w = 32 or 64).
+//
+// Replaces the arithmetic of the reference's src/phase1.c:
+//   inner_product_local (14-20)            -> p1_gram_kernel  (wrap-around u64 Gram, LDS tiled)
+//   diagonal special case (562-567, 364-369)-> p1_diag_kernel  (IEEE double, k ascending, no FMA)
+//   run_trusted_initializer PRG + <x,y> (241-287) -> ti_prg_kernel (AES-128-CTR) + p1_dot_kernel
+//   inner_product_ti masking / shares (148-236)   -> p1_mask_kernel, p1_dot_kernel
+// The transport (TCP mesh, length-prefixed protobuf messages, phase1.c:100-145) stays on
+// the host and is out of scope here; these entry points take and return host buffers.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/linreg_gc.h"
+#include "gc_device.h"
+
+using namespace gc;
+
+int lgc_fail(int code, const char *fmt, ...);
+int lgc_need_device(int device);
+int lgc_upload_constants();
+
+#define P1CHK(x)                                                                             \
+    do {                                                                                     \
+        hipError_t e_ = (x);                                                                 \
+        if (e_ != hipSuccess) return lgc_fail(LGC_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct lgc_p1 {
+    int device, w, p;
+    size_t n, d;
+    int64_t *X;      // n x (d + 1) row-major, column d = y (zero when this party does not own y)
+    bool have_y;
+};
+
+// ---- wrap-around Gram block: C[a][b] = sum_k X[k][cols[a]] * X[k][cols[b]]  (mod 2^64)
+// 64 x 64 output tile per workgroup, 4 x 4 per thread, K staged through LDS in slabs of 16 rows;
+// split-K partial sums are combined with integer atomics (exact and order-independent).
+#define P1_KT 16
+__global__ void __launch_bounds__(256)
+p1_gram_kernel(const int64_t *X, size_t n, size_t ld, const uint32_t *cols, uint32_t L, uint64_t *C, size_t kchunk) {
+    __shared__ uint64_t As[P1_KT][64], Bs[P1_KT][64];
+    const uint32_t i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    if (j0 > i0) return;   // lower triangle of tiles only
+    const size_t k0 = (size_t)blockIdx.z * kchunk;
+    const size_t k1 = k0 + kchunk < n ? k0 + kchunk : n;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    uint64_t acc[4][4] = {};
+    const int lc = threadIdx.x & 63, lr = threadIdx.x >> 6;   // loader: 4 rows x 64 columns per pass
+    const uint32_t ca = i0 + lc < L ? cols[i0 + lc] : 0xffffffffu;
+    const uint32_t cb = j0 + lc < L ? cols[j0 + lc] : 0xffffffffu;
+    for (size_t kb = k0; kb < k1; kb += P1_KT) {
+#pragma unroll
+        for (int r = 0; r < P1_KT; r += 4) {
+            size_t k = kb + r + lr;
+            As[r + lr][lc] = (k < k1 && ca != 0xffffffffu) ? (uint64_t)X[k * ld + ca] : 0;
+            Bs[r + lr][lc] = (k < k1 && cb != 0xffffffffu) ? (uint64_t)X[k * ld + cb] : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < P1_KT; kk++) {
+            uint64_t a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a[u] = As[kk][ty * 4 + u]; b[u] = Bs[kk][tx * 4 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) acc[u][v] += a[u] * b[v];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            uint32_t i = i0 + ty * 4 + u, j = j0 + tx * 4 + v;
+            if (i < L && j < L && j <= i) atomicAdd((unsigned long long *)&C[(size_t)i * L + j], (unsigned long long)acc[u][v]);
+        }
+}
+
+// ---- diagonal: xy += pow(fixed_to_double(x_k, p), 2) * pow(2, p), k ascending, in IEEE double;
+// share = double_to_fixed(xy / d, p)  (src/phase1.c:562-567).  One thread per column; explicit
+// round-to-nearest multiplies/adds so that no FMA contraction can change the rounding.
+__global__ void p1_diag_kernel(const int64_t *X, size_t n, size_t ld, const uint32_t *cols, uint32_t L,
+                               int p, int w, double normalizer2, uint64_t *out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L) return;
+    const uint32_t c = cols[t];
+    const double scale = (double)(1ll << p);
+    double xy = 0.0;
+    for (size_t k = 0; k < n; k++) {
+        double v = __ddiv_rn((double)X[k * ld + c], scale);
+        xy = __dadd_rn(xy, __dmul_rn(__dmul_rn(v, v), scale));
+    }
+    double tq = __dmul_rn(__ddiv_rn(xy, normalizer2), scale);
+    uint64_t r;
+    if (w == 32) {   // (int32_t) cast with the x86 "integer indefinite" result when out of range
+        if (!(tq > -2147483649.0 && tq < 2147483648.0)) r = 0x80000000ull;
+        else r = (uint64_t)(uint32_t)(int32_t)tq;
+    } else {
+        if (!(tq >= -9223372036854775808.0 && tq < 9223372036854775808.0)) r = 0x8000000000000000ull;
+        else r = (uint64_t)(int64_t)tq;
+    }
+    out[t] = r;
+}
+
+// ---- batched masking: out[q][k] = X[k][col[q]] + sign * V[q][k]   (mod 2^64)
+__global__ void p1_mask_kernel(const int64_t *X, size_t n, size_t ld, const uint32_t *cols, const uint64_t *V,
+                               int sign, uint64_t *out) {
+    const uint32_t q = blockIdx.y;
+    const uint32_t c = cols[q];
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        uint64_t x = (uint64_t)X[k * ld + c], v = V[(size_t)q * n + k];
+        out[(size_t)q * n + k] = sign > 0 ? x + v : x - v;
+    }
+}
+
+// ---- batched wrap-around dot products: out[q] = sum_k A[q][k] * B[q][k]; B is either a vector
+// batch (colsB == NULL) or columns of X
+__global__ void __launch_bounds__(256)
+p1_dot_kernel(const uint64_t *A, const uint64_t *Bv, const int64_t *X, size_t ld, const uint32_t *colsB, size_t n,
+              uint64_t *out) {
+    const uint32_t q = blockIdx.y;
+    uint64_t acc = 0;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        uint64_t a = A[(size_t)q * n + k];
+        uint64_t b = colsB ? (uint64_t)X[k * ld + colsB[q]] : Bv[(size_t)q * n + k];
+        acc += a * b;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&out[q], (unsigned long long)acc);
+}
+
+// ---- AES-128-CTR keystream: block c = AES_k(c) (little-endian 128-bit counter, nonce 0).
+// rk: 44 round-key words of the session key.  One block per lane per iteration.
+__global__ void __launch_bounds__(1024)
+ti_prg_kernel(const uint32_t *rk, uint64_t first_block, uint64_t nblocks, uint4 *out) {
+    __shared__ uint32_t lds_te0[kLdsTabWords];
+    __shared__ uint32_t srk[44];
+    lds_tab_fill(lds_te0);
+    if (threadIdx.x < 44) srk[threadIdx.x] = rk[threadIdx.x];
+    __syncthreads();
+    LdsTab lt = lds_tab_make(lds_te0);
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t c = first_block + b;
+        uint32_t s[1][4] = {{(uint32_t)c, (uint32_t)(c >> 32), 0u, 0u}};
+        aes_encrypt_n<1, LdsTab>(lt, srk, s);
+        out[b] = make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
+    }
+}
+
+// =============================================================== C ABI
+extern "C" int lgc_p1_create(lgc_p1 **out, int device, size_t n, size_t d, int width, int precision) {
+    if (!out) return lgc_fail(LGC_EINVAL, "null out");
+    if (width != 32 && width != 64) return lgc_fail(LGC_EINVAL, "width must be 32 or 64");
+    if (precision < 0 || precision >= width) return lgc_fail(LGC_EINVAL, "precision must satisfy 0 <= p < width");
+    if (n < 1 || d < 1) return lgc_fail(LGC_EINVAL, "empty data");
+    int rc = lgc_need_device(device);
+    if (rc) return rc;
+    lgc_p1 *h = new lgc_p1();
+    h->device = device; h->w = width; h->p = precision; h->n = n; h->d = d; h->X = 0; h->have_y = false;
+    hipError_t e = hipMalloc(&h->X, n * (d + 1) * sizeof(int64_t));
+    if (e != hipSuccess) { delete h; return lgc_fail(LGC_ENOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    *out = h;
+    return LGC_OK;
+}
+extern "C" void lgc_p1_destroy(lgc_p1 *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->X) (void)hipFree(h->X);
+    delete h;
+}
+extern "C" int lgc_p1_set_data(lgc_p1 *h, const int64_t *Xq, const int64_t *yq) {
+    if (!h || !Xq) return lgc_fail(LGC_EINVAL, "null argument");
+    P1CHK(hipSetDevice(h->device));
+    const size_t ld = h->d + 1;
+    std::vector<int64_t> tmp(h->n * ld);
+    for (size_t k = 0; k < h->n; k++) {
+        memcpy(&tmp[k * ld], Xq + k * h->d, h->d * sizeof(int64_t));
+        tmp[k * ld + h->d] = yq ? yq[k] : 0;
+    }
+    P1CHK(hipMemcpy(h->X, tmp.data(), tmp.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    h->have_y = yq != 0;
+    return LGC_OK;
+}
+
+static uint64_t maskw(int w) { return w == 32 ? 0xffffffffull : ~0ull; }
+
+// shares of the block a data provider can compute alone (src/phase1.c:562-571; 359-384 in OT mode)
+extern "C" int lgc_p1_local(lgc_p1 *h, size_t c0, size_t c1, int with_y, uint64_t *out_A, uint64_t *out_b) {
+    if (!h || !out_A) return lgc_fail(LGC_EINVAL, "null argument");
+    if (c0 >= c1 || c1 > h->d) return lgc_fail(LGC_EINVAL, "bad column range");
+    if (with_y && (!h->have_y || !out_b)) return lgc_fail(LGC_EINVAL, "y requested but not set");
+    P1CHK(hipSetDevice(h->device));
+    const uint32_t own = (uint32_t)(c1 - c0), L = own + (with_y ? 1u : 0u);
+    std::vector<uint32_t> cols(L);
+    for (uint32_t i = 0; i < own; i++) cols[i] = (uint32_t)(c0 + i);
+    if (with_y) cols[own] = (uint32_t)h->d;
+    uint32_t *dcols = 0;
+    uint64_t *dC = 0, *ddiag = 0;
+    P1CHK(hipMalloc(&dcols, L * sizeof(uint32_t)));
+    P1CHK(hipMalloc(&dC, (size_t)L * L * sizeof(uint64_t)));
+    P1CHK(hipMalloc(&ddiag, own * sizeof(uint64_t)));
+    P1CHK(hipMemcpy(dcols, cols.data(), L * sizeof(uint32_t), hipMemcpyHostToDevice));
+    P1CHK(hipMemset(dC, 0, (size_t)L * L * sizeof(uint64_t)));
+    const uint32_t tiles = (L + 63) / 64;
+    // enough workgroups for 256 CUs: split K so that tiles^2/2 * ksplit >= ~1024
+    size_t ksplit = 1;
+    while ((size_t)tiles * tiles * ksplit < 2048 && h->n / (ksplit * 2) >= 256) ksplit *= 2;
+    size_t kchunk = (h->n + ksplit - 1) / ksplit;
+    kchunk = (kchunk + P1_KT - 1) / P1_KT * P1_KT;
+    ksplit = (h->n + kchunk - 1) / kchunk;
+    hipLaunchKernelGGL(p1_gram_kernel, dim3(tiles, tiles, (unsigned)ksplit), dim3(256), 0, 0, h->X, h->n, h->d + 1, dcols, L,
+                       dC, kchunk);
+    hipLaunchKernelGGL(p1_diag_kernel, dim3((own + 63) / 64), dim3(64), 0, 0, h->X, h->n, h->d + 1, dcols, own, h->p, h->w,
+                       (double)h->d, ddiag);
+    std::vector<uint64_t> C((size_t)L * L), diag(own);
+    P1CHK(hipMemcpy(C.data(), dC, C.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    P1CHK(hipMemcpy(diag.data(), ddiag, own * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    (void)hipFree(dcols); (void)hipFree(dC); (void)hipFree(ddiag);
+    const uint64_t m = maskw(h->w);
+    for (uint32_t i = 0; i < own; i++)
+        for (uint32_t j = 0; j <= i; j++)
+            out_A[(size_t)i * (i + 1) / 2 + j] = (i == j ? diag[i] : C[(size_t)i * L + j]) & m;
+    if (with_y)
+        for (uint32_t i = 0; i < own; i++) out_b[i] = C[(size_t)own * L + i] & m;
+    return LGC_OK;
+}
+
+// out[q][k] = column cols[q] (d means y) +/- V[q][k]: the vectors a DP sends in inner_product_ti
+// (b + x at phase1.c:201-207, a - y at 186-191)
+extern "C" int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const uint64_t *V, int sign, uint64_t *out) {
+    if (!h || !cols || !V || !out) return lgc_fail(LGC_EINVAL, "null argument");
+    if (npairs == 0) return LGC_OK;
+    for (size_t q = 0; q < npairs; q++) if (cols[q] > h->d) return lgc_fail(LGC_EINVAL, "column out of range");
+    P1CHK(hipSetDevice(h->device));
+    uint32_t *dcols = 0; uint64_t *dV = 0, *dout = 0;
+    size_t bytes = npairs * h->n * sizeof(uint64_t);
+    P1CHK(hipMalloc(&dcols, npairs * sizeof(uint32_t)));
+    P1CHK(hipMalloc(&dV, bytes));
+    P1CHK(hipMalloc(&dout, bytes));
+    P1CHK(hipMemcpy(dcols, cols, npairs * sizeof(uint32_t), hipMemcpyHostToDevice));
+    P1CHK(hipMemcpy(dV, V, bytes, hipMemcpyHostToDevice));
+    unsigned gx = (unsigned)((h->n + 255) / 256); if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(p1_mask_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, h->X, h->n, h->d + 1, dcols, dV, sign, dout);
+    P1CHK(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    const uint64_t m = maskw(h->w);
+    if (h->w == 32) for (size_t i = 0; i < npairs * h->n; i++) out[i] &= m;
+    (void)hipFree(dcols); (void)hipFree(dV); (void)hipFree(dout);
+    return LGC_OK;
+}
+
+// out[q] = <A[q], B[q]> (colsB == NULL) or <A[q], column colsB[q]>, minus sub[q]  (mod 2^w):
+// the share arithmetic of inner_product_ti (phase1.c:194-196, 220-222)
+extern "C" int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const uint32_t *colsB, size_t npairs,
+                          const uint64_t *sub, uint64_t *out) {
+    if (!h || !A || !out || (!B && !colsB)) return lgc_fail(LGC_EINVAL, "null argument");
+    if (npairs == 0) return LGC_OK;
+    P1CHK(hipSetDevice(h->device));
+    size_t bytes = npairs * h->n * sizeof(uint64_t);
+    uint64_t *dA = 0, *dB = 0, *dout = 0; uint32_t *dcols = 0;
+    P1CHK(hipMalloc(&dA, bytes));
+    P1CHK(hipMemcpy(dA, A, bytes, hipMemcpyHostToDevice));
+    if (colsB) {
+        for (size_t q = 0; q < npairs; q++) if (colsB[q] > h->d) return lgc_fail(LGC_EINVAL, "column out of range");
+        P1CHK(hipMalloc(&dcols, npairs * sizeof(uint32_t)));
+        P1CHK(hipMemcpy(dcols, colsB, npairs * sizeof(uint32_t), hipMemcpyHostToDevice));
+    } else {
+        P1CHK(hipMalloc(&dB, bytes));
+        P1CHK(hipMemcpy(dB, B, bytes, hipMemcpyHostToDevice));
+    }
+    P1CHK(hipMalloc(&dout, npairs * sizeof(uint64_t)));
+    P1CHK(hipMemset(dout, 0, npairs * sizeof(uint64_t)));
+    unsigned gx = (unsigned)((h->n + 255) / 256); if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(p1_dot_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, dA, dB, h->X, h->d + 1, dcols, h->n, dout);
+    P1CHK(hipMemcpy(out, dout, npairs * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    const uint64_t m = maskw(h->w);
+    for (size_t q = 0; q < npairs; q++) out[q] = (out[q] - (sub ? sub[q] : 0)) & m;
+    (void)hipFree(dA); if (dB) (void)hipFree(dB); if (dcols) (void)hipFree(dcols); (void)hipFree(dout);
+    return LGC_OK;
+}
+
+// Trusted initializer (phase1.c:241-287): for pairs [first_pair, first_pair + npairs) of the
+// (i, j) enumeration, words x[n], y[n], r drawn in this order from one AES-128-CTR stream keyed
+// by `seed`; xy_minus_r[q] = <x,y> - r.  Stream position of pair q is q * (2n + 1) words.
+extern "C" int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t first_pair, size_t npairs, size_t n, int width,
+                               uint64_t *x, uint64_t *y, uint64_t *r, uint64_t *xy_minus_r) {
+    if (!seed || !x || !y || !r || !xy_minus_r) return lgc_fail(LGC_EINVAL, "null argument");
+    if (width != 32 && width != 64) return lgc_fail(LGC_EINVAL, "width must be 32 or 64");
+    if (npairs == 0) return LGC_OK;
+    int rc = lgc_need_device(device);
+    if (rc) return rc;
+    rc = lgc_upload_constants();
+    if (rc) return rc;
+    AesTables t;
+    aes_build_tables(t, seed);
+    uint32_t *drk = 0;
+    P1CHK(hipMalloc(&drk, sizeof(t.rk)));
+    P1CHK(hipMemcpy(drk, t.rk, sizeof(t.rk), hipMemcpyHostToDevice));
+    const size_t wb = width / 8;
+    const uint64_t words_per_pair = 2 * n + 1;
+    const uint64_t byte0 = first_pair * words_per_pair * wb, byte1 = (first_pair + npairs) * words_per_pair * wb;
+    const uint64_t blk0 = byte0 / 16, blk1 = (byte1 + 15) / 16;
+    uint4 *dks = 0;
+    P1CHK(hipMalloc(&dks, (blk1 - blk0) * 16));
+    hipLaunchKernelGGL(ti_prg_kernel, dim3(512), dim3(1024), 0, 0, drk, blk0, blk1 - blk0, dks);
+    std::vector<uint8_t> ks((blk1 - blk0) * 16);
+    P1CHK(hipMemcpy(ks.data(), dks, ks.size(), hipMemcpyDeviceToHost));
+    (void)hipFree(dks); (void)hipFree(drk);
+    const uint8_t *s = ks.data() + (byte0 - blk0 * 16);
+    const uint64_t m = maskw(width);
+    // unpack the stream; <x,y> on the device through the generic dot kernel would need the data
+    // resident anyway: do the n-term wrap-around sums here on the unpacked words with the GPU dot
+    std::vector<uint64_t> xs(npairs * n), ys(npairs * n);
+    for (size_t q = 0; q < npairs; q++) {
+        for (size_t k = 0; k < n; k++) { uint64_t v = 0; memcpy(&v, s, wb); s += wb; xs[q * n + k] = v; }
+        for (size_t k = 0; k < n; k++) { uint64_t v = 0; memcpy(&v, s, wb); s += wb; ys[q * n + k] = v; }
+        uint64_t v = 0; memcpy(&v, s, wb); s += wb; r[q] = v;
+    }
+    memcpy(x, xs.data(), xs.size() * 8);
+    memcpy(y, ys.data(), ys.size() * 8);
+    uint64_t *dA = 0, *dB = 0, *dout = 0;
+    size_t bytes = npairs * n * 8;
+    P1CHK(hipMalloc(&dA, bytes)); P1CHK(hipMalloc(&dB, bytes)); P1CHK(hipMalloc(&dout, npairs * 8));
+    P1CHK(hipMemcpy(dA, xs.data(), bytes, hipMemcpyHostToDevice));
+    P1CHK(hipMemcpy(dB, ys.data(), bytes, hipMemcpyHostToDevice));
+    P1CHK(hipMemset(dout, 0, npairs * 8));
+    unsigned gx = (unsigned)((n + 255) / 256); if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(p1_dot_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, dA, dB, (const int64_t *)0, (size_t)0,
+                       (const uint32_t *)0, n, dout);
+    P1CHK(hipMemcpy(xy_minus_r, dout, npairs * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dout);
+    for (size_t q = 0; q < npairs; q++) xy_minus_r[q] = (xy_minus_r[q] - r[q]) & m;
+    return LGC_OK;
+}

@@ -78,12 +78,17 @@ def lib():
             ("lgc_program_build", [C.POINTER(vp), C.POINTER(System)]),
             ("lgc_program_info_get", [vp, C.POINTER(ProgramInfo)]),
             ("lgc_aes_bench", [ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+            ("lgc_p1_create", [C.POINTER(vp), ci, sz, sz, ci, ci]), ("lgc_p1_set_data", [vp, vp, vp]),
+            ("lgc_p1_local", [vp, sz, sz, ci, vp, vp]), ("lgc_p1_mask", [vp, vp, sz, vp, ci, vp]),
+            ("lgc_p1_dot", [vp, vp, vp, vp, sz, vp, vp]),
+            ("lgc_ti_generate", [ci, C.c_char_p, C.c_uint64, sz, sz, ci, vp, vp, vp, vp]),
             ("lgc_aes_encrypt", [ci, vp, vp, sz]),
         ]:
             fn = getattr(L, name)
             fn.restype, fn.argtypes = ci, args
         L.lgc_solver_destroy.argtypes = [vp]; L.lgc_solver_destroy.restype = None
         L.lgc_program_destroy.argtypes = [vp]; L.lgc_program_destroy.restype = None
+        L.lgc_p1_destroy.argtypes = [vp]; L.lgc_p1_destroy.restype = None
         L.lgc_program_records.argtypes = [vp]; L.lgc_program_records.restype = C.POINTER(Record)
         L.lgc_program_launches.argtypes = [vp]; L.lgc_program_launches.restype = C.POINTER(Launch)
         _lib = L
@@ -190,6 +195,67 @@ class Solver:
             self.close()
         except Exception:
             pass
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Phase1:
+    """One data provider's quantised data on the device (phase-1 aggregation arithmetic,
+    reference src/phase1.c)."""
+
+    def __init__(self, Xq, yq=None, width=64, precision=56, device=0):
+        Xq = np.ascontiguousarray(Xq, dtype=np.int64)
+        self.n, self.d = Xq.shape
+        self.w, self.p = width, precision
+        self._h = C.c_void_p()
+        _chk(lib().lgc_p1_create(C.byref(self._h), device, self.n, self.d, width, precision))
+        yq = None if yq is None else np.ascontiguousarray(yq, dtype=np.int64)
+        _chk(lib().lgc_p1_set_data(self._h, _vp(Xq), _vp(yq)))
+
+    def local(self, c0, c1, with_y=False):
+        own = c1 - c0
+        A = np.zeros(own * (own + 1) // 2, dtype=np.uint64)
+        b = np.zeros(own, dtype=np.uint64)
+        _chk(lib().lgc_p1_local(self._h, c0, c1, 1 if with_y else 0, _vp(A), _vp(b)))
+        return (A, b) if with_y else A
+
+    def mask(self, cols, V, sign):
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        V = np.ascontiguousarray(V, dtype=np.uint64).reshape(len(cols), self.n)
+        out = np.empty_like(V)
+        _chk(lib().lgc_p1_mask(self._h, _vp(cols), len(cols), _vp(V), sign, _vp(out)))
+        return out
+
+    def dot(self, A, B=None, cols=None, sub=None):
+        A = np.ascontiguousarray(A, dtype=np.uint64).reshape(-1, self.n)
+        npairs = A.shape[0]
+        B = None if B is None else np.ascontiguousarray(B, dtype=np.uint64).reshape(npairs, self.n)
+        cols = None if cols is None else np.ascontiguousarray(cols, dtype=np.uint32)
+        sub = None if sub is None else np.ascontiguousarray(sub, dtype=np.uint64)
+        out = np.zeros(npairs, dtype=np.uint64)
+        _chk(lib().lgc_p1_dot(self._h, _vp(A), _vp(B), _vp(cols), npairs, _vp(sub), _vp(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().lgc_p1_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ti_generate(seed, first_pair, npairs, n, width=64, device=0):
+    """(x, y, r, xy_minus_r) of the trusted initializer for `npairs` cross-party pairs"""
+    x = np.zeros((npairs, n), dtype=np.uint64); y = np.zeros((npairs, n), dtype=np.uint64)
+    r = np.zeros(npairs, dtype=np.uint64); xyr = np.zeros(npairs, dtype=np.uint64)
+    _chk(lib().lgc_ti_generate(device, seed, first_pair, npairs, n, width, _vp(x), _vp(y), _vp(r), _vp(xyr)))
+    return x, y, r, xyr
 
 
 def aes_bench(waves=8192, blocks_per_lane=256, device=0):

@@ -227,6 +227,21 @@ void gcc_aes_encrypt(const uint8_t *in, uint8_t *out, size_t n) {
         _mm_storeu_si128((__m128i *)out + i, s[0]);
     }
 }
+// AES-128-CTR keystream with an arbitrary key: block c = AES_key(c), little-endian counter
+// (mirror of ti_prg_kernel in linreg-mpc_amd/csrc/phase1.hip)
+void gcc_aes_ctr(const uint8_t key[16], uint64_t first_block, uint64_t nblocks, uint8_t *out) {
+    AesTables t;
+    aes_build_tables(t, key);
+    __m128i rk[11];
+    for (int i = 0; i < 11; i++) rk[i] = _mm_loadu_si128((const __m128i *)&t.rk[4 * i]);
+    for (uint64_t b = 0; b < nblocks; b++) {
+        __m128i s = _mm_set_epi64x(0, (long long)(first_block + b));
+        s = _mm_xor_si128(s, rk[0]);
+        for (int r = 1; r < 10; r++) s = _mm_aesenc_si128(s, rk[r]);
+        s = _mm_aesenclast_si128(s, rk[10]);
+        _mm_storeu_si128((__m128i *)out + b, s);
+    }
+}
 // portable T-table path of gc_aes.h on the host (the algorithm the GPU runs)
 void gcc_aes_encrypt_ttable(const uint8_t *in, uint8_t *out, size_t n) {
     init();

@@ -28,6 +28,7 @@ class GcCpu:
         L.gcc_aes_encrypt.argtypes = [vp, vp, sz]
         L.gcc_aes_encrypt_ttable.argtypes = [vp, vp, sz]
         L.gcc_hash.argtypes = [vp, u64, vp]
+        L.gcc_aes_ctr.argtypes = [C.c_char_p, u64, u64, vp]
         L.gcc_baseline_mac.restype = C.c_double
         L.gcc_baseline_mac.argtypes = [ci, ci, u32, u32, C.POINTER(u64), C.POINTER(C.c_double)]
 
@@ -48,6 +49,21 @@ class GcCpu:
         out = np.empty_like(blocks)
         (self.lib.gcc_aes_encrypt_ttable if ttable else self.lib.gcc_aes_encrypt)(_p(blocks), _p(out), len(blocks))
         return out
+
+    def aes_ctr(self, key, first_block, nblocks):
+        out = np.zeros(nblocks * 16, dtype=np.uint8)
+        self.lib.gcc_aes_ctr(key, first_block, nblocks, _p(out))
+        return out
+
+    def ti_stream_words(self, seed, first_word, nwords, w):
+        """words [first_word, first_word + nwords) of the TI's AES-128-CTR stream (w-bit words)"""
+        wb = w // 8
+        b0 = first_word * wb // 16
+        b1 = ((first_word + nwords) * wb + 15) // 16
+        ks = self.aes_ctr(seed, b0, b1 - b0)
+        off = first_word * wb - b0 * 16
+        raw = ks[off:off + nwords * wb]
+        return raw.view(np.uint64 if w == 64 else np.uint32).astype(np.uint64)
 
     def garble_eval(self, prog, shares, seed=b"\x01" * 16):
         """Run a whole program (linreg_gc.Program) through CPU garbler + evaluator.
