@@ -156,6 +156,34 @@ int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const uint32_t *
 int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t first_pair, size_t npairs, size_t n, int width,
                     uint64_t *x, uint64_t *y, uint64_t *r, uint64_t *xy_minus_r);
 
+/* ------------------------------------------------------------- OT extension */
+/* IKNP semi-honest OT extension, kappa = 128.  The base OTs (Naor-Pinkas in Obliv-C) run on the
+ * host; their outputs come in as seeds: the extension sender holds delta and k_j^{delta_j}, the
+ * extension receiver holds (k_j^0, k_j^1).  Replaces honestOTExtSenderNew / RecverNew and the
+ * Send1Of2 / Recv1Of2 / correlated variants (src/phase1.c:58-65,84-89,394-397; src/input.c:28-44,67,108).
+ * A transfer is three calls: receiver *_recv_start -> u (16 bytes per OT, lgc_ot_u_bytes(m));
+ * sender *_send(u) -> payload; receiver *_recv_finish(payload). */
+typedef struct lgc_ot_sender lgc_ot_sender;
+typedef struct lgc_ot_receiver lgc_ot_receiver;
+int lgc_ot_sender_create(lgc_ot_sender **out, int device, const uint8_t delta[16], const uint8_t seeds[128][16]);
+void lgc_ot_sender_destroy(lgc_ot_sender *s);
+int lgc_ot_receiver_create(lgc_ot_receiver **out, int device, const uint8_t seeds0[128][16], const uint8_t seeds1[128][16]);
+void lgc_ot_receiver_destroy(lgc_ot_receiver *r);
+size_t lgc_ot_u_bytes(uint64_t m);
+/* Gilboa inner products (inner_product_ot_recver / _sender, src/phase1.c:53-96), batched over
+ * npairs: OT index (q*n + k)*width + bit; receiver choice = bit of a[q][k] (LSB first), sender
+ * correlation 2^bit * b[q][k] + s.  y: npairs*n*width words.  shares: npairs words each side;
+ * share_sender + share_receiver = <a[q], b[q]> mod 2^width. */
+int lgc_ot_gilboa_recv_start(lgc_ot_receiver *r, const uint64_t *a, size_t npairs, size_t n, int width, uint8_t *u_out);
+int lgc_ot_gilboa_send(lgc_ot_sender *s, const uint64_t *b, size_t npairs, size_t n, int width, const uint8_t *u_in,
+                       uint64_t *y_out, uint64_t *shares);
+int lgc_ot_gilboa_recv_finish(lgc_ot_receiver *r, const uint64_t *y_in, uint64_t *shares);
+/* 1-of-2 OT of 16-byte messages (wire labels; dcsSendIntArray / dcrRecvBitArray, src/input.c:37-113).
+ * choice: one byte per OT; e: 32 bytes per OT; out: 16 bytes per OT. */
+int lgc_ot_labels_recv_start(lgc_ot_receiver *r, const uint8_t *choice, size_t m, uint8_t *u_out);
+int lgc_ot_labels_send(lgc_ot_sender *s, const uint8_t *msg0, const uint8_t *msg1, size_t m, const uint8_t *u_in, uint8_t *e_out);
+int lgc_ot_labels_recv_finish(lgc_ot_receiver *r, const uint8_t *e_in, uint8_t *out);
+
 /* ------------------------------------------------------- micro-benchmarks */
 /* Stand-alone LDS T-table AES throughput (the "AES roofline" of the north
  * star): blocks_per_lane AES-128 encryptions in every lane of `waves` waves.

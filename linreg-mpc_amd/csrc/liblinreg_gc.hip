@@ -2,3 +2,4 @@
 // constants c_rk / c_te0 of gc_device.h must exist once).
 #include "gc_engine.hip"
 #include "phase1.hip"
+#include "ot.hip"

@@ -82,6 +82,13 @@ def lib():
             ("lgc_p1_local", [vp, sz, sz, ci, vp, vp]), ("lgc_p1_mask", [vp, vp, sz, vp, ci, vp]),
             ("lgc_p1_dot", [vp, vp, vp, vp, sz, vp, vp]),
             ("lgc_ti_generate", [ci, C.c_char_p, C.c_uint64, sz, sz, ci, vp, vp, vp, vp]),
+            ("lgc_ot_sender_create", [C.POINTER(vp), ci, C.c_char_p, vp]),
+            ("lgc_ot_receiver_create", [C.POINTER(vp), ci, vp, vp]),
+            ("lgc_ot_gilboa_recv_start", [vp, vp, sz, sz, ci, vp]),
+            ("lgc_ot_gilboa_send", [vp, vp, sz, sz, ci, vp, vp, vp]),
+            ("lgc_ot_gilboa_recv_finish", [vp, vp, vp]),
+            ("lgc_ot_labels_recv_start", [vp, vp, sz, vp]), ("lgc_ot_labels_send", [vp, vp, vp, sz, vp, vp]),
+            ("lgc_ot_labels_recv_finish", [vp, vp, vp]),
             ("lgc_aes_encrypt", [ci, vp, vp, sz]),
         ]:
             fn = getattr(L, name)
@@ -89,6 +96,9 @@ def lib():
         L.lgc_solver_destroy.argtypes = [vp]; L.lgc_solver_destroy.restype = None
         L.lgc_program_destroy.argtypes = [vp]; L.lgc_program_destroy.restype = None
         L.lgc_p1_destroy.argtypes = [vp]; L.lgc_p1_destroy.restype = None
+        L.lgc_ot_sender_destroy.argtypes = [vp]; L.lgc_ot_sender_destroy.restype = None
+        L.lgc_ot_receiver_destroy.argtypes = [vp]; L.lgc_ot_receiver_destroy.restype = None
+        L.lgc_ot_u_bytes.argtypes = [C.c_uint64]; L.lgc_ot_u_bytes.restype = sz
         L.lgc_program_records.argtypes = [vp]; L.lgc_program_records.restype = C.POINTER(Record)
         L.lgc_program_launches.argtypes = [vp]; L.lgc_program_launches.restype = C.POINTER(Launch)
         _lib = L
@@ -256,6 +266,81 @@ def ti_generate(seed, first_pair, npairs, n, width=64, device=0):
     r = np.zeros(npairs, dtype=np.uint64); xyr = np.zeros(npairs, dtype=np.uint64)
     _chk(lib().lgc_ti_generate(device, seed, first_pair, npairs, n, width, _vp(x), _vp(y), _vp(r), _vp(xyr)))
     return x, y, r, xyr
+
+
+class OtSender:
+    """IKNP extension sender (holds delta and the 128 seeds k_j^{delta_j} from the base OTs)"""
+
+    def __init__(self, delta, seeds, device=0):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint8).reshape(128, 16)
+        self._h = C.c_void_p()
+        _chk(lib().lgc_ot_sender_create(C.byref(self._h), device, bytes(delta), _vp(seeds)))
+
+    def gilboa(self, b, width, u):
+        b = np.ascontiguousarray(b, dtype=np.uint64); npairs, n = b.shape
+        y = np.zeros(npairs * n * width, dtype=np.uint64); sh = np.zeros(npairs, dtype=np.uint64)
+        _chk(lib().lgc_ot_gilboa_send(self._h, _vp(b), npairs, n, width, _vp(u), _vp(y), _vp(sh)))
+        return y, sh
+
+    def labels(self, m0, m1, u):
+        m0 = np.ascontiguousarray(m0, dtype=np.uint8).reshape(-1, 16); m1 = np.ascontiguousarray(m1, dtype=np.uint8).reshape(-1, 16)
+        e = np.zeros((len(m0), 32), dtype=np.uint8)
+        _chk(lib().lgc_ot_labels_send(self._h, _vp(m0), _vp(m1), len(m0), _vp(u), _vp(e)))
+        return e
+
+    def close(self):
+        if self._h:
+            lib().lgc_ot_sender_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OtReceiver:
+    """IKNP extension receiver (holds the 128 seed pairs (k_j^0, k_j^1) from the base OTs)"""
+
+    def __init__(self, seeds0, seeds1, device=0):
+        seeds0 = np.ascontiguousarray(seeds0, dtype=np.uint8).reshape(128, 16)
+        seeds1 = np.ascontiguousarray(seeds1, dtype=np.uint8).reshape(128, 16)
+        self._h = C.c_void_p()
+        _chk(lib().lgc_ot_receiver_create(C.byref(self._h), device, _vp(seeds0), _vp(seeds1)))
+
+    def gilboa_start(self, a, width):
+        a = np.ascontiguousarray(a, dtype=np.uint64); npairs, n = a.shape
+        self._np = npairs
+        u = np.zeros(lib().lgc_ot_u_bytes(npairs * n * width), dtype=np.uint8)
+        _chk(lib().lgc_ot_gilboa_recv_start(self._h, _vp(a), npairs, n, width, _vp(u)))
+        return u
+
+    def gilboa_finish(self, y):
+        sh = np.zeros(self._np, dtype=np.uint64)
+        _chk(lib().lgc_ot_gilboa_recv_finish(self._h, _vp(np.ascontiguousarray(y, dtype=np.uint64)), _vp(sh)))
+        return sh
+
+    def labels_start(self, choice):
+        choice = np.ascontiguousarray(choice, dtype=np.uint8)
+        self._m = len(choice)
+        u = np.zeros(lib().lgc_ot_u_bytes(self._m), dtype=np.uint8)
+        _chk(lib().lgc_ot_labels_recv_start(self._h, _vp(choice), self._m, _vp(u)))
+        return u
+
+    def labels_finish(self, e):
+        out = np.zeros((self._m, 16), dtype=np.uint8)
+        _chk(lib().lgc_ot_labels_recv_finish(self._h, _vp(np.ascontiguousarray(e, dtype=np.uint8)), _vp(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().lgc_ot_receiver_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def aes_bench(waves=8192, blocks_per_lane=256, device=0):

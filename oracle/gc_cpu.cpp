@@ -242,6 +242,79 @@ void gcc_aes_ctr(const uint8_t key[16], uint64_t first_block, uint64_t nblocks, 
         _mm_storeu_si128((__m128i *)out + b, s);
     }
 }
+// ---- CPU mirror of the IKNP extension of linreg-mpc_amd/csrc/ot.hip (both roles in one call).
+// seeds0/seeds1: 128 x 16 bytes; delta: 16 bytes; cbits: m bits packed LSB-first.
+// Outputs: u (128 columns x m128 blocks), rows_t / rows_q (m128*128 x 16 bytes).
+static inline __m128i hash1(__m128i x, uint64_t tw) {
+    __m128i k = hprep(x, tw);
+    __m128i h[1] = {k};
+    aesni_n<1>(h);
+    return _mm_xor_si128(h[0], k);
+}
+void gcc_iknp_extend(const uint8_t *seeds0, const uint8_t *seeds1, const uint8_t delta[16], const uint8_t *cbits,
+                     uint64_t m, uint64_t ctr0, uint8_t *u, uint8_t *rows_t, uint8_t *rows_q) {
+    init();
+    const uint64_t m128 = (m + 127) / 128;
+    std::vector<uint8_t> T0(128 * m128 * 16), Q(128 * m128 * 16), g1(m128 * 16);
+    for (int j = 0; j < 128; j++) {
+        gcc_aes_ctr(seeds0 + 16 * j, ctr0, m128, &T0[(size_t)j * m128 * 16]);
+        gcc_aes_ctr(seeds1 + 16 * j, ctr0, m128, g1.data());
+        const bool dj = (delta[j >> 3] >> (j & 7)) & 1;
+        for (uint64_t k = 0; k < m128 * 16; k++) {
+            uint8_t uu = (uint8_t)(T0[(size_t)j * m128 * 16 + k] ^ g1[k] ^ cbits[k]);
+            u[(size_t)j * m128 * 16 + k] = uu;
+            // sender: G(k^{delta_j}) ^ delta_j * u
+            Q[(size_t)j * m128 * 16 + k] = dj ? (uint8_t)(g1[k] ^ uu) : T0[(size_t)j * m128 * 16 + k];
+        }
+    }
+    memset(rows_t, 0, m128 * 128 * 16);
+    memset(rows_q, 0, m128 * 128 * 16);
+    for (uint64_t i = 0; i < m128 * 128; i++)
+        for (int j = 0; j < 128; j++) {
+            size_t byte = (size_t)j * m128 * 16 + (i >> 3);
+            if ((T0[byte] >> (i & 7)) & 1) rows_t[i * 16 + (j >> 3)] |= (uint8_t)(1u << (j & 7));
+            if ((Q[byte] >> (i & 7)) & 1) rows_q[i * 16 + (j >> 3)] |= (uint8_t)(1u << (j & 7));
+        }
+}
+// Gilboa payload arithmetic on given rows: y, sender shares, receiver shares
+void gcc_iknp_gilboa(const uint8_t *rows_t, const uint8_t *rows_q, const uint8_t delta[16], const uint64_t *a,
+                     const uint64_t *b, uint64_t npairs, uint64_t n, int w, uint64_t tweak0, uint64_t *y,
+                     uint64_t *share_s, uint64_t *share_r) {
+    init();
+    const uint64_t mask = w == 32 ? 0xffffffffull : ~0ull;
+    __m128i D = _mm_loadu_si128((const __m128i *)delta);
+    for (uint64_t q = 0; q < npairs; q++) {
+        uint64_t ss = 0, sr = 0;
+        for (uint64_t k = 0; k < n; k++)
+            for (int bit = 0; bit < w; bit++) {
+                uint64_t i = (q * n + k) * (uint64_t)w + (uint64_t)bit;
+                __m128i qi = _mm_loadu_si128((const __m128i *)rows_q + i), ti = _mm_loadu_si128((const __m128i *)rows_t + i);
+                uint64_t x0 = (uint64_t)_mm_cvtsi128_si64(hash1(qi, tweak0 + i)) & mask;
+                uint64_t h1 = (uint64_t)_mm_cvtsi128_si64(hash1(_mm_xor_si128(qi, D), tweak0 + i)) & mask;
+                uint64_t d = (b[q * n + k] << bit) & mask;
+                y[i] = (x0 + d - h1) & mask;
+                ss -= x0;
+                uint64_t v = (uint64_t)_mm_cvtsi128_si64(hash1(ti, tweak0 + i)) & mask;
+                if ((a[q * n + k] >> bit) & 1) v += y[i];
+                sr += v;
+            }
+        share_s[q] = ss & mask;
+        share_r[q] = sr & mask;
+    }
+}
+void gcc_iknp_labels(const uint8_t *rows_t, const uint8_t *rows_q, const uint8_t delta[16], const uint8_t *choice,
+                     const uint8_t *m0, const uint8_t *m1, uint64_t m, uint64_t tweak0, uint8_t *e, uint8_t *out) {
+    init();
+    __m128i D = _mm_loadu_si128((const __m128i *)delta);
+    for (uint64_t i = 0; i < m; i++) {
+        __m128i qi = _mm_loadu_si128((const __m128i *)rows_q + i), ti = _mm_loadu_si128((const __m128i *)rows_t + i);
+        __m128i e0 = _mm_xor_si128(_mm_loadu_si128((const __m128i *)m0 + i), hash1(qi, tweak0 + i));
+        __m128i e1 = _mm_xor_si128(_mm_loadu_si128((const __m128i *)m1 + i), hash1(_mm_xor_si128(qi, D), tweak0 + i));
+        _mm_storeu_si128((__m128i *)e + 2 * i, e0);
+        _mm_storeu_si128((__m128i *)e + 2 * i + 1, e1);
+        _mm_storeu_si128((__m128i *)out + i, _mm_xor_si128(choice[i] ? e1 : e0, hash1(ti, tweak0 + i)));
+    }
+}
 // portable T-table path of gc_aes.h on the host (the algorithm the GPU runs)
 void gcc_aes_encrypt_ttable(const uint8_t *in, uint8_t *out, size_t n) {
     init();

@@ -29,6 +29,9 @@ class GcCpu:
         L.gcc_aes_encrypt_ttable.argtypes = [vp, vp, sz]
         L.gcc_hash.argtypes = [vp, u64, vp]
         L.gcc_aes_ctr.argtypes = [C.c_char_p, u64, u64, vp]
+        L.gcc_iknp_extend.argtypes = [vp, vp, C.c_char_p, vp, u64, u64, vp, vp, vp]
+        L.gcc_iknp_gilboa.argtypes = [vp, vp, C.c_char_p, vp, vp, u64, u64, ci, u64, vp, vp, vp]
+        L.gcc_iknp_labels.argtypes = [vp, vp, C.c_char_p, vp, vp, vp, u64, u64, vp, vp]
         L.gcc_baseline_mac.restype = C.c_double
         L.gcc_baseline_mac.argtypes = [ci, ci, u32, u32, C.POINTER(u64), C.POINTER(C.c_double)]
 
@@ -64,6 +67,30 @@ class GcCpu:
         off = first_word * wb - b0 * 16
         raw = ks[off:off + nwords * wb]
         return raw.view(np.uint64 if w == 64 else np.uint32).astype(np.uint64)
+
+    def iknp_extend(self, seeds0, seeds1, delta, cbits_packed, m, ctr0):
+        m128 = (m + 127) // 128
+        cbits_packed = np.ascontiguousarray(cbits_packed).view(np.uint8).ravel()
+        cb = np.zeros(m128 * 16, dtype=np.uint8); cb[:len(cbits_packed)] = cbits_packed
+        u = np.zeros(128 * m128 * 16, dtype=np.uint8)
+        rt = np.zeros(m128 * 128 * 16, dtype=np.uint8); rq = np.zeros(m128 * 128 * 16, dtype=np.uint8)
+        self.lib.gcc_iknp_extend(_p(np.ascontiguousarray(seeds0)), _p(np.ascontiguousarray(seeds1)), bytes(delta), _p(cb), m, ctr0,
+                                 _p(u), _p(rt), _p(rq))
+        return u, rt, rq
+
+    def iknp_gilboa(self, rt, rq, delta, a, b, w, tweak0):
+        a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
+        npairs, n = a.shape
+        y = np.zeros(npairs * n * w, dtype=np.uint64); ss = np.zeros(npairs, dtype=np.uint64); sr = np.zeros(npairs, dtype=np.uint64)
+        self.lib.gcc_iknp_gilboa(_p(rt), _p(rq), bytes(delta), _p(a), _p(b), npairs, n, w, tweak0, _p(y), _p(ss), _p(sr))
+        return y, ss, sr
+
+    def iknp_labels(self, rt, rq, delta, choice, m0, m1, tweak0):
+        m = len(choice)
+        e = np.zeros((m, 32), dtype=np.uint8); out = np.zeros((m, 16), dtype=np.uint8)
+        self.lib.gcc_iknp_labels(_p(rt), _p(rq), bytes(delta), _p(np.ascontiguousarray(choice, dtype=np.uint8)),
+                                 _p(np.ascontiguousarray(m0, dtype=np.uint8)), _p(np.ascontiguousarray(m1, dtype=np.uint8)), m, tweak0, _p(e), _p(out))
+        return e, out
 
     def garble_eval(self, prog, shares, seed=b"\x01" * 16):
         """Run a whole program (linreg_gc.Program) through CPU garbler + evaluator.

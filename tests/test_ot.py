@@ -1,0 +1,112 @@
+"""IKNP OT extension: CPU mirror self-consistency (no GPU) and GPU vs mirror (bit-exact transcripts)."""
+import numpy as np
+import pytest
+
+
+def _setup(rng):
+    seeds0 = rng.integers(0, 256, size=(128, 16), dtype=np.uint8)
+    seeds1 = rng.integers(0, 256, size=(128, 16), dtype=np.uint8)
+    delta = rng.integers(0, 256, size=16, dtype=np.uint8)
+    dbits = np.unpackbits(delta, bitorder="little")
+    seeds_s = np.where(dbits[:, None] == 1, seeds1, seeds0)      # what the base OTs give the sender
+    return seeds0, seeds1, delta, seeds_s
+
+
+def _ip(a, b, w):
+    m = (1 << w) - 1
+    return [sum(int(x) * int(y) for x, y in zip(ra, rb)) & m for ra, rb in zip(a, b)]
+
+
+@pytest.mark.parametrize("w", [64, 32])
+def test_cpu_mirror_gilboa_and_labels(gccpu, w):
+    rng = np.random.default_rng(w)
+    seeds0, seeds1, delta, _ = _setup(rng)
+    npairs, n = 3, 5
+    mask = np.uint64((1 << w) - 1) if w < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    a = rng.integers(0, 2 ** 63, size=(npairs, n), dtype=np.uint64) & mask
+    b = rng.integers(0, 2 ** 63, size=(npairs, n), dtype=np.uint64) & mask
+    m = npairs * n * w
+    cb = a.view(np.uint8) if w == 64 else a.astype(np.uint32).view(np.uint8)
+    u, rt, rq = gccpu.iknp_extend(seeds0, seeds1, delta.tobytes(), cb, m, 0)
+    y, ss, sr = gccpu.iknp_gilboa(rt, rq, delta.tobytes(), a, b, w, 0)
+    got = [(int(x) + int(z)) & ((1 << w) - 1) for x, z in zip(ss, sr)]
+    assert got == _ip(a, b, w)
+    # labels
+    mm = 300
+    choice = rng.integers(0, 2, size=mm, dtype=np.uint8)
+    m0 = rng.integers(0, 256, size=(mm, 16), dtype=np.uint8); m1 = rng.integers(0, 256, size=(mm, 16), dtype=np.uint8)
+    u, rt, rq = gccpu.iknp_extend(seeds0, seeds1, delta.tobytes(), np.packbits(choice, bitorder="little"), mm, 7)
+    e, out = gccpu.iknp_labels(rt, rq, delta.tobytes(), choice, m0, m1, 1000)
+    assert np.array_equal(out, np.where(choice[:, None] == 1, m1, m0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,npairs,n", [(64, 3, 17), (32, 2, 50), (64, 1, 1000)])
+def test_gpu_gilboa_matches_mirror(lgc, gccpu, w, npairs, n):
+    rng = np.random.default_rng(w + n)
+    seeds0, seeds1, delta, seeds_s = _setup(rng)
+    mask = np.uint64((1 << w) - 1) if w < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    S = lgc.OtSender(delta.tobytes(), seeds_s); R = lgc.OtReceiver(seeds0, seeds1)
+    ctr = tw = 0
+    for rep in range(2):                      # two transfers on one session: stream positions advance
+        a = rng.integers(0, 2 ** 63, size=(npairs, n), dtype=np.uint64) & mask
+        b = rng.integers(0, 2 ** 63, size=(npairs, n), dtype=np.uint64) & mask
+        u = R.gilboa_start(a, w)
+        y, ss = S.gilboa(b, w, u)
+        sr = R.gilboa_finish(y)
+        assert [(int(x) + int(z)) & ((1 << w) - 1) for x, z in zip(ss, sr)] == _ip(a, b, w)
+        m = npairs * n * w
+        cb = a.view(np.uint8) if w == 64 else a.astype(np.uint32).view(np.uint8)
+        cu, rt, rq = gccpu.iknp_extend(seeds0, seeds1, delta.tobytes(), cb, m, ctr)
+        cy, css, csr = gccpu.iknp_gilboa(rt, rq, delta.tobytes(), a, b, w, tw)
+        assert np.array_equal(u, cu)
+        assert np.array_equal(y, cy) and np.array_equal(ss, css) and np.array_equal(sr, csr)
+        ctr += (m + 127) // 128
+        tw += m
+    S.close(); R.close()
+
+
+@pytest.mark.gpu
+def test_gpu_label_ot_matches_mirror(lgc, gccpu):
+    rng = np.random.default_rng(5)
+    seeds0, seeds1, delta, seeds_s = _setup(rng)
+    S = lgc.OtSender(delta.tobytes(), seeds_s); R = lgc.OtReceiver(seeds0, seeds1)
+    m = 5150 * 4 + 3                          # ragged: not a multiple of 128
+    choice = rng.integers(0, 2, size=m, dtype=np.uint8)
+    m0 = rng.integers(0, 256, size=(m, 16), dtype=np.uint8); m1 = rng.integers(0, 256, size=(m, 16), dtype=np.uint8)
+    u = R.labels_start(choice)
+    e = S.labels(m0, m1, u)
+    out = R.labels_finish(e)
+    assert np.array_equal(out, np.where(choice[:, None] == 1, m1, m0))
+    cu, rt, rq = gccpu.iknp_extend(seeds0, seeds1, delta.tobytes(), np.packbits(choice, bitorder="little"), m, 0)
+    ce, cout = gccpu.iknp_labels(rt, rq, delta.tobytes(), choice, m0, m1, 0)
+    assert np.array_equal(u, cu) and np.array_equal(e, ce)
+    S.close(); R.close()
+
+
+@pytest.mark.gpu
+def test_gpu_phase1_ot_mode_shares(lgc, oracle):
+    """OT-mode phase 1 for two data providers (role rule of src/phase1.c:392): the GPU Gilboa
+    shares plus the local blocks recombine to the oracle's aggregate"""
+    rng = np.random.default_rng(9)
+    n, d, p, w = 40, 4, 56, 64
+    X = rng.standard_normal((n, d)); X /= np.abs(X).max(axis=0)
+    yv = X @ rng.random(d) + 0.1 * rng.standard_normal(n)
+    Xq = oracle.quantize(X, p, n, w).reshape(n, d); yq = oracle.quantize(yv, p, n, w)
+    A, b = oracle.aggregate(Xq, yq, n, d, p, w)
+    seeds0, seeds1, delta, seeds_s = _setup(rng)
+    # DPs 0 (cols 0,1) and 1 (cols 2,3 + y): different parity -> the higher index is the OT sender
+    S = lgc.OtSender(delta.tobytes(), seeds_s); R = lgc.OtReceiver(seeds0, seeds1)
+    U = lambda v: np.ascontiguousarray(v).astype(np.int64).view(np.uint64)
+    pairs = [(i, j) for i in (2, 3) for j in (0, 1)]       # sender rows i (party 1), receiver cols j (party 0)
+    a = np.stack([U(Xq[:, j]) for (_, j) in pairs] + [U(Xq[:, j]) for j in (0, 1)])       # receiver values
+    bv = np.stack([U(Xq[:, i]) for (i, _) in pairs] + [U(yq), U(yq)])                     # sender values (target rows last)
+    u = R.gilboa_start(a, w)
+    y, ss = S.gilboa(bv, w, u)
+    sr = R.gilboa_finish(y)
+    m = (1 << 64) - 1
+    for q, (i, j) in enumerate(pairs):
+        assert (int(ss[q]) + int(sr[q])) & m == int(A[oracle.lib.orc_idx(i, j)])
+    for t, j in enumerate((0, 1)):
+        assert (int(ss[4 + t]) + int(sr[4 + t])) & m == int(b[j])
+    S.close(); R.close()
