@@ -132,6 +132,35 @@ const lgc_launch *lgc_program_launches(const lgc_program *p);
 int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[16], const uint64_t *shares,
               int64_t *beta, int64_t *trace, lgc_stats *stats);
 
+/* ----------------------------------------- phase 2 with the two roles apart */
+/* CSP (party 1, garbler) and Evaluator (party 2) as separate objects, possibly in different
+ * processes (src/cmd/linreg.c:145-199).  The host carries the bytes: input labels (through the OT
+ * below, src/input.c), one table buffer per launch, the garbler's decode bits at the end.
+ * Both sides must pass the same `sys` and `max_launch_table_bytes` (0 = 256 MiB): the lowered
+ * program, and with it every table offset and gate id, is a function of those only. */
+#define LGC_ROLE_GARBLER 1
+#define LGC_ROLE_EVALUATOR 2
+typedef struct lgc_party lgc_party;
+int lgc_party_create(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
+                     size_t max_launch_table_bytes);
+void lgc_party_destroy(lgc_party *p);
+size_t lgc_party_num_launches(const lgc_party *p);
+size_t lgc_party_table_bytes(const lgc_party *p, size_t launch);
+size_t lgc_party_input_bits(const lgc_party *p);      /* (T + d) * width, per share */
+size_t lgc_party_num_reveal(const lgc_party *p);
+uint64_t lgc_party_and_gates(const lgc_party *p);
+/* garbler: per input bit of share k (word-major, LSB first: sel[i*intsize+j], src/input.c:41) the
+ * label pair (m0, m1), 16 bytes each -- the sender messages of dcrRecvBitArray's OT (input.c:94-108) */
+int lgc_party_input_pairs(lgc_party *p, size_t share, uint8_t *m0, uint8_t *m1);
+/* garbler: labels of values it knows itself (feedOblivLLong for its own party, linear.oc:116-127) */
+int lgc_party_encode_inputs(lgc_party *p, size_t share, const uint64_t *values, uint8_t *labels_out);
+/* evaluator: the labels a data provider forwarded (dcsSendIntArray -> orecv, input.c:46, 84-92) */
+int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint8_t *labels);
+int lgc_party_garble(lgc_party *p, size_t launch, uint8_t *tables_out);
+int lgc_party_evaluate(lgc_party *p, size_t launch, const uint8_t *tables_in);
+int lgc_party_decode_bits(lgc_party *p, uint64_t *dec_out);       /* garbler -> evaluator */
+int lgc_party_finish(lgc_party *p, const uint64_t *garbler_dec, int64_t *beta, int64_t *trace, int64_t *inputs);
+
 /* ------------------------------------------------------------------ phase 1 */
 /* Quantised data of one data provider, resident on the device (src/phase1.c:473-476 result). */
 typedef struct lgc_p1 lgc_p1;

@@ -85,10 +85,10 @@ gc_input_kernel(Lbl *wordsG, Lbl *wordsE, const uint64_t *vals, uint32_t base, u
     Lbl z;
     hash_n<1, LdsTab>(lt, c_rk, &seed, &tw, &z);
     if (lane >= w) z = lzero();
-    uint32_t bit = (uint32_t)(vals[k] >> lane) & 1u;
+    uint32_t bit = vals ? (uint32_t)(vals[k] >> lane) & 1u : 0u;
     if (lane >= w) bit = 0;
-    st_lbl(wordsG + (size_t)id * 64 + lane, z);
-    st_lbl(wordsE + (size_t)id * 64 + lane, lxor(z, lmask(R, bit)));
+    if (wordsG) st_lbl(wordsG + (size_t)id * 64 + lane, z);
+    if (wordsE) st_lbl(wordsE + (size_t)id * 64 + lane, lxor(z, lmask(R, bit)));
 }
 
 __global__ void __launch_bounds__(1024)
@@ -148,7 +148,8 @@ static uint64_t lambda_to_fixed(double lambda, int p, int w) {
     return (uint64_t)(int64_t)t;
 }
 
-static void build(Program &P, const lgc_system *sys) {
+static void build(Program &P, const lgc_system *sys, uint64_t cap_steps = 0) {
+    if (cap_steps) P.cap_steps = cap_steps;
     int iters = sys->algorithm == LGC_ALG_CGD ? sys->num_iterations : 0;
     build_program(P, sys->algorithm, sys->d, sys->width, sys->precision, iters, sys->nshares, sys->normalize,
                   lambda_to_fixed(sys->lambda, sys->precision, sys->width), sys->reveal_inputs, sys->trace);

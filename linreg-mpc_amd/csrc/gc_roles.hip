@@ -1,0 +1,231 @@
+// gc_roles.hip -- garbler (CSP, party 1) and evaluator (party 2) as separate objects, for
+// deployments where the two run in different processes / on different hosts, as in the
+// reference (src/cmd/linreg.c:145-199).  The host moves bytes between them (tables, labels,
+// decode bits); nothing here touches a socket.
+//
+//   garbler   : lgc_party_input_pairs / lgc_party_encode_inputs -> labels for the OT / transfer
+//               for k in launches: lgc_party_garble(k) -> table bytes -> (network) ->
+//   evaluator : lgc_party_set_input_labels;  lgc_party_evaluate(k, table bytes)
+//   end       : garbler lgc_party_decode_bits -> evaluator lgc_party_finish -> beta (revealed to
+//               party 2 only, cgd.oc:206-208)
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/linreg_gc.h"
+#include "gc_device.h"
+#include "gc_program.h"
+
+using namespace gc;
+
+#define RCHK(x)                                                                              \
+    do {                                                                                     \
+        hipError_t e_ = (x);                                                                 \
+        if (e_ != hipSuccess) return lgc_fail(LGC_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct lgc_party {
+    lgc_system sys;
+    Program P;
+    int device, role;
+    Lbl R, seed;
+    Lbl *words, *tab;
+    uint64_t *dec;
+    Rec *recs;
+    bool labels_ready;
+    std::vector<uint64_t> hdec;
+};
+
+// (m0, m1) = (zero label, zero label ^ R) per input bit of one share: yaoKeyNewPair (input.c:94-101)
+__global__ void gc_export_pairs_kernel(const Lbl *words, uint32_t base, uint32_t n, Lbl R, int w, const uint64_t *vals,
+                                       Lbl *m0, Lbl *m1) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * (uint32_t)w) return;
+    uint32_t k = t / (uint32_t)w, lane = t % (uint32_t)w;
+    Lbl z = ld_lbl(words + (size_t)(base + k) * 64 + lane);
+    if (m1) {
+        st_lbl(m0 + t, z);
+        st_lbl(m1 + t, lxor(z, R));
+    } else {   // labels of known values (garbler's own inputs, feedObliv*)
+        uint32_t bit = (uint32_t)(vals[k] >> lane) & 1u;
+        st_lbl(m0 + t, lxor(z, lmask(R, bit)));
+    }
+}
+__global__ void gc_import_labels_kernel(Lbl *words, uint32_t base, uint32_t n, int w, const Lbl *labels) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 64u) return;
+    uint32_t k = t / 64u, lane = t % 64u;
+    Lbl v = lane < (uint32_t)w ? ld_lbl(labels + (size_t)k * w + lane) : lzero();
+    st_lbl(words + (size_t)(base + k) * 64 + lane, v);
+}
+
+extern "C" void lgc_party_destroy(lgc_party *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->words) (void)hipFree(p->words);
+    if (p->tab) (void)hipFree(p->tab);
+    if (p->dec) (void)hipFree(p->dec);
+    if (p->recs) (void)hipFree(p->recs);
+    delete p;
+}
+
+extern "C" int lgc_party_create(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
+                                size_t max_launch_table_bytes) {
+    int rc = check_system(sys);
+    if (rc) return rc;
+    if (!out) return lgc_fail(LGC_EINVAL, "null out");
+    if (role != LGC_ROLE_GARBLER && role != LGC_ROLE_EVALUATOR) return lgc_fail(LGC_EINVAL, "role must be 1 (garbler) or 2 (evaluator)");
+    if (role == LGC_ROLE_GARBLER && !seed) return lgc_fail(LGC_EINVAL, "the garbler needs a seed");
+    rc = lgc_need_device(device);
+    if (rc) return rc;
+    rc = lgc_upload_constants();
+    if (rc) return rc;
+    lgc_party *p = new lgc_party();
+    p->sys = *sys; p->device = device; p->role = role;
+    p->words = 0; p->tab = 0; p->dec = 0; p->recs = 0; p->labels_ready = false;
+    if (!max_launch_table_bytes) max_launch_table_bytes = (size_t)256 << 20;
+    build(p->P, sys, max_launch_table_bytes / 2048 ? max_launch_table_bytes / 2048 : 1);
+    memset(&p->R, 0, sizeof(Lbl)); memset(&p->seed, 0, sizeof(Lbl));
+    if (role == LGC_ROLE_GARBLER) {
+        memcpy(&p->seed, seed, 16);
+        p->R = host_hash(p->seed, 0x52ull << 56);
+        p->R.x |= 1u;
+    }
+    const Program &P = p->P;
+    size_t wbytes = (size_t)P.n_words * 64 * sizeof(Lbl);
+    hipError_t e;
+    if ((e = hipMalloc(&p->words, wbytes)) != hipSuccess || (e = hipMalloc(&p->tab, P.max_launch_steps * 2048 + 16)) != hipSuccess ||
+        (e = hipMalloc(&p->dec, (P.n_reveal + 1) * 8)) != hipSuccess || (e = hipMalloc(&p->recs, P.recs.size() * sizeof(Rec))) != hipSuccess) {
+        lgc_party_destroy(p);
+        return lgc_fail(LGC_ENOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    RCHK(hipMemcpy(p->recs, P.recs.data(), P.recs.size() * sizeof(Rec), hipMemcpyHostToDevice));
+    RCHK(hipMemset(p->words, 0, wbytes));
+    RCHK(hipMemset(p->dec, 0, (P.n_reveal + 1) * 8));
+    if (role == LGC_ROLE_GARBLER) {   // fresh zero-labels for every input word
+        size_t nin = P.nshares * (P.T + P.d);
+        hipLaunchKernelGGL(gc_input_kernel, dim3((unsigned)((nin + 3) / 4)), dim3(256), 0, 0, p->words, (Lbl *)0,
+                           (const uint64_t *)0, P.in_base, (uint32_t)nin, p->R, p->seed, P.w);
+        RCHK(hipDeviceSynchronize());
+        p->labels_ready = true;
+    }
+    p->hdec.resize(P.n_reveal + 1);
+    *out = p;
+    return LGC_OK;
+}
+
+extern "C" size_t lgc_party_num_launches(const lgc_party *p) { return p ? p->P.launches.size() : 0; }
+extern "C" size_t lgc_party_table_bytes(const lgc_party *p, size_t launch) {
+    return (p && launch < p->P.launches.size()) ? (size_t)p->P.launches[launch].steps * 2048 : 0;
+}
+extern "C" size_t lgc_party_input_bits(const lgc_party *p) { return p ? (p->P.T + p->P.d) * (size_t)p->P.w : 0; }
+extern "C" size_t lgc_party_num_reveal(const lgc_party *p) { return p ? p->P.n_reveal : 0; }
+extern "C" uint64_t lgc_party_and_gates(const lgc_party *p) { return p ? p->P.total_gates : 0; }
+
+static int export_labels(lgc_party *p, size_t share, const uint64_t *values, uint8_t *m0, uint8_t *m1) {
+    if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "only the garbler owns label pairs");
+    if (share >= p->P.nshares) return lgc_fail(LGC_EINVAL, "share index out of range");
+    RCHK(hipSetDevice(p->device));
+    const uint32_t n = (uint32_t)(p->P.T + p->P.d);
+    const size_t bits = (size_t)n * p->P.w;
+    Lbl *d0 = 0, *d1 = 0; uint64_t *dv = 0;
+    RCHK(hipMalloc(&d0, bits * 16));
+    if (m1) RCHK(hipMalloc(&d1, bits * 16));
+    if (values) { RCHK(hipMalloc(&dv, n * 8)); RCHK(hipMemcpy(dv, values, n * 8, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(gc_export_pairs_kernel, dim3((unsigned)((bits + 255) / 256)), dim3(256), 0, 0, p->words,
+                       p->P.in_base + (uint32_t)(share * n), n, p->R, p->P.w, dv, d0, d1);
+    RCHK(hipMemcpy(m0, d0, bits * 16, hipMemcpyDeviceToHost));
+    if (m1) RCHK(hipMemcpy(m1, d1, bits * 16, hipMemcpyDeviceToHost));
+    (void)hipFree(d0); if (d1) (void)hipFree(d1); if (dv) (void)hipFree(dv);
+    return LGC_OK;
+}
+extern "C" int lgc_party_input_pairs(lgc_party *p, size_t share, uint8_t *m0, uint8_t *m1) {
+    if (!p || !m0 || !m1) return lgc_fail(LGC_EINVAL, "null argument");
+    return export_labels(p, share, 0, m0, m1);
+}
+extern "C" int lgc_party_encode_inputs(lgc_party *p, size_t share, const uint64_t *values, uint8_t *labels_out) {
+    if (!p || !values || !labels_out) return lgc_fail(LGC_EINVAL, "null argument");
+    return export_labels(p, share, values, labels_out, 0);
+}
+extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint8_t *labels) {
+    if (!p || !labels) return lgc_fail(LGC_EINVAL, "null argument");
+    if (p->role != LGC_ROLE_EVALUATOR) return lgc_fail(LGC_ESTATE, "only the evaluator imports labels");
+    if (share >= p->P.nshares) return lgc_fail(LGC_EINVAL, "share index out of range");
+    RCHK(hipSetDevice(p->device));
+    const uint32_t n = (uint32_t)(p->P.T + p->P.d);
+    const size_t bits = (size_t)n * p->P.w;
+    Lbl *d = 0;
+    RCHK(hipMalloc(&d, bits * 16));
+    RCHK(hipMemcpy(d, labels, bits * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(gc_import_labels_kernel, dim3((unsigned)((n * 64u + 255) / 256)), dim3(256), 0, 0, p->words,
+                       p->P.in_base + (uint32_t)(share * n), n, p->P.w, d);
+    RCHK(hipDeviceSynchronize());
+    (void)hipFree(d);
+    p->labels_ready = true;
+    return LGC_OK;
+}
+
+template <bool G>
+static void party_launch(lgc_party *p, const Launch &L) {
+    if (L.mac_only) {
+        constexpr int TPB = G ? 768 : 1024;
+        const unsigned per = TPB / 64;
+        hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(TPB), 0, 0, p->recs + L.first_rec, L.nrec,
+                           p->words, p->tab, L.step0, p->R, p->P.w, p->P.p);
+    } else if (L.nrec >= 2048) {
+        hipLaunchKernelGGL((gc_exec_kernel<G, false>), dim3((L.nrec + 3) / 4), dim3(256), 0, 0, p->recs + L.first_rec, L.nrec,
+                           p->words, p->tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
+    } else {
+        hipLaunchKernelGGL((gc_exec_kernel<G, true>), dim3(L.nrec), dim3(256), 0, 0, p->recs + L.first_rec, L.nrec, p->words,
+                           p->tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
+    }
+}
+
+extern "C" int lgc_party_garble(lgc_party *p, size_t launch, uint8_t *tables_out) {
+    if (!p || (!tables_out && lgc_party_table_bytes(p, launch))) return lgc_fail(LGC_EINVAL, "null argument");
+    if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "not the garbler");
+    if (launch >= p->P.launches.size()) return lgc_fail(LGC_EINVAL, "launch out of range");
+    RCHK(hipSetDevice(p->device));
+    const Launch &L = p->P.launches[launch];
+    if (L.steps) RCHK(hipMemset(p->tab, 0, (size_t)L.steps * 2048));   // inactive lanes: defined bytes on the wire
+    party_launch<true>(p, L);
+    if (L.steps) RCHK(hipMemcpy(tables_out, p->tab, (size_t)L.steps * 2048, hipMemcpyDeviceToHost));
+    else RCHK(hipDeviceSynchronize());
+    return LGC_OK;
+}
+extern "C" int lgc_party_evaluate(lgc_party *p, size_t launch, const uint8_t *tables_in) {
+    if (!p || (!tables_in && lgc_party_table_bytes(p, launch))) return lgc_fail(LGC_EINVAL, "null argument");
+    if (p->role != LGC_ROLE_EVALUATOR) return lgc_fail(LGC_ESTATE, "not the evaluator");
+    if (!p->labels_ready) return lgc_fail(LGC_ESTATE, "input labels have not been set");
+    if (launch >= p->P.launches.size()) return lgc_fail(LGC_EINVAL, "launch out of range");
+    RCHK(hipSetDevice(p->device));
+    const Launch &L = p->P.launches[launch];
+    if (L.steps) RCHK(hipMemcpy(p->tab, tables_in, (size_t)L.steps * 2048, hipMemcpyHostToDevice));
+    party_launch<false>(p, L);
+    RCHK(hipDeviceSynchronize());
+    return LGC_OK;
+}
+extern "C" int lgc_party_decode_bits(lgc_party *p, uint64_t *dec_out) {
+    if (!p || !dec_out) return lgc_fail(LGC_EINVAL, "null argument");
+    RCHK(hipSetDevice(p->device));
+    RCHK(hipMemcpy(dec_out, p->dec, p->P.n_reveal * 8, hipMemcpyDeviceToHost));
+    return LGC_OK;
+}
+extern "C" int lgc_party_finish(lgc_party *p, const uint64_t *garbler_dec, int64_t *beta, int64_t *trace, int64_t *inputs) {
+    if (!p || !garbler_dec) return lgc_fail(LGC_EINVAL, "null argument");
+    if (p->role != LGC_ROLE_EVALUATOR) return lgc_fail(LGC_ESTATE, "results are revealed to the evaluator (party 2) only");
+    RCHK(hipSetDevice(p->device));
+    RCHK(hipMemcpy(p->hdec.data(), p->dec, p->P.n_reveal * 8, hipMemcpyDeviceToHost));
+    const Program &P = p->P;
+    auto val = [&](uint32_t slot) -> int64_t {
+        uint64_t v = p->hdec[slot] ^ garbler_dec[slot];
+        return P.w == 32 ? (int64_t)(int32_t)(uint32_t)v : (int64_t)v;
+    };
+    if (beta) for (size_t i = 0; i < P.d; i++) beta[i] = val(P.rv_beta + (uint32_t)i);
+    if (trace && P.rv_trace != ~0u)
+        for (size_t i = 0; i < (size_t)p->sys.num_iterations * (P.d + 4); i++) trace[i] = val(P.rv_trace + (uint32_t)i);
+    if (inputs && P.rv_ab != ~0u)
+        for (size_t i = 0; i < P.T + P.d; i++) inputs[i] = val(P.rv_ab + (uint32_t)i);
+    return LGC_OK;
+}

@@ -3,3 +3,4 @@
 #include "gc_engine.hip"
 #include "phase1.hip"
 #include "ot.hip"
+#include "gc_roles.hip"

@@ -82,6 +82,11 @@ def lib():
             ("lgc_p1_local", [vp, sz, sz, ci, vp, vp]), ("lgc_p1_mask", [vp, vp, sz, vp, ci, vp]),
             ("lgc_p1_dot", [vp, vp, vp, vp, sz, vp, vp]),
             ("lgc_ti_generate", [ci, C.c_char_p, C.c_uint64, sz, sz, ci, vp, vp, vp, vp]),
+            ("lgc_party_create", [C.POINTER(vp), ci, C.POINTER(System), ci, C.c_char_p, sz]),
+            ("lgc_party_input_pairs", [vp, sz, vp, vp]), ("lgc_party_encode_inputs", [vp, sz, vp, vp]),
+            ("lgc_party_set_input_labels", [vp, sz, vp]), ("lgc_party_garble", [vp, sz, vp]),
+            ("lgc_party_evaluate", [vp, sz, vp]), ("lgc_party_decode_bits", [vp, vp]),
+            ("lgc_party_finish", [vp, vp, vp, vp, vp]),
             ("lgc_ot_sender_create", [C.POINTER(vp), ci, C.c_char_p, vp]),
             ("lgc_ot_receiver_create", [C.POINTER(vp), ci, vp, vp]),
             ("lgc_ot_gilboa_recv_start", [vp, vp, sz, sz, ci, vp]),
@@ -96,6 +101,11 @@ def lib():
         L.lgc_solver_destroy.argtypes = [vp]; L.lgc_solver_destroy.restype = None
         L.lgc_program_destroy.argtypes = [vp]; L.lgc_program_destroy.restype = None
         L.lgc_p1_destroy.argtypes = [vp]; L.lgc_p1_destroy.restype = None
+        L.lgc_party_destroy.argtypes = [vp]; L.lgc_party_destroy.restype = None
+        for nme in ("lgc_party_num_launches", "lgc_party_input_bits", "lgc_party_num_reveal"):
+            getattr(L, nme).argtypes = [vp]; getattr(L, nme).restype = sz
+        L.lgc_party_table_bytes.argtypes = [vp, sz]; L.lgc_party_table_bytes.restype = sz
+        L.lgc_party_and_gates.argtypes = [vp]; L.lgc_party_and_gates.restype = C.c_uint64
         L.lgc_ot_sender_destroy.argtypes = [vp]; L.lgc_ot_sender_destroy.restype = None
         L.lgc_ot_receiver_destroy.argtypes = [vp]; L.lgc_ot_receiver_destroy.restype = None
         L.lgc_ot_u_bytes.argtypes = [C.c_uint64]; L.lgc_ot_u_bytes.restype = sz
@@ -266,6 +276,80 @@ def ti_generate(seed, first_pair, npairs, n, width=64, device=0):
     r = np.zeros(npairs, dtype=np.uint64); xyr = np.zeros(npairs, dtype=np.uint64)
     _chk(lib().lgc_ti_generate(device, seed, first_pair, npairs, n, width, _vp(x), _vp(y), _vp(r), _vp(xyr)))
     return x, y, r, xyr
+
+
+GARBLER, EVALUATOR = 1, 2
+
+
+class Party:
+    """CSP (garbler, role 1) or Evaluator (role 2) on its own: the host carries tables, labels
+    and decode bits between the two (reference src/cmd/linreg.c:145-199, src/input.c)."""
+
+    def __init__(self, system, role, seed=None, device=0, max_launch_table_bytes=0):
+        self._h = C.c_void_p()
+        self.system, self.role = system, role
+        _chk(lib().lgc_party_create(C.byref(self._h), device, C.byref(system), role, seed, max_launch_table_bytes))
+        self.num_launches = lib().lgc_party_num_launches(self._h)
+        self.input_bits = lib().lgc_party_input_bits(self._h)
+        self.num_reveal = lib().lgc_party_num_reveal(self._h)
+        self.and_gates = lib().lgc_party_and_gates(self._h)
+
+    def table_bytes(self, k):
+        return lib().lgc_party_table_bytes(self._h, k)
+
+    def input_pairs(self, share):
+        m0 = np.zeros((self.input_bits, 16), dtype=np.uint8); m1 = np.zeros((self.input_bits, 16), dtype=np.uint8)
+        _chk(lib().lgc_party_input_pairs(self._h, share, _vp(m0), _vp(m1)))
+        return m0, m1
+
+    def encode_inputs(self, share, values):
+        values = np.ascontiguousarray(values, dtype=np.uint64)
+        out = np.zeros((self.input_bits, 16), dtype=np.uint8)
+        _chk(lib().lgc_party_encode_inputs(self._h, share, _vp(values), _vp(out)))
+        return out
+
+    def set_input_labels(self, share, labels):
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+        assert labels.size == self.input_bits * 16
+        _chk(lib().lgc_party_set_input_labels(self._h, share, _vp(labels)))
+
+    def garble(self, k):
+        buf = np.zeros(max(1, self.table_bytes(k)), dtype=np.uint8)
+        _chk(lib().lgc_party_garble(self._h, k, _vp(buf)))
+        return buf[:self.table_bytes(k)]
+
+    def evaluate(self, k, tables):
+        tables = np.ascontiguousarray(tables, dtype=np.uint8)
+        _chk(lib().lgc_party_evaluate(self._h, k, _vp(tables) if tables.size else None))
+
+    def decode_bits(self):
+        out = np.zeros(max(1, self.num_reveal), dtype=np.uint64)
+        _chk(lib().lgc_party_decode_bits(self._h, _vp(out)))
+        return out
+
+    def finish(self, garbler_dec):
+        d = self.system.d
+        beta = np.zeros(d, dtype=np.int64)
+        trace = np.zeros((max(1, self.system.num_iterations), d + 4), dtype=np.int64)
+        inputs = np.zeros(d * (d + 1) // 2 + d, dtype=np.int64)
+        _chk(lib().lgc_party_finish(self._h, _vp(np.ascontiguousarray(garbler_dec, dtype=np.uint64)), _vp(beta), _vp(trace), _vp(inputs)))
+        return beta, trace, inputs
+
+    def close(self):
+        if self._h:
+            lib().lgc_party_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def share_choice_bits(values, width):
+    """sel[i*intsize+j] = (input[i] >> j) & 1  (reference src/input.c:41)"""
+    values = np.ascontiguousarray(values, dtype=np.uint64)
+    return ((values[:, None] >> np.arange(width, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.uint8).ravel()
 
 
 class OtSender:

@@ -1,0 +1,94 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the per-lambda sharding (the per-circuit solve is
+replaced by the oracle here; on GPUs it is the HIP solver, see test_gpu_sweep_single_rank)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import orc, sweep
+    from helpers import oracle_solve, split_shares, synth_system
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle = orc.load()
+    rng = np.random.default_rng(0)
+    w, p, d, n = 64, 56, 4, 30
+    A, b = synth_system(oracle, rng, n, d, w, p)
+    shares = split_shares(rng, A, b, 2, w)
+    lams = sweep.c5_lambdas(7)                       # ragged: 7 circuits over 2 ranks -> 4 + 3
+    calls = []
+
+    def solve(sh, lam, index):
+        calls.append(index)
+        tot = sh.sum(axis=0, dtype=np.uint64)
+        return oracle_solve(oracle, tot[:d * (d + 1) // 2], tot[d * (d + 1) // 2:], d, w, p, "cgd", 3, lam, 1)[0]
+    res = sweep.lambda_sweep(shares, lams, d, solve, dist=dist)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, calls, res.tolist()))
+
+
+def test_partition_is_contiguous_and_complete():
+    sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python"))
+    import sweep
+    for n in (0, 1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            blocks = [sweep.partition(n, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in blocks) - min(h - l for l, h in blocks) <= 1
+    assert sweep.partition(64, 8, 3) == (24, 32)
+    lams = sweep.c5_lambdas()
+    assert len(lams) == 64 and abs(lams[0] - 1e-6) < 1e-18 and abs(lams[-1] - 1.0) < 1e-12
+
+
+def test_lambda_sweep_two_ranks_gloo(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    outs = sorted(q.get(timeout=120) for _ in range(2))
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    assert outs[0][1] == [0, 1, 2, 3] and outs[1][1] == [4, 5, 6]      # each rank solved only its block
+    assert outs[0][2] == outs[1][2]                                    # every rank holds all results
+    # and they are what a single process computes
+    sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python"))
+    import sweep
+    from helpers import oracle_solve, split_shares, synth_system
+    rng = np.random.default_rng(0)
+    w, p, d, n = 64, 56, 4, 30
+    A, b = synth_system(oracle, rng, n, d, w, p)
+    exp = [oracle_solve(oracle, A, b, d, w, p, "cgd", 3, lam, 1)[0].tolist() for lam in sweep.c5_lambdas(7)]
+    assert outs[0][2] == exp
+    assert len(set(map(tuple, exp))) > 1                               # lambda actually matters
+
+
+@pytest.mark.gpu
+def test_gpu_sweep_single_rank(lgc, oracle):
+    import sweep
+    from helpers import oracle_solve, split_shares, synth_system
+    rng = np.random.default_rng(1)
+    w, p, d, n = 64, 56, 5, 40
+    A, b = synth_system(oracle, rng, n, d, w, p)
+    shares = split_shares(rng, A, b, 2, w)
+    lams = sweep.c5_lambdas(4)
+    solve = sweep.gpu_solve_factory(d, w, p, "cgd", 4, 2, 0)
+    res = sweep.lambda_sweep(shares, lams, d, solve)
+    exp = [oracle_solve(oracle, A, b, d, w, p, "cgd", 4, lam, 1)[0].tolist() for lam in lams]
+    assert res.tolist() == exp
