@@ -1,0 +1,136 @@
+#include "net.h"
+
+#include <arpa/inet.h>
+#include <errno.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <time.h>
+#include <unistd.h>
+
+double wall_clock(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_REALTIME, &t);
+    return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+
+static int io_all(int fd, void *buf, size_t len, int wr) {
+    char *p = buf;
+    while (len) {
+        ssize_t k = wr ? send(fd, p, len, MSG_NOSIGNAL) : recv(fd, p, len, 0);
+        if (k < 0 && errno == EINTR) continue;
+        if (k <= 0) return -1;
+        p += k; len -= (size_t)k;
+    }
+    return 0;
+}
+
+int net_send(node *n, int to, const void *buf, size_t len) {
+    if (to < 1 || to > n->num_parties || n->fd[to - 1] < 0) return -1;
+    n->sent[to - 1] += len;
+    return io_all(n->fd[to - 1], (void *)buf, len, 1);
+}
+int net_recv(node *n, int from, void *buf, size_t len) {
+    if (from < 1 || from > n->num_parties || n->fd[from - 1] < 0) return -1;
+    return io_all(n->fd[from - 1], buf, len, 0);
+}
+
+static int split_endpoint(const char *ep, char *host, size_t hl, char *port, size_t pl) {
+    const char *c = strrchr(ep, ':');
+    if (!c || (size_t)(c - ep) >= hl || strlen(c + 1) >= pl) return -1;
+    memcpy(host, ep, (size_t)(c - ep)); host[c - ep] = 0;
+    strcpy(port, c + 1);
+    return 0;
+}
+
+static int connect_retry(const char *host, const char *port) {
+    for (;;) {   /* retry every 200 ms like util_loop_connect (src/util.c:26-38) */
+        struct addrinfo hints, *res = 0;
+        memset(&hints, 0, sizeof hints);
+        hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
+        if (getaddrinfo(host, port, &hints, &res) == 0) {
+            int s = socket(res->ai_family, res->ai_socktype, res->ai_protocol);
+            if (s >= 0 && connect(s, res->ai_addr, res->ai_addrlen) == 0) {
+                int one = 1;
+                setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+                freeaddrinfo(res);
+                return s;
+            }
+            if (s >= 0) close(s);
+            freeaddrinfo(res);
+        }
+        struct timespec ts = {0, 200000000};
+        nanosleep(&ts, 0);
+    }
+}
+
+int node_new(node **out, int party, int num_parties, char **endpoints) {
+    node *n = calloc(1, sizeof *n);
+    if (!n) return 1;
+    n->party = party; n->num_parties = num_parties;
+    n->fd = malloc(sizeof(int) * (size_t)num_parties);
+    n->sent = calloc((size_t)num_parties, sizeof(uint64_t));
+    for (int i = 0; i < num_parties; i++) n->fd[i] = -1;
+    char host[256], port[32];
+    for (int q = 1; q < party; q++) {                       /* lower-numbered peers listen */
+        if (split_endpoint(endpoints[q - 1], host, sizeof host, port, sizeof port)) goto fail;
+        int s = connect_retry(host, port);
+        n->fd[q - 1] = s;
+        int32_t me = party;
+        if (io_all(s, &me, sizeof me, 1)) goto fail;      /* announce ourselves (node.c:37) */
+    }
+    if (party < num_parties) {
+        if (split_endpoint(endpoints[party - 1], host, sizeof host, port, sizeof port)) goto fail;
+        int ls = socket(AF_INET, SOCK_STREAM, 0), one = 1;
+        setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+        struct sockaddr_in sa;
+        memset(&sa, 0, sizeof sa);
+        sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)atoi(port)); sa.sin_addr.s_addr = INADDR_ANY;
+        if (bind(ls, (struct sockaddr *)&sa, sizeof sa) < 0 || listen(ls, SOMAXCONN) < 0) {
+            fprintf(stderr, "Could not create listen socket on port %s: %s\n", port, strerror(errno));
+            close(ls);
+            goto fail;
+        }
+        for (int k = party; k < num_parties; k++) {
+            int s = accept(ls, 0, 0);
+            if (s < 0) { close(ls); goto fail; }
+            setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+            int32_t other = 0;
+            if (io_all(s, &other, sizeof other, 0) || other <= party || other > num_parties || n->fd[other - 1] >= 0) {
+                fprintf(stderr, "Party %d received invalid party number %d from remote\n", party, other);
+                close(s); close(ls);
+                goto fail;
+            }
+            n->fd[other - 1] = s;
+        }
+        close(ls);
+    }
+    *out = n;
+    return 0;
+fail:
+    node_destroy(&n);
+    return 1;
+}
+
+void node_destroy(node **nn) {
+    if (!nn || !*nn) return;
+    node *n = *nn;
+    if (n->fd) for (int i = 0; i < n->num_parties; i++) if (n->fd[i] >= 0) close(n->fd[i]);
+    free(n->fd); free(n->sent); free(n);
+    *nn = 0;
+}
+
+int net_barrier(node *n) {
+    int32_t flag = 42;
+    if (n->party != 1 && net_recv(n, n->party - 1, &flag, sizeof flag)) return -1;
+    if (n->party != n->num_parties) {
+        if (net_send(n, n->party + 1, &flag, sizeof flag)) return -1;
+        if (net_recv(n, n->party + 1, &flag, sizeof flag)) return -1;
+    }
+    if (n->party != 1 && net_send(n, n->party - 1, &flag, sizeof flag)) return -1;
+    return 0;
+}

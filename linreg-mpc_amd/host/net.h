@@ -1,0 +1,22 @@
+/* net.h -- TCP mesh between parties, by party number (counterpart of the reference's
+ * src/node.c:11-70 and the osend/orecv calls of Obliv-C's ProtocolDesc).  Blocking sockets;
+ * every party connects to all lower-numbered parties and accepts all higher-numbered ones. */
+#ifndef LINREG_NET_H
+#define LINREG_NET_H
+#include <stddef.h>
+#include <stdint.h>
+
+typedef struct {
+    int party;          /* 1-based */
+    int num_parties;
+    int *fd;            /* fd[q-1] = socket to party q, -1 for self */
+    uint64_t *sent;     /* bytes sent per peer (PROFILE_NETWORK-style accounting) */
+} node;
+
+int node_new(node **out, int party, int num_parties, char **endpoints);
+void node_destroy(node **n);
+int net_send(node *n, int to_party, const void *buf, size_t len);
+int net_recv(node *n, int from_party, void *buf, size_t len);
+int net_barrier(node *n);    /* chain barrier of src/cmd/linreg.c:19-41 */
+double wall_clock(void);
+#endif

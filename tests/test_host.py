@@ -1,0 +1,120 @@
+"""Host side (C): wire format and config parser on CPU; the five-process `bin/linreg` run of the
+README example (BASELINE.json config 1) on the GPU box."""
+import ctypes as C
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "linreg-mpc_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    so = os.path.join(HOST, "libhosttest.so")
+    subprocess.check_call(["make", "-C", HOST, "libhosttest.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    L.pmsg_packed_size.restype = C.c_size_t
+    L.pmsg_packed_size.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+    L.pmsg_pack.restype = C.c_size_t
+    L.pmsg_pack.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
+    L.pmsg_unpack.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+    return L
+
+
+def _pack(L, vec, value):
+    v = np.ascontiguousarray(vec, dtype=np.uint64)
+    n = L.pmsg_packed_size(v.ctypes.data, len(v), value)
+    out = np.zeros(n, dtype=np.uint8)
+    assert L.pmsg_pack(v.ctypes.data, len(v), value, out.ctypes.data) == n
+    return bytes(out)
+
+
+def test_pmsg_wire_format(hostlib):
+    # proto2: repeated uint64 vector = 1 [packed]; required uint64 value = 2 (src/protobuf/*.proto)
+    assert _pack(hostlib, [1, 300], 5) == bytes.fromhex("0a0301ac021005")
+    assert _pack(hostlib, [], 0) == bytes.fromhex("1000")
+    big = _pack(hostlib, [2 ** 64 - 1], 2 ** 63)
+    assert big == bytes.fromhex("0a0a" + "ff" * 9 + "01" + "10" + "80" * 9 + "01")
+    rng = np.random.default_rng(0)
+    vec = rng.integers(0, 2 ** 63, size=1000, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    blob = _pack(hostlib, vec, 12345678901234567890)
+    pv = C.POINTER(C.c_uint64)(); n = C.c_size_t(); val = C.c_uint64()
+    buf = np.frombuffer(blob, dtype=np.uint8).copy()
+    assert hostlib.pmsg_unpack(buf.ctypes.data, len(buf), C.byref(pv), C.byref(n), C.byref(val)) == 0
+    assert n.value == 1000 and val.value == 12345678901234567890
+    assert np.array_equal(np.ctypeslib.as_array(pv, (1000,)), vec)
+    # a message without the required `value` is rejected (recv_pmsg's check, phase1.c:112)
+    bad = np.frombuffer(bytes.fromhex("0a0101"), dtype=np.uint8).copy()
+    assert hostlib.pmsg_unpack(bad.ctypes.data, len(bad), C.byref(pv), C.byref(n), C.byref(val)) != 0
+
+
+def _free_ports(k):
+    socks = [socket.socket() for _ in range(k)]
+    for s in socks:
+        s.bind(("127.0.0.1", 0))
+    ports = [s.getsockname()[1] for s in socks]
+    for s in socks:
+        s.close()
+    return ports
+
+
+def _rewrite_ports(src, dst):
+    tok = open(src).read().split("\n")
+    n, d, P = map(int, tok[0].split())
+    ports = _free_ports(P + 2)
+    for i in range(P + 2):
+        parts = tok[1 + i].split()
+        parts[0] = "127.0.0.1:%d" % ports[i]
+        tok[1 + i] = " ".join(parts)
+    open(dst, "w").write("\n".join(tok))
+    return P
+
+
+def _run_all(infile, P, args, timeout=300):
+    exe = os.path.join(HOST, "bin", "linreg")
+    procs = []
+    for party in range(1, P + 3):
+        cmd = [exe, infile, args[0], str(party)] + args[1:]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-2000:]
+    return [o.decode() for o, _ in outs]
+
+
+README_RESULT = ["0.984331027786964", "0.792399824970372", "0.754117840176144", "0.592849130685193", "0.057351715952213"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--use_ot"]], ids=["ti", "ot"])
+def test_five_process_readme_example(tmp_path, golden_dir, extra):
+    """bin/linreg examples/readme_example.in 56 $party cgd 10 0.001 (README.md:81) -> README.md:87"""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    infile = str(tmp_path / "readme.in")
+    P = _rewrite_ports(os.path.join(golden_dir, "readme_example.in"), infile)
+    outs = _run_all(infile, P, ["56", "cgd", "10", "0.001"] + extra)
+    ev = outs[1]
+    last = ev.strip().splitlines()[-1]
+    assert last.startswith("Result:")
+    assert re.findall("-?[0-9]+\\.[0-9]+", last) == README_RESULT
+    assert '{"n":"10", "d":"5" "p":"4"}' in ev and "Algorithm: cgd" in ev and "Number of gates:" in ev
+    assert ev.count("Iteration") >= 30 and "Time elapsed:" in ev
+    for k, o in enumerate(outs):
+        assert "Party %d finished phase 1" % (k + 1) in o
+
+
+@pytest.mark.gpu
+def test_five_process_cholesky_matches_oracle(tmp_path, golden_dir, oracle):
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    infile = str(tmp_path / "readme.in")
+    P = _rewrite_ports(os.path.join(golden_dir, "readme_example.in"), infile)
+    outs = _run_all(infile, P, ["56", "cholesky", "0", "0.001"])
+    got = re.findall("-?[0-9]+\\.[0-9]+", outs[1].strip().splitlines()[-1])
+    beta = oracle.linreg_file(os.path.join(golden_dir, "readme_example.in"), 56, -1, 64, 64, 0, 0, 0.001)
+    assert got == ["%.15f" % (int(b) / 2.0 ** 56) for b in beta]
