@@ -1,0 +1,51 @@
+"""Parity at BASELINE.json's full sizes: the oracle is plain integer arithmetic and finishes
+d = 500 in seconds, so these are exact comparisons, not just invariants."""
+import numpy as np
+import pytest
+
+from helpers import oracle_solve, split_shares, synth_system
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(lgc, oracle, n, d, w, p, alg, iters, nshares, normalize, lam, seed):
+    rng = np.random.default_rng(seed)
+    A, b = synth_system(oracle, rng, n, d, w, p)
+    shares = split_shares(rng, A, b, nshares, w)
+    sysm = lgc.make_system(d, w, p, alg, iters, lam, nshares, normalize, 0, 1 if alg == "cgd" else 0)
+    s = lgc.Solver(sysm, seed=bytes(range(16)))
+    s.set_shares(shares)
+    s.run()
+    exp, _, _ = oracle_solve(oracle, A, b, d, w, p, alg, iters, lam, normalize, trace=(alg == "cgd"))
+    if alg == "cgd":
+        assert s.trace().tolist() == exp[1].tolist()
+        exp = exp[0]
+    assert s.beta().tolist() == exp.tolist()
+    st = s.stats()
+    s.close()
+    return st
+
+
+def test_config2_cholesky_d20(lgc, oracle):
+    """BASELINE config 2: n=1000 d=20 cholesky 64-bit, two parties co-located"""
+    _run(lgc, oracle, 1000, 20, 64, 56, "cholesky", 0, 2, 0, 0.0, 2)
+
+
+def test_config3_cgd15_d100(lgc, oracle):
+    """BASELINE config 3 (phase 2): d=100 cgd 15 iterations 64-bit, data-provider input path"""
+    _run(lgc, oracle, 2000, 100, 64, 56, "cgd", 15, 2, 1, 1e-3, 3)
+
+
+def test_headline_cgd15_d500_bit_exact(lgc, oracle):
+    """the bench workload itself: d=500 CGD-15, 64-bit, every per-iteration reveal compared"""
+    st = _run(lgc, oracle, 1500, 500, 64, 56, "cgd", 15, 2, 0, 0.0, 4)
+    assert st["and_gates"] > 3e10
+
+
+def test_config4_cgd20_d500_32bit(lgc, oracle):
+    """BASELINE config 4 (phase 2): d=500 cgd 20 iterations in 32-bit / precision 30, 5 providers"""
+    _run(lgc, oracle, 1500, 500, 32, 30, "cgd", 20, 5, 1, 1e-3, 5)
+
+
+def test_ldlt_d60(lgc, oracle):
+    _run(lgc, oracle, 800, 60, 64, 56, "ldlt", 0, 2, 1, 1e-3, 6)
