@@ -121,7 +121,7 @@ GC_HD uint32_t last_hi(uint32_t v3, uint32_t v2) {   // byte2 <- S[i2], byte3 <-
 // N independent blocks, interleaved round by round (ILP hides LDS latency).
 // T: table accessor, T::lk(word, k) returns Te0[byte k of word].
 template <int N, class T>
-GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4]) {
+GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4], const uint32_t *rk24 = 0) {
 #pragma unroll
     for (int b = 0; b < N; b++) {
         s[b][0] ^= rk[0]; s[b][1] ^= rk[1]; s[b][2] ^= rk[2]; s[b][3] ^= rk[3];
@@ -135,16 +135,23 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4]) {
             for (int j = 0; j < 4; j++) {
                 v[b][4 * j + 0] = tab.lk(s[b][j], 0);
                 v[b][4 * j + 1] = tab.lk(s[b][(j + 1) & 3], 1);
-                v[b][4 * j + 2] = tab.lk(s[b][(j + 2) & 3], 2);
-                v[b][4 * j + 3] = tab.lk(s[b][(j + 3) & 3], 3);
+                v[b][4 * j + 2] = T::kTwoTables ? tab.lk2(s[b][(j + 2) & 3], 2) : tab.lk(s[b][(j + 2) & 3], 2);
+                v[b][4 * j + 3] = T::kTwoTables ? tab.lk2(s[b][(j + 3) & 3], 3) : tab.lk(s[b][(j + 3) & 3], 3);
             }
         }
 #pragma unroll
         for (int b = 0; b < N; b++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint32_t t = xor3(v[b][4 * j], rotl32(v[b][4 * j + 2], 16), rk[4 * rnd + j]);
-                s[b][j] = xor3(t, rotl32(v[b][4 * j + 1], 8), rotl32(v[b][4 * j + 3], 24));
+                if (T::kTwoTables) {
+                    // v2, v3 come from Te2 = rotl16(Te0): col = Te0[i0]^Te2[i2] ^ rotl8(Te0[i1]^Te2[i3]) ^ rk,
+                    // with the round key folded in before the rotation (rk24 = rotl24(rk))
+                    uint32_t x = xor3(v[b][4 * j + 1], v[b][4 * j + 3], rk24[4 * rnd + j]);
+                    s[b][j] = xor3(v[b][4 * j], v[b][4 * j + 2], rotl32(x, 8));
+                } else {
+                    uint32_t t = xor3(v[b][4 * j], rotl32(v[b][4 * j + 2], 16), rk[4 * rnd + j]);
+                    s[b][j] = xor3(t, rotl32(v[b][4 * j + 1], 8), rotl32(v[b][4 * j + 3], 24));
+                }
             }
         }
     }
@@ -179,14 +186,14 @@ GC_HD void hash_prep(Lbl x, uint64_t tweak, uint32_t k[4]) {
 
 // N hashes at once: out[b] = AES(K_b) ^ K_b
 template <int N, class T>
-GC_HD void hash_n(const T &tab, const uint32_t *rk, const Lbl *x, const uint64_t *tw, Lbl *out) {
+GC_HD void hash_n(const T &tab, const uint32_t *rk, const Lbl *x, const uint64_t *tw, Lbl *out, const uint32_t *rk24 = 0) {
     uint32_t s[N][4], k[N][4];
 #pragma unroll
     for (int b = 0; b < N; b++) {
         hash_prep(x[b], tw[b], k[b]);
         s[b][0] = k[b][0]; s[b][1] = k[b][1]; s[b][2] = k[b][2]; s[b][3] = k[b][3];
     }
-    aes_encrypt_n<N, T>(tab, rk, s);
+    aes_encrypt_n<N, T>(tab, rk, s, rk24);
 #pragma unroll
     for (int b = 0; b < N; b++) {
         out[b].x = s[b][0] ^ k[b][0]; out[b].y = s[b][1] ^ k[b][1];
@@ -196,18 +203,29 @@ GC_HD void hash_n(const T &tab, const uint32_t *rk, const Lbl *x, const uint64_t
 
 // host table accessor (plain array)
 struct HostTab {
+    static const bool kTwoTables = false;
     const uint32_t *te0;
     inline uint32_t lk(uint32_t word, int k) const { return te0[(word >> (8 * k)) & 0xffu]; }
+    inline uint32_t lk2(uint32_t word, int k) const { return rotl32(lk(word, k), 16); }
 };
 
 // ---- half-gates, one AND gate (lane-local).  gid: unique gate id.
 // Garbler: a0, b0 zero-labels; returns c0 and the two ciphertexts.
 template <class T>
-GC_HD Lbl garble_and(const T &tab, const uint32_t *rk, Lbl R, Lbl a0, Lbl b0, uint64_t gid, Lbl &TG, Lbl &TE) {
+GC_HD Lbl garble_and(const T &tab, const uint32_t *rk, Lbl R, Lbl a0, Lbl b0, uint64_t gid, Lbl &TG, Lbl &TE,
+                     const uint32_t *rk24 = 0) {
     Lbl in[4] = {a0, lxor(a0, R), b0, lxor(b0, R)};
     uint64_t tw[4] = {2 * gid, 2 * gid, 2 * gid + 1, 2 * gid + 1};
     Lbl h[4];
-    hash_n<4, T>(tab, rk, in, tw, h);
+#ifndef GC_GARBLE_SPLIT22
+#define GC_GARBLE_SPLIT22 1   /* two pairs of interleaved blocks: fewer live registers, 4 waves/SIMD */
+#endif
+#if GC_GARBLE_SPLIT22
+    hash_n<2, T>(tab, rk, in, tw, h, rk24);
+    hash_n<2, T>(tab, rk, in + 2, tw + 2, h + 2, rk24);
+#else
+    hash_n<4, T>(tab, rk, in, tw, h, rk24);
+#endif
     uint32_t pa = a0.x & 1u, pb = b0.x & 1u;
     TG = lxor(lxor(h[0], h[1]), lmask(R, pb));
     Lbl WG = lxor(h[0], lmask(TG, pa));
@@ -217,11 +235,11 @@ GC_HD Lbl garble_and(const T &tab, const uint32_t *rk, Lbl R, Lbl a0, Lbl b0, ui
 }
 // Evaluator: a, b active labels.
 template <class T>
-GC_HD Lbl eval_and(const T &tab, const uint32_t *rk, Lbl a, Lbl b, uint64_t gid, Lbl TG, Lbl TE) {
+GC_HD Lbl eval_and(const T &tab, const uint32_t *rk, Lbl a, Lbl b, uint64_t gid, Lbl TG, Lbl TE, const uint32_t *rk24 = 0) {
     Lbl in[2] = {a, b};
     uint64_t tw[2] = {2 * gid, 2 * gid + 1};
     Lbl h[2];
-    hash_n<2, T>(tab, rk, in, tw, h);
+    hash_n<2, T>(tab, rk, in, tw, h, rk24);
     uint32_t sa = a.x & 1u, sb = b.x & 1u;
     Lbl WG = lxor(h[0], lmask(TG, sa));
     Lbl WE = lxor(h[1], lmask(lxor(TE, a), sb));

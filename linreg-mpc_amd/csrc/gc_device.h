@@ -19,10 +19,12 @@ namespace gc {
 
 __constant__ uint32_t c_rk[44];
 __constant__ uint32_t c_te0[256];
+__constant__ uint32_t c_rk24[44];   // rotl24 of the round keys (two-table AES rounds)
 
 static constexpr int kLdsTabWords = 256 * 64;   // 64 KiB: entry x occupies the 256-byte row x
 
 struct LdsTab {
+    static const bool kTwoTables = false;
     const char *base;    // LDS byte address of the table
     uint32_t lane4;      // (lane << 2): fits one byte, merged into the address by v_perm_b32
     // Te0[byte k of word]: address = (byte << 8) | (lane << 2)
@@ -30,7 +32,39 @@ struct LdsTab {
         uint32_t off = __builtin_amdgcn_perm(word, lane4, 0x0c0c0400u + ((uint32_t)k << 8));
         return *reinterpret_cast<const uint32_t *>(base + off);
     }
+    __device__ __forceinline__ uint32_t lk2(uint32_t word, int k) const { return rotl32(lk(word, k), 16); }
 };
+
+// MAC kernels: Te0 and Te2 = rotl16(Te0) side by side (128 KiB): one rotate per column instead of three
+struct LdsTab2 {
+    static const bool kTwoTables = true;
+    const char *base;
+    uint32_t lane4;
+    __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const {
+        uint32_t off = __builtin_amdgcn_perm(word, lane4, 0x0c0c0400u + ((uint32_t)k << 8));
+        return *reinterpret_cast<const uint32_t *>(base + off);
+    }
+    // second table at +64 KiB: bit 16 of the address comes from byte 2 of lane4 (= 0x01), so the
+    // address is still ONE v_perm_b32 (a +65536 immediate does not fit the 16-bit DS offset field)
+    __device__ __forceinline__ uint32_t lk2(uint32_t word, int k) const {
+        uint32_t off = __builtin_amdgcn_perm(word, lane4, 0x0c020400u + ((uint32_t)k << 8));
+        return *reinterpret_cast<const uint32_t *>(base + off);
+    }
+};
+__device__ __forceinline__ void lds_tab2_fill(uint32_t *lds) {
+    for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) {
+        uint32_t v = c_te0[i >> 6];
+        lds[i] = v;
+        lds[kLdsTabWords + i] = (v << 16) | (v >> 16);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ LdsTab2 lds_tab2_make(const uint32_t *lds) {
+    LdsTab2 t;
+    t.base = reinterpret_cast<const char *>(lds);
+    t.lane4 = ((threadIdx.x & 63u) << 2) | 0x10000u;
+    return t;
+}
 
 __device__ __forceinline__ void lds_tab_fill(uint32_t *lds) {
     for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) lds[i] = c_te0[i >> 6];
@@ -62,7 +96,7 @@ __device__ __forceinline__ void st_lbl(Lbl *p, Lbl v) {
 //            launches (dividers, adders, max trees).
 enum { MODE_MAC = 0, MODE_SOLO = 1, MODE_QUAD = 2 };
 
-template <bool GARBLER, int MODE>
+template <bool GARBLER, int MODE, class TAB = LdsTab>
 struct GpuBackend {
     typedef Lbl W;
     int wave;            // MODE_QUAD: wave index inside the workgroup (wave-uniform)
@@ -75,7 +109,7 @@ struct GpuBackend {
     uint64_t step;       // global gate-step counter (wave-uniform)
     uint64_t launch_step0;
     int lane;
-    LdsTab lt;
+    TAB lt;
 
     __device__ __forceinline__ W zero() const { return lzero(); }
     __device__ __forceinline__ uint32_t bit(uint64_t m) const { return (uint32_t)(m >> lane) & 1u; }
@@ -133,28 +167,28 @@ struct GpuBackend {
         xsel ^= 1;
         and2_quad(lt, R, a1, b1, a2, b2, gid, slot, on1, on2, wave, xch + xsel * 512, lane, c1, c2);
     }
-    static __device__ __forceinline__ W and_impl(LdsTab lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on) {
+    static __device__ __forceinline__ W and_impl(TAB lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on) {
         W c = lzero();
         if (on) {
             if (GARBLER) {
                 Lbl TG, TE;
-                c = garble_and(lt, c_rk, R, a, b, gid, TG, TE);
+                c = garble_and(lt, c_rk, R, a, b, gid, TG, TE, c_rk24);
                 st_lbl(slot, TG);
                 st_lbl(slot + 64, TE);
             } else {
                 Lbl TG = ld_lbl(slot), TE = ld_lbl(slot + 64);
-                c = eval_and(lt, c_rk, a, b, gid, TG, TE);
+                c = eval_and(lt, c_rk, a, b, gid, TG, TE, c_rk24);
             }
         }
         return c;
     }
-    static __device__ __noinline__ W and_outlined(LdsTab lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on) {
+    static __device__ __noinline__ W and_outlined(TAB lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on) {
         return and_impl(lt, R, a, b, gid, slot, on);
     }
     // cooperative gate step (one out-of-line copy: code size, compile time).  Every wave of
     // the workgroup calls this with identical operands; exactly one barrier per step, the
     // exchange area is double-buffered by step parity.
-    static __device__ __noinline__ W and_quad(LdsTab lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on,
+    static __device__ __noinline__ W and_quad(TAB lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on,
                                               int wave, Lbl *xbuf, int lane) {
         const int nh = GARBLER ? 4 : 2;
         Lbl TGe = lzero(), TEe = lzero();
@@ -165,7 +199,7 @@ struct GpuBackend {
                 Lbl x = (wave < (nh >> 1)) ? a : b;
                 if (GARBLER && (wave & 1)) x = lxor(x, R);
                 uint64_t tw = 2 * gid + (uint64_t)(wave >= (nh >> 1));
-                hash_n<1, LdsTab>(lt, c_rk, &x, &tw, &h);
+                hash_n<1, TAB>(lt, c_rk, &x, &tw, &h);
             }
             xbuf[wave * 64 + lane] = h;
         }
@@ -195,7 +229,7 @@ struct GpuBackend {
         return c;
     }
     // two gate steps (gid, gid + 64) at once: 8 (garbler) / 4 (evaluator) hashes over 4 waves
-    static __device__ __noinline__ void and2_quad(LdsTab lt, Lbl R, W a1, W b1, W a2, W b2, uint64_t gid, Lbl *slot,
+    static __device__ __noinline__ void and2_quad(TAB lt, Lbl R, W a1, W b1, W a2, W b2, uint64_t gid, Lbl *slot,
                                                   bool on1, bool on2, int wave, Lbl *xbuf, int lane, W &c1, W &c2) {
         const uint64_t gid2 = gid + 64;
         Lbl *slot2 = slot + 128;
@@ -210,7 +244,7 @@ struct GpuBackend {
             if (wave & 1) { x[0] = lxor(x[0], R); x[1] = lxor(x[1], R); }
             uint64_t tw[2] = {2 * gid + (uint64_t)(wave >= 2), 2 * gid2 + (uint64_t)(wave >= 2)};
             Lbl h[2] = {lzero(), lzero()};
-            if (on1 || on2) hash_n<2, LdsTab>(lt, c_rk, x, tw, h);
+            if (on1 || on2) hash_n<2, TAB>(lt, c_rk, x, tw, h);
             xbuf[wave * 64 + lane] = h[0];
             xbuf[256 + wave * 64 + lane] = h[1];
         } else {
@@ -218,7 +252,7 @@ struct GpuBackend {
             Lbl x = (wave & 1) ? ((wave < 2) ? b1 : b2) : ((wave < 2) ? a1 : a2);
             uint64_t tw = 2 * ((wave < 2) ? gid : gid2) + (uint64_t)(wave & 1);
             Lbl h = lzero();
-            if ((wave < 2) ? on1 : on2) hash_n<1, LdsTab>(lt, c_rk, &x, &tw, &h);
+            if ((wave < 2) ? on1 : on2) hash_n<1, TAB>(lt, c_rk, &x, &tw, &h);
             xbuf[(wave >> 1) * 256 + (wave & 1) * 64 + lane] = h;
         }
         __syncthreads();
@@ -272,12 +306,12 @@ struct GpuBackend {
 template <bool GARBLER, int TPB>
 __global__ void __launch_bounds__(TPB)
 gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
-    __shared__ uint32_t lds_te0[kLdsTabWords];
-    lds_tab_fill(lds_te0);
+    __shared__ uint32_t lds_te0[2 * kLdsTabWords];   // Te0 | Te2: 128 KiB, one workgroup per CU
+    lds_tab2_fill(lds_te0);
     const int lane = threadIdx.x & 63;
     const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wid >= nrec) return;
-    typedef GpuBackend<GARBLER, MODE_MAC> B;
+    typedef GpuBackend<GARBLER, MODE_MAC, LdsTab2> B;
     B be;
     be.R = R;
     be.words = words;
@@ -288,7 +322,7 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
     be.lane = lane;
     be.wave = 0;
     be.xch = 0;
-    be.lt = lds_tab_make(lds_te0);
+    be.lt = lds_tab2_make(lds_te0);
     Rec r = recs[wid];
     r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);
     r.dst = __builtin_amdgcn_readfirstlane(r.dst);

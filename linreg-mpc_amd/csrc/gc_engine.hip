@@ -58,6 +58,9 @@ int lgc_upload_constants() {
     const AesTables &t = tables();
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rk), t.rk, sizeof(t.rk)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_te0), t.te0, sizeof(t.te0)));
+    uint32_t rk24[44];
+    for (int i = 0; i < 44; i++) rk24[i] = (t.rk[i] << 24) | (t.rk[i] >> 8);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rk24), rk24, sizeof(rk24)));
     return LGC_OK;
 }
 
@@ -300,9 +303,16 @@ extern "C" int lgc_solver_set_shares(lgc_solver *s, const uint64_t *shares) {
     return LGC_OK;
 }
 
-// workgroup sizes: the 64 KiB table allows one workgroup per CU for the big MAC launches
-// (12 / 16 waves = 3 / 4 per SIMD, matching the kernels' VGPR use)
-static constexpr int kTpbMacG = 768, kTpbMacE = 1024;
+// workgroup sizes of the MAC kernels (one workgroup per CU: 128 KiB of tables).  Measured on
+// d=500 (scripts/exp/mac_ab.sh): garbler 1024 threads (4 waves/SIMD, 128 VGPRs) and evaluator
+// 768 threads are the fastest; 256-thread workgroups are 25 % slower
+#ifndef GC_TPB_MACG
+#define GC_TPB_MACG 1024
+#endif
+#ifndef GC_TPB_MACE
+#define GC_TPB_MACE 768
+#endif
+static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
 // generic launches with at least this many records run one wave per record (throughput);
 // narrower ones run one 4-wave workgroup per record (latency)
 static constexpr uint32_t kWideLaunch = 2048;

@@ -169,7 +169,7 @@ extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint
 template <bool G>
 static void party_launch(lgc_party *p, const Launch &L) {
     if (L.mac_only) {
-        constexpr int TPB = G ? 768 : 1024;
+        constexpr int TPB = G ? kTpbMacG : kTpbMacE;
         const unsigned per = TPB / 64;
         hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(TPB), 0, 0, p->recs + L.first_rec, L.nrec,
                            p->words, p->tab, L.step0, p->R, p->P.w, p->P.p);

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "liblinreg_gc.so")
+LIB_PATH = os.environ.get("LGC_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "liblinreg_gc.so")
 
 ALG = {"cholesky": 0, "ldlt": 1, "cgd": 2}
 
