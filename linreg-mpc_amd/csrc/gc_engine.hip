@@ -487,6 +487,28 @@ extern "C" int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[1
     return rc;
 }
 
+// diagnostic: keep `blocks` workgroups busy with VALU work for about `ms` milliseconds on a
+// separate stream (used to study how the clock the chip holds depends on load)
+__global__ void gc_spin_kernel(uint32_t *out, unsigned long long ticks_100mhz) {
+    unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t a = threadIdx.x, b = blockIdx.x * 2654435761u;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz) {
+#pragma unroll 64
+        for (int i = 0; i < 256; i++) { a = a * 1664525u + b; b ^= a >> 7; }
+    }
+    if (a == 0x12345678u) out[0] = b;
+}
+static hipStream_t g_spin_stream = 0;
+extern "C" int lgc_debug_spin(int device, int blocks, double ms) {
+    int rc = lgc_need_device(device);
+    if (rc) return rc;
+    static uint32_t *dummy = 0;
+    if (!dummy) HIPCHK(hipMalloc(&dummy, 64));
+    if (!g_spin_stream) HIPCHK(hipStreamCreateWithFlags(&g_spin_stream, hipStreamNonBlocking));
+    hipLaunchKernelGGL(gc_spin_kernel, dim3(blocks), dim3(256), 0, g_spin_stream, dummy, (unsigned long long)(ms * 1e5));
+    return LGC_OK;
+}
+
 // --------------------------------------------------------- micro-benchmarks
 extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double *rate, uint32_t *check) {
     int rc = lgc_need_device(device);
