@@ -1,0 +1,97 @@
+"""Edge cases of the domain on the GPU path vs the oracle: smallest dimensions, a single share,
+extreme precisions, convergence to a zero residual (division by zero, unspecified in the reference
+and defined identically in oracle and circuit), extreme operand values."""
+import numpy as np
+import pytest
+
+from helpers import oracle_solve, split_shares, synth_system
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(lgc, oracle, A, b, d, w, p, alg, iters, nshares, normalize, lam, rng):
+    shares = split_shares(rng, A, b, nshares, w) if nshares > 1 else np.concatenate([A, b])[None, :].astype(np.uint64)
+    sysm = lgc.make_system(d, w, p, alg, iters, lam, nshares, normalize, 1, 1 if alg == "cgd" else 0)
+    s = lgc.Solver(sysm, seed=bytes(range(7, 23)))
+    s.set_shares(shares)
+    s.run()
+    exp, a, bb = oracle_solve(oracle, A, b, d, w, p, alg, iters, lam, normalize, trace=(alg == "cgd"))
+    assert s.inputs().tolist() == np.concatenate([a, bb]).tolist()
+    if alg == "cgd":
+        assert s.trace().tolist() == exp[1].tolist()
+        exp = exp[0]
+    assert s.beta().tolist() == exp.tolist()
+    s.close()
+
+
+@pytest.mark.parametrize("alg", ["cgd", "cholesky", "ldlt"])
+def test_dimension_one_and_single_share(lgc, oracle, alg):
+    rng = np.random.default_rng(0)
+    A, b = synth_system(oracle, rng, 12, 1, 64, 56)
+    _check(lgc, oracle, A, b, 1, 64, 56, alg, 3, 1, 1, 0.01, rng)
+    A, b = synth_system(oracle, rng, 12, 2, 32, 30)
+    _check(lgc, oracle, A, b, 2, 32, 30, alg, 3, 1, 0, 0.0, rng)
+
+
+def test_cgd_past_convergence_divides_by_zero(lgc, oracle):
+    """d=2 converges in two steps; after that the residual is exactly zero and every division has
+    a zero divisor.  Oracle and circuit share one definition of that case."""
+    rng = np.random.default_rng(1)
+    for w, p in ((64, 56), (32, 30)):
+        A, b = synth_system(oracle, rng, 30, 2, w, p)
+        _check(lgc, oracle, A, b, 2, w, p, "cgd", 12, 2, 0, 0.0, rng)
+    # an all-zero system: division by zero from the first step
+    z = np.zeros(3, dtype=np.uint64), np.zeros(2, dtype=np.uint64)
+    _check(lgc, oracle, z[0], z[1], 2, 64, 56, "cgd", 3, 2, 0, 0.0, rng)
+
+
+@pytest.mark.parametrize("w,p", [(64, 1), (64, 60), (64, 63), (32, 1), (32, 31), (32, 29)])
+def test_extreme_precisions_cgd(lgc, oracle, w, p):
+    rng = np.random.default_rng(w + p)
+    d = 3
+    T = d * (d + 1) // 2
+    m = (1 << w) - 1
+    # arbitrary words (not a meaningful regression problem): pure arithmetic parity, wrap-around included
+    A = rng.integers(0, 2 ** 63, size=T, dtype=np.uint64) & np.uint64(m)
+    b = rng.integers(0, 2 ** 63, size=d, dtype=np.uint64) & np.uint64(m)
+    _check(lgc, oracle, A, b, d, w, p, "cgd", 3, 2, 0, 0.0, rng)
+
+
+@pytest.mark.parametrize("w,p", [(64, 60), (64, 2), (32, 31), (32, 30), (32, 3)])
+def test_extreme_precisions_cholesky_ldlt(lgc, oracle, w, p):
+    """square root with odd and even datapath widths (the 32-bit loop of fixed.oc:228-240 at odd
+    32+p, the 64-bit shifting form at its widest supported width), garbage operands included"""
+    rng = np.random.default_rng(100 + w + p)
+    d = 3
+    T = d * (d + 1) // 2
+    m = (1 << w) - 1
+    A = rng.integers(0, 2 ** 63, size=T, dtype=np.uint64) & np.uint64(m)
+    b = rng.integers(0, 2 ** 63, size=d, dtype=np.uint64) & np.uint64(m)
+    for alg in ("cholesky", "ldlt"):
+        _check(lgc, oracle, A, b, d, w, p, alg, 0, 2, 1, 0.5, rng)
+
+
+def test_extreme_operand_values(lgc, oracle):
+    rng = np.random.default_rng(9)
+    for w, p in ((64, 56), (32, 30)):
+        lo = 1 << (w - 1)
+        specials = [0, 1, (1 << w) - 1, lo, lo - 1, lo + 1, 1 << (w - 2)]
+        d = 3
+        for rep in range(3):
+            A = np.array([specials[(rep + k) % len(specials)] for k in range(6)], dtype=np.uint64)
+            b = np.array([specials[(2 * rep + k + 3) % len(specials)] for k in range(3)], dtype=np.uint64)
+            _check(lgc, oracle, A, b, d, w, p, "cgd", 2, 2, 0, 0.0, rng)
+
+
+def test_rejects_unsupported_parameters(lgc):
+    with pytest.raises(lgc.LgcError):
+        lgc.Solver(lgc.make_system(3, width=64, precision=61, algorithm="cholesky"))
+    with pytest.raises(lgc.LgcError):
+        lgc.Solver(lgc.make_system(3, width=64, precision=64))
+    with pytest.raises(lgc.LgcError):
+        lgc.Solver(lgc.make_system(0))
+    s = lgc.Solver(lgc.make_system(2, algorithm="cgd", num_iterations=1))
+    with pytest.raises(lgc.LgcError):
+        s.run()                      # shares not set
+    with pytest.raises(lgc.LgcError):
+        s.beta()                     # not run
