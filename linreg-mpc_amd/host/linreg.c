@@ -17,226 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../../include/linreg_gc.h"
 #include "baseot.h"
-#include "config.h"
-#include "net.h"
-#include "pmsg.h"
-
-#define check(cond, ...)                              \
-    do {                                              \
-        if (!(cond)) {                                \
-            fprintf(stderr, __VA_ARGS__);             \
-            fprintf(stderr, "\n");                    \
-            goto error;                               \
-        }                                             \
-    } while (0)
-#define LGC(x) check((x) == 0, "%s: %s", #x, lgc_last_error())
-
-static size_t idx(size_t i, size_t j) { if (j > i) { size_t t = i; i = j; j = t; } return (i * (i + 1)) / 2 + j; }
-
-/* (fixed_t)(d * (1ll << p)) with the phase-2 type (src/fixed.c:3-5, src/linear.c:51) */
-static int64_t double_to_fixed(double d, int p, int w) {
-    double t = d * (double)(1ll << p);
-    if (w == 32) return (int64_t)(int32_t)t;
-    return (int64_t)t;
-}
-static double fixed_to_double(int64_t f, int p) { return ((double)f) / (double)(1ll << p); }
-
-/* read_matrix / read_vector (src/linear.c:27-102), values divided by the normalizer */
-static int read_values(FILE *f, size_t count, int precision, double normalizer, int w2, int64_t *out) {
-    for (size_t i = 0; i < count; i++) {
-        double val;
-        if (fscanf(f, "%lf", &val) != 1) return 1;
-        val /= normalizer;
-        out[i] = double_to_fixed(val, precision, w2);
-    }
-    return 0;
-}
-
-/* length-prefixed protobuf message (src/phase1.c:100-145) */
-static int send_pmsg(node *self, int to, const uint64_t *vec, size_t n, uint64_t value) {
-    size_t sz = pmsg_packed_size(vec, n, value);
-    uint8_t *buf = malloc(sz + sizeof(size_t));
-    memcpy(buf, &sz, sizeof sz);
-    pmsg_pack(vec, n, value, buf + sizeof sz);
-    int rc = net_send(self, to, buf, sz + sizeof sz);
-    free(buf);
-    return rc;
-}
-static int recv_pmsg(node *self, int from, uint64_t **vec, size_t *n, uint64_t *value) {
-    size_t sz = 0;
-    if (net_recv(self, from, &sz, sizeof sz)) return 1;
-    uint8_t *buf = malloc(sz ? sz : 1);
-    if (net_recv(self, from, buf, sz)) { free(buf); return 1; }
-    int rc = pmsg_unpack(buf, sz, vec, n, value);
-    free(buf);
-    return rc;
-}
-static int send_blob(node *self, int to, const void *buf, uint64_t len) {
-    if (net_send(self, to, &len, sizeof len)) return 1;
-    return len ? net_send(self, to, buf, len) : 0;
-}
-static int recv_blob(node *self, int from, void *buf, uint64_t len) {
-    uint64_t got = 0;
-    if (net_recv(self, from, &got, sizeof got) || got != len) return 1;
-    return len ? net_recv(self, from, buf, len) : 0;
-}
-
-/* ---------------------------------------------------------------- phase 1: trusted initializer */
-static int run_trusted_initializer(node *self, config *c, int w1, int device) {
-    uint8_t seed[16];
-    RAND_bytes(seed, sizeof seed);                       /* newBCipherRandomGen (src/phase1.c:243) */
-    const size_t n = c->n;
-    uint64_t *x = malloc(n * 8), *y = malloc(n * 8), r, xyr;
-    uint64_t pair = 0;
-    int rc = 1;
-    for (size_t i = 0; i <= c->d; i++)
-        for (size_t j = 0; j <= i && j < c->d; j++) {
-            int pa = config_owner(c, i), pb = config_owner(c, j);
-            if (pa == pb) continue;
-            LGC(lgc_ti_generate(device, seed, pair++, 1, n, w1, x, y, &r, &xyr));
-            check(!send_pmsg(self, pa + 1, y, n, xyr), "Could not send message to party A (%d)", pa);   /* (y, <x,y> - r) */
-            check(!send_pmsg(self, pb + 1, x, n, r), "Could not send message to party B (%d)", pb);     /* (x, r) */
-        }
-    rc = 0;
-error:
-    free(x); free(y);
-    return rc;
-}
-
-/* ---------------------------------------------------------------- phase 1: data provider */
-static void column_of(const int64_t *Xq, const int64_t *yq, size_t n, size_t d, size_t row, uint64_t *out) {
-    for (size_t k = 0; k < n; k++) out[k] = (uint64_t)(row < d ? Xq[k * d + row] : yq[k]);
-}
-
-static int run_party(node *self, config *c, int precision, int precision_p2, int w1, int w2, int use_ot, int device,
-                     uint64_t **res_A, uint64_t **res_b) {
-    const size_t n = c->n, d = c->d, T = d * (d + 1) / 2;
-    const int me = c->party - 1, last = c->num_parties - 1;
-    int64_t *Xq = malloc(n * d * 8), *yq = malloc(n * 8);
-    uint64_t *share_A = calloc(T, 8), *share_b = calloc(d, 8), *va = 0, *vb = 0, *tmp = 0, *tmp2 = 0;
-    lgc_p1 *p1 = 0;
-    int rc = 1;
-    double normalizer = sqrt(pow(2, precision) * (double)n);      /* src/phase1.c:473 */
-    size_t n2, d2;
-    check(fscanf(c->input, "%zu %zu", &n2, &d2) == 2 && n2 == n && d2 == d, "Input dimensions invalid");
-    check(!read_values(c->input, n * d, precision, normalizer, w2, Xq), "Could not read data");
-    check(fscanf(c->input, "%zu", &n2) == 1 && n2 == n, "Input dimensions invalid");
-    check(!read_values(c->input, n, precision, normalizer, w2, yq), "Could not read target");
-    LGC(lgc_p1_create(&p1, device, n, d, w1, precision));
-    LGC(lgc_p1_set_data(p1, Xq, yq));
-    const size_t c0 = (size_t)c->index_owned[me], c1 = me < last ? (size_t)c->index_owned[me + 1] : d;
-    /* everything this party can do alone: its own block, incl. the floating-point diagonal */
-    {
-        size_t own = c1 - c0;
-        uint64_t *blk = malloc((own * (own + 1) / 2 + 1) * 8), *bb = malloc((own + 1) * 8);
-        LGC(lgc_p1_local(p1, c0, c1, me == last, blk, bb));
-        for (size_t i = 0; i < own; i++) {
-            for (size_t j = 0; j <= i; j++) share_A[idx(c0 + i, c0 + j)] = blk[i * (i + 1) / 2 + j];
-            if (me == last) share_b[c0 + i] = bb[i];
-        }
-        free(blk); free(bb);
-    }
-    va = malloc(n * 8); vb = malloc(n * 8); tmp = malloc(n * 8); tmp2 = malloc(n * 8);
-    if (!use_ot) {
-        /* TI mode, loop order of src/phase1.c:534-586 */
-        for (size_t i = 0; i <= d; i++)
-            for (size_t j = 0; j <= i && j < d; j++) {
-                int oi = config_owner(c, i), oj = config_owner(c, j);
-                if (oi == oj || (oi != me && oj != me)) continue;
-                uint64_t *tv = 0, tval = 0, share = 0, sub;
-                size_t tn = 0;
-                check(!recv_pmsg(self, 1, &tv, &tn, &tval) && tn == n, "Could not receive message from TI");
-                uint32_t col;
-                if (oi == me) {                                  /* party a (phase1.c:171-197) */
-                    uint64_t *in = 0, inval; size_t in_n = 0;
-                    check(!recv_pmsg(self, oj + 1, &in, &in_n, &inval) && in_n == n, "Could not receive message from party B (%d)", oj);
-                    col = (uint32_t)i;
-                    LGC(lgc_p1_mask(p1, &col, 1, tv, -1, tmp));               /* a - y */
-                    check(!send_pmsg(self, oj + 1, tmp, n, 0), "Could not send message to party B (%d)", oj);
-                    sub = tval;
-                    LGC(lgc_p1_dot(p1, in, tv, 0, 1, &sub, &share));          /* <b+x, y> - (xy - r) */
-                    free(in);
-                } else {                                         /* party b (phase1.c:198-223) */
-                    uint64_t *in = 0, inval; size_t in_n = 0;
-                    col = (uint32_t)j;
-                    LGC(lgc_p1_mask(p1, &col, 1, tv, +1, tmp));               /* b + x */
-                    check(!send_pmsg(self, oi + 1, tmp, n, 0), "Could not send message to party A (%d)", oi);
-                    check(!recv_pmsg(self, oi + 1, &in, &in_n, &inval) && in_n == n, "Could not receive message from party A (%d)", oi);
-                    sub = tval;
-                    LGC(lgc_p1_dot(p1, in, 0, &col, 1, &sub, &share));        /* <a-y, b> - r */
-                    free(in);
-                }
-                free(tv);
-                if (i < d) share_A[idx(i, j)] = share; else share_b[j] = share;
-            }
-    } else {
-        /* OT mode (src/phase1.c:353-450): one Gilboa batch per peer, peers in a global order */
-        for (int lo = 2; lo < c->num_parties; lo++)
-            for (int hi = lo + 1; hi < c->num_parties; hi++) {
-                if (me != lo && me != hi) continue;
-                int peer = me == lo ? hi : lo;
-                int i_am_sender = ((me % 2 == peer % 2) == (me < peer));          /* phase1.c:392 */
-                int pi = i_am_sender ? me : peer, pj = i_am_sender ? peer : me;
-                size_t i0 = (size_t)c->index_owned[pi], i1 = pi < last ? (size_t)c->index_owned[pi + 1] : d;
-                size_t j0 = (size_t)c->index_owned[pj], j1 = pj < last ? (size_t)c->index_owned[pj + 1] : d;
-                size_t npairs = (i1 - i0) * (j1 - j0) + (pj == last ? (i1 - i0) : 0) + (pi == last ? (j1 - j0) : 0);
-                /* rows of the sender / receiver per pair, and where the share goes */
-                size_t *ri = malloc(npairs * sizeof(size_t)), *rj = malloc(npairs * sizeof(size_t)), q = 0;
-                for (size_t i = i0; i < i1; i++) {
-                    for (size_t j = j0; j < j1; j++) { ri[q] = i; rj[q++] = j; }
-                    if (pj == last) { ri[q] = i; rj[q++] = d; }
-                }
-                if (pi == last) for (size_t j = j0; j < j1; j++) { ri[q] = d; rj[q++] = j; }
-                uint64_t *vals = malloc(npairs * n * 8), *shares = malloc(npairs * 8);
-                const uint64_t m = (uint64_t)npairs * n * (uint64_t)w1;
-                size_t ub = lgc_ot_u_bytes(m);
-                uint8_t *u = malloc(ub);
-                uint64_t *yv = malloc(m * 8);
-                if (i_am_sender) {
-                    uint8_t delta[16], seeds[128][16];
-                    check(!baseot_ext_sender(self, peer + 1, delta, seeds), "base OT failed");
-                    lgc_ot_sender *S = 0;
-                    LGC(lgc_ot_sender_create(&S, device, delta, seeds));
-                    for (q = 0; q < npairs; q++) column_of(Xq, yq, n, d, ri[q], vals + q * n);
-                    check(!recv_blob(self, peer + 1, u, ub), "OT: could not receive u");
-                    LGC(lgc_ot_gilboa_send(S, vals, npairs, n, w1, u, yv, shares));
-                    check(!send_blob(self, peer + 1, yv, m * 8), "OT: could not send y");
-                    lgc_ot_sender_destroy(S);
-                } else {
-                    uint8_t s0[128][16], s1[128][16];
-                    check(!baseot_ext_receiver(self, peer + 1, s0, s1), "base OT failed");
-                    lgc_ot_receiver *R = 0;
-                    LGC(lgc_ot_receiver_create(&R, device, s0, s1));
-                    for (q = 0; q < npairs; q++) column_of(Xq, yq, n, d, rj[q], vals + q * n);
-                    LGC(lgc_ot_gilboa_recv_start(R, vals, npairs, n, w1, u));
-                    check(!send_blob(self, peer + 1, u, ub), "OT: could not send u");
-                    check(!recv_blob(self, peer + 1, yv, m * 8), "OT: could not receive y");
-                    LGC(lgc_ot_gilboa_recv_finish(R, yv, shares));
-                    lgc_ot_receiver_destroy(R);
-                }
-                for (q = 0; q < npairs; q++) {
-                    if (ri[q] < d && rj[q] < d) share_A[idx(ri[q], rj[q])] += shares[q];
-                    else share_b[ri[q] < d ? ri[q] : rj[q]] += shares[q];
-                }
-                free(ri); free(rj); free(vals); free(shares); free(u); free(yv);
-            }
-        if (w1 == 32) { for (size_t k = 0; k < T; k++) share_A[k] &= 0xffffffffull; for (size_t k = 0; k < d; k++) share_b[k] &= 0xffffffffull; }
-    }
-    /* different widths in the two phases: every share is shifted on its own (src/phase1.c:609-638) */
-    if (w1 == 64 && w2 == 32) {
-        for (size_t k = 0; k < T; k++) share_A[k] = (uint64_t)(uint32_t)(uint64_t)(((int64_t)share_A[k]) >> (precision - precision_p2));
-        for (size_t k = 0; k < d; k++) share_b[k] = (uint64_t)(uint32_t)(uint64_t)(((int64_t)share_b[k]) >> (precision - precision_p2));
-    }
-    *res_A = share_A; *res_b = share_b;
-    share_A = share_b = 0;
-    rc = 0;
-error:
-    if (p1) lgc_p1_destroy(p1);
-    free(Xq); free(yq); free(share_A); free(share_b); free(va); free(vb); free(tmp); free(tmp2);
-    return rc;
-}
+#include "protocol.h"
 
 /* ------------------------------------------------------------------------------ main */
 int main(int argc, char **argv) {

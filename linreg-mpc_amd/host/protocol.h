@@ -1,0 +1,31 @@
+/* protocol.h -- shared host-side protocol drivers (see protocol.c) */
+#ifndef LINREG_PROTOCOL_H
+#define LINREG_PROTOCOL_H
+#include <stdint.h>
+#include <stdio.h>
+#include "config.h"
+#include "net.h"
+#include "../../include/linreg_gc.h"
+
+#define check(cond, ...)                              \
+    do {                                              \
+        if (!(cond)) {                                \
+            fprintf(stderr, __VA_ARGS__);             \
+            fprintf(stderr, "\n");                    \
+            goto error;                               \
+        }                                             \
+    } while (0)
+#define LGC(x) check((x) == 0, "%s: %s", #x, lgc_last_error())
+
+size_t idx(size_t i, size_t j);
+int64_t double_to_fixed(double d, int p, int w);
+double fixed_to_double(int64_t f, int p);
+int read_values(FILE *f, size_t count, int precision, double normalizer, int w2, int64_t *out);
+int send_pmsg(node *self, int to, const uint64_t *vec, size_t n, uint64_t value);
+int recv_pmsg(node *self, int from, uint64_t **vec, size_t *n, uint64_t *value);
+int send_blob(node *self, int to, const void *buf, uint64_t len);
+int recv_blob(node *self, int from, void *buf, uint64_t len);
+int run_trusted_initializer(node *self, config *c, int w1, int device);
+int run_party(node *self, config *c, int precision, int precision_p2, int w1, int w2, int use_ot, int device,
+              uint64_t **res_A, uint64_t **res_b);
+#endif

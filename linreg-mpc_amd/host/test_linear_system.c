@@ -1,0 +1,170 @@
+/* test_linear_system.c -- two-party phase-2 benchmark with the reference's command line
+ * (src/cmd/test/test_linear_system.c:81-137):
+ *     test_linear_system [Port] [Party] [Input file] [Algorithm] [Num. iterations CGD] [Precision]
+ * Both parties read the same clear system (A, b); the "shares" are fabricated with the constant
+ * masks 123456 / 0xDEADBEEF (:34-44); party 1 (server, garbler) holds the masks, party 2
+ * (evaluator) the masked values; the circuit adds them (src/linear.oc:96-135).  Party 2 prints the
+ * lines experiments/test_phase2_aws.py parses.  Options: --width=<32|64>, --host=<server>. */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <openssl/rand.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "baseot.h"
+#include "protocol.h"
+
+int main(int argc, char **argv) {
+    node *self = NULL;
+    lgc_party *po = NULL;
+    FILE *f = NULL;
+    check(argc >= 7, "Usage: %s [Port] [Party] [Input file] [Algorithm] [Num. iterations CGD] [Precision]", argv[0]);
+    char *algorithm = argv[4], *end;
+    check(!strcmp(algorithm, "cholesky") || !strcmp(algorithm, "ldlt") || !strcmp(algorithm, "cgd"),
+          "Algorithm must be cholesky, ldlt, or cgd.");
+    errno = 0;
+    int precision = (int)strtol(argv[6], &end, 10);
+    check(!errno && !*end, "Precision must be a number");
+    int party = !strcmp(argv[2], "1") ? 1 : (!strcmp(argv[2], "2") ? 2 : 0);
+    check(party > 0, "Party must be either 1 or 2.");
+    int w = 64;
+    const char *host = "localhost";
+    for (int i = 7; i < argc; i++) {
+        if (sscanf(argv[i], "--width=%i", &w) == 1) continue;
+        if (!strncmp(argv[i], "--host=", 7)) host = argv[i] + 7;
+    }
+    int num_iterations = !strcmp(algorithm, "cgd") ? atoi(argv[5]) : 0;
+    int device = getenv("LINREG_DEVICE") ? atoi(getenv("LINREG_DEVICE")) : 0;
+
+    /* read_ls_from_file (:11-79): A as d x d, b as d, no normalisation */
+    f = fopen(argv[3], "r");
+    check(f, "Could not open file: %s.", strerror(errno));
+    size_t d, d2, dl;
+    check(fscanf(f, "%zu %zu", &d, &d2) == 2 && d == d2, "Could not read A.");
+    int64_t *Af = malloc(d * d * 8), *bf = malloc(d * 8);
+    check(!read_values(f, d * d, precision, 1.0, w, Af), "Could not read A.");
+    check(fscanf(f, "%zu", &dl) == 1 && dl == d, "Could not read b.");
+    check(!read_values(f, d, precision, 1.0, w, bf), "Could not read b.");
+    fclose(f); f = NULL;
+    const size_t T = d * (d + 1) / 2;
+    const uint64_t mw = w == 32 ? 0xffffffffull : ~0ull;
+    uint64_t *mine = malloc((T + d) * 8);
+    for (size_t i = 0; i < d; i++) {
+        for (size_t j = 0; j <= i; j++) {
+            uint64_t mask = 123456;
+            mine[idx(i, j)] = (party == 1 ? mask : (uint64_t)Af[i * d + j] - mask) & mw;
+        }
+        uint64_t bm = 0xDEADBEEFull;
+        mine[T + i] = (party == 1 ? bm : (uint64_t)bf[i] - bm) & mw;
+    }
+
+    char ep1[300], ep2[300], *eps[2] = {ep1, ep2};
+    snprintf(ep1, sizeof ep1, "%s:%s", host, argv[1]);
+    snprintf(ep2, sizeof ep2, "%s:0", host);
+    check(!node_new(&self, party, 2, eps), "Could not connect");
+    double time = wall_clock();
+    if (party == 2) printf("\nAlgorithm: %s\n", algorithm);
+
+    lgc_system sys;
+    memset(&sys, 0, sizeof sys);
+    sys.d = d; sys.width = w; sys.precision = precision;
+    sys.algorithm = !strcmp(algorithm, "cholesky") ? LGC_ALG_CHOLESKY : (!strcmp(algorithm, "ldlt") ? LGC_ALG_LDLT : LGC_ALG_CGD);
+    sys.num_iterations = num_iterations; sys.nshares = 2; sys.normalize = 0; sys.trace = 1;
+    const size_t chunk = (size_t)64 << 20;
+    if (party == 1) {
+        uint8_t seed[16];
+        RAND_bytes(seed, sizeof seed);
+        LGC(lgc_party_create(&po, device, &sys, LGC_ROLE_GARBLER, seed, chunk));
+        size_t bits = lgc_party_input_bits(po);
+        uint8_t *lab = malloc(bits * 16), *m0 = malloc(bits * 16), *m1 = malloc(bits * 16), *u = malloc(lgc_ot_u_bytes(bits)), *e = malloc(bits * 32);
+        LGC(lgc_party_encode_inputs(po, 0, mine, lab));                         /* feedOblivLLong(.., 1) */
+        check(!send_blob(self, 2, lab, bits * 16), "could not send labels");
+        uint8_t delta[16], seeds[128][16];
+        check(!baseot_ext_sender(self, 2, delta, seeds), "base OT failed");
+        lgc_ot_sender *S = 0;
+        LGC(lgc_ot_sender_create(&S, device, delta, seeds));
+        LGC(lgc_party_input_pairs(po, 1, m0, m1));                              /* feedOblivLLong(.., 2): OT */
+        check(!recv_blob(self, 2, u, lgc_ot_u_bytes(bits)), "OT: could not receive u");
+        LGC(lgc_ot_labels_send(S, m0, m1, bits, u, e));
+        check(!send_blob(self, 2, e, bits * 32), "OT: could not send");
+        lgc_ot_sender_destroy(S);
+        free(lab); free(m0); free(m1); free(u); free(e);
+        uint8_t *tab = malloc(chunk + 4096);
+        for (size_t i = 0; i < lgc_party_num_launches(po); i++) {
+            LGC(lgc_party_garble(po, i, tab));
+            check(!send_blob(self, 2, tab, lgc_party_table_bytes(po, i)), "could not send garbled tables");
+        }
+        free(tab);
+        size_t nr = lgc_party_num_reveal(po);
+        uint64_t *dec = malloc((nr + 1) * 8);
+        LGC(lgc_party_decode_bits(po, dec));
+        check(!send_blob(self, 2, dec, nr * 8), "could not send decode bits");
+        free(dec);
+    } else {
+        double t0 = wall_clock();
+        LGC(lgc_party_create(&po, device, &sys, LGC_ROLE_EVALUATOR, NULL, chunk));
+        size_t bits = lgc_party_input_bits(po);
+        uint8_t *lab = malloc(bits * 16), *sel = malloc(bits), *u = malloc(lgc_ot_u_bytes(bits)), *e = malloc(bits * 32);
+        check(!recv_blob(self, 1, lab, bits * 16), "could not receive labels");
+        LGC(lgc_party_set_input_labels(po, 0, lab));
+        uint8_t s0[128][16], s1[128][16];
+        check(!baseot_ext_receiver(self, 1, s0, s1), "base OT failed");
+        lgc_ot_receiver *R = 0;
+        LGC(lgc_ot_receiver_create(&R, device, s0, s1));
+        for (size_t i = 0; i < T + d; i++)
+            for (int j = 0; j < w; j++) sel[i * (size_t)w + (size_t)j] = (uint8_t)((mine[i] >> j) & 1);
+        LGC(lgc_ot_labels_recv_start(R, sel, bits, u));
+        check(!send_blob(self, 1, u, lgc_ot_u_bytes(bits)), "OT: could not send u");
+        check(!recv_blob(self, 1, e, bits * 32), "OT: could not receive");
+        LGC(lgc_ot_labels_recv_finish(R, e, lab));
+        LGC(lgc_party_set_input_labels(po, 1, lab));
+        lgc_ot_receiver_destroy(R);
+        free(lab); free(sel); free(u); free(e);
+        double t_ot = wall_clock() - t0;
+        uint8_t *tab = malloc(chunk + 4096);
+        for (size_t i = 0; i < lgc_party_num_launches(po); i++) {
+            check(!recv_blob(self, 1, tab, lgc_party_table_bytes(po, i)), "could not receive garbled tables");
+            LGC(lgc_party_evaluate(po, i, tab));
+        }
+        free(tab);
+        size_t nr = lgc_party_num_reveal(po);
+        uint64_t *dec = malloc((nr + 1) * 8);
+        check(!recv_blob(self, 1, dec, nr * 8), "could not receive decode bits");
+        int64_t *beta = malloc(d * 8), *trace = malloc(((size_t)num_iterations * (d + 4) + 1) * 8);
+        LGC(lgc_party_finish(po, dec, beta, trace, NULL));
+        free(dec);
+        long long gates = (long long)lgc_party_and_gates(po);
+        if (sys.algorithm == LGC_ALG_CGD) {
+            printf("OT time: %f\nStarting iterations.\n", t_ot);
+            for (int t = 0; t < num_iterations; t++) {
+                const int64_t *row = trace + (size_t)t * (d + 4);
+                printf("Iteration %d (x):\n", t);
+                for (size_t i = 0; i < d; i++) printf("%20.15f ", fixed_to_double(row[i], precision));
+                printf("\nGamma: %30.20f ", fixed_to_double(row[d], precision));
+                printf("\nEta: %30.20f ", fixed_to_double(row[d + 1], precision));
+                printf("\nq: %30.20f ", fixed_to_double(row[d + 2], precision));
+                printf("\nng: %30.20f ", fixed_to_double(row[d + 3], precision));
+                printf("\nIteration %d gate count: %lld", t, gates * (t + 1) / (num_iterations ? num_iterations : 1));
+                printf("\nIteration %d time: %f\n", t, wall_clock() - t0);
+            }
+        } else {
+            printf("OT time: %f\n", t_ot);
+        }
+        printf("Time elapsed: %f\n", wall_clock() - time);
+        printf("Number of gates: %lld\n", gates);
+        printf("Result: ");
+        for (size_t i = 0; i < d; i++) printf("%20.15f ", fixed_to_double(beta[i], precision));
+        printf("\n");
+        free(beta); free(trace);
+    }
+    lgc_party_destroy(po);
+    node_destroy(&self);
+    free(Af); free(bf); free(mine);
+    return 0;
+error:
+    if (f) fclose(f);
+    if (po) lgc_party_destroy(po);
+    node_destroy(&self);
+    return 1;
+}

@@ -118,3 +118,70 @@ def test_five_process_cholesky_matches_oracle(tmp_path, golden_dir, oracle):
     got = re.findall("-?[0-9]+\\.[0-9]+", outs[1].strip().splitlines()[-1])
     beta = oracle.linreg_file(os.path.join(golden_dir, "readme_example.in"), 56, -1, 64, 64, 0, 0, 0.001)
     assert got == ["%.15f" % (int(b) / 2.0 ** 56) for b in beta]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--use_ot"]], ids=["ti", "ot"])
+def test_secure_multiplication_binary(tmp_path, golden_dir, extra):
+    """phase-1-only benchmark driver: the JSON lines of src/cmd/secure_multiplication.c:74,98-104"""
+    import json
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    infile = str(tmp_path / "readme.in")
+    P = _rewrite_ports(os.path.join(golden_dir, "readme_example.in"), infile)
+    exe = os.path.join(HOST, "bin", "secure_multiplication")
+    procs = [subprocess.Popen([exe, infile, "56", str(k)] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for k in range(1, P + 3)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-1000:]
+    assert '{"n":"10", "d":"5", "p":"3"}' in outs[0][0].decode()
+    for k, (o, _) in enumerate(outs):
+        lines = [l for l in o.decode().splitlines() if l.startswith('{"party"')]
+        t = json.loads(lines[0])
+        assert t["party"] == str(k + 1) and float(t["realtime"]) >= 0 and (k == 1 or float(t["realtime"]) > 0 or extra)
+        sent = json.loads(lines[1])["bytes_sent"]
+        assert len(sent) == P + 2
+        if k >= 2:
+            assert sum(sent) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg,w,p", [("cgd", 64, 56), ("cholesky", 64, 54), ("ldlt", 32, 28)])
+def test_test_linear_system_binary(tmp_path, oracle, alg, w, p):
+    """two-party phase-2 benchmark (src/cmd/test/test_linear_system.c) vs the oracle on the same file"""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(17)
+    d, iters = 4, 5
+    X = rng.standard_normal((40, d)); X /= np.abs(X).max(axis=0)
+    A = X.T @ X / (40 * d) + np.eye(d) * 1e-2
+    sol = rng.random(d)
+    b = A @ sol
+    path = str(tmp_path / "ls.in")
+    with open(path, "w") as f:                       # experiments/generate_tests.py:9-26 layout
+        f.write("%d %d\n" % (d, d))
+        for i in range(d):
+            f.write(" ".join(repr(float(v)) for v in A[i]) + " \n")
+        f.write("%d\n" % d + " ".join(repr(float(v)) for v in b) + " \n")
+        f.write("%d\n" % d + " ".join(repr(float(v)) for v in sol) + " ")
+    port = _free_ports(1)[0]
+    exe = os.path.join(HOST, "bin", "test_linear_system")
+    opt = ["--width=%d" % w, "--host=127.0.0.1"]
+    procs = [subprocess.Popen([exe, str(port), str(k), path, alg, str(iters), str(p)] + opt,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for k in (1, 2)]
+    outs = [q.communicate(timeout=300) for q in procs]
+    for q, (o, e) in zip(procs, outs):
+        assert q.returncode == 0, e.decode()[-1000:]
+    ev = outs[1][0].decode()
+    got = re.findall("-?[0-9]+\\.[0-9]+", ev.strip().splitlines()[-1])
+    aq = np.array([oracle.lib.orc_double_to_fixed(float(A[i, j]), p, w) for i in range(d) for j in range(i + 1)], dtype=np.int64)
+    bq = np.array([oracle.lib.orc_double_to_fixed(float(v), p, w) for v in b], dtype=np.int64)
+    if alg == "cgd":
+        exp = oracle.cgd(aq, bq, d, p, w, iters)
+    elif alg == "cholesky":
+        exp = oracle.cholesky(aq, bq, d, p, w)
+    else:
+        exp = oracle.ldlt(aq, bq, d, p, w)
+    assert got == ["%.15f" % (int(v) / 2.0 ** p) for v in exp]
+    assert "Number of gates:" in ev and "Time elapsed:" in ev and "Algorithm: %s" % alg in ev
+    if alg != "ldlt":                                 # sanity: close to the floating-point solution
+        assert np.allclose([float(x) for x in got], sol, atol=1e-3 if alg == "cgd" else 1e-6)
