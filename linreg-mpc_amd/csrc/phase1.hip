@@ -91,7 +91,18 @@ __global__ void p1_diag_kernel(const int64_t *X, size_t n, size_t ld, const uint
     const uint32_t c = cols[t];
     const double scale = (double)(1ll << p);
     double xy = 0.0;
-    for (size_t k = 0; k < n; k++) {
+    size_t k = 0;
+    for (; k + 8 <= n; k += 8) {   // 8 independent loads in flight; the additions stay in k order
+        int64_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = X[(k + u) * ld + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            double v = __ddiv_rn((double)x[u], scale);
+            xy = __dadd_rn(xy, __dmul_rn(__dmul_rn(v, v), scale));
+        }
+    }
+    for (; k < n; k++) {
         double v = __ddiv_rn((double)X[k * ld + c], scale);
         xy = __dadd_rn(xy, __dmul_rn(__dmul_rn(v, v), scale));
     }
@@ -149,6 +160,22 @@ ti_prg_kernel(const uint32_t *rk, uint64_t first_block, uint64_t nblocks, uint4 
         uint32_t s[1][4] = {{(uint32_t)c, (uint32_t)(c >> 32), 0u, 0u}};
         aes_encrypt_n<1, LdsTab>(lt, srk, s);
         out[b] = make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
+    }
+}
+
+// split the TI keystream into x[q][n], y[q][n], r[q]: word t of pair q sits at stream word
+// q * (2n + 1) + t  (w-bit little-endian words; `skip` = byte offset of the first word in ks)
+__global__ void ti_unpack_kernel(const uint8_t *ks, size_t skip, size_t npairs, size_t n, int wb, uint64_t *x, uint64_t *y,
+                                 uint64_t *r) {
+    const size_t per = 2 * n + 1, total = npairs * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint8_t *p = ks + skip + i * (size_t)wb;
+        uint64_t v = 0;
+        for (int b = 0; b < wb; b++) v |= (uint64_t)p[b] << (8 * b);
+        size_t q = i / per, t = i % per;
+        if (t < n) x[q * n + t] = v;
+        else if (t < 2 * n) y[q * n + (t - n)] = v;
+        else r[q] = v;
     }
 }
 
@@ -307,32 +334,22 @@ extern "C" int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t firs
     uint4 *dks = 0;
     P1CHK(hipMalloc(&dks, (blk1 - blk0) * 16));
     hipLaunchKernelGGL(ti_prg_kernel, dim3(512), dim3(1024), 0, 0, drk, blk0, blk1 - blk0, dks);
-    std::vector<uint8_t> ks((blk1 - blk0) * 16);
-    P1CHK(hipMemcpy(ks.data(), dks, ks.size(), hipMemcpyDeviceToHost));
-    (void)hipFree(dks); (void)hipFree(drk);
-    const uint8_t *s = ks.data() + (byte0 - blk0 * 16);
     const uint64_t m = maskw(width);
-    // unpack the stream; <x,y> on the device through the generic dot kernel would need the data
-    // resident anyway: do the n-term wrap-around sums here on the unpacked words with the GPU dot
-    std::vector<uint64_t> xs(npairs * n), ys(npairs * n);
-    for (size_t q = 0; q < npairs; q++) {
-        for (size_t k = 0; k < n; k++) { uint64_t v = 0; memcpy(&v, s, wb); s += wb; xs[q * n + k] = v; }
-        for (size_t k = 0; k < n; k++) { uint64_t v = 0; memcpy(&v, s, wb); s += wb; ys[q * n + k] = v; }
-        uint64_t v = 0; memcpy(&v, s, wb); s += wb; r[q] = v;
-    }
-    memcpy(x, xs.data(), xs.size() * 8);
-    memcpy(y, ys.data(), ys.size() * 8);
-    uint64_t *dA = 0, *dB = 0, *dout = 0;
+    uint64_t *dA = 0, *dB = 0, *dr = 0, *dout = 0;
     size_t bytes = npairs * n * 8;
-    P1CHK(hipMalloc(&dA, bytes)); P1CHK(hipMalloc(&dB, bytes)); P1CHK(hipMalloc(&dout, npairs * 8));
-    P1CHK(hipMemcpy(dA, xs.data(), bytes, hipMemcpyHostToDevice));
-    P1CHK(hipMemcpy(dB, ys.data(), bytes, hipMemcpyHostToDevice));
+    P1CHK(hipMalloc(&dA, bytes)); P1CHK(hipMalloc(&dB, bytes)); P1CHK(hipMalloc(&dr, npairs * 8)); P1CHK(hipMalloc(&dout, npairs * 8));
+    hipLaunchKernelGGL(ti_unpack_kernel, dim3(1024), dim3(256), 0, 0, (const uint8_t *)dks, (size_t)(byte0 - blk0 * 16), npairs, n,
+                       (int)wb, dA, dB, dr);
     P1CHK(hipMemset(dout, 0, npairs * 8));
     unsigned gx = (unsigned)((n + 255) / 256); if (gx > 64) gx = 64;
     hipLaunchKernelGGL(p1_dot_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, dA, dB, (const int64_t *)0, (size_t)0,
                        (const uint32_t *)0, n, dout);
+    P1CHK(hipMemcpy(x, dA, bytes, hipMemcpyDeviceToHost));
+    P1CHK(hipMemcpy(y, dB, bytes, hipMemcpyDeviceToHost));
+    P1CHK(hipMemcpy(r, dr, npairs * 8, hipMemcpyDeviceToHost));
     P1CHK(hipMemcpy(xy_minus_r, dout, npairs * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dout);
+    (void)hipFree(dks); (void)hipFree(drk);
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dr); (void)hipFree(dout);
     for (size_t q = 0; q < npairs; q++) xy_minus_r[q] = (xy_minus_r[q] - r[q]) & m;
     return LGC_OK;
 }
