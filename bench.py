@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--d", type=int, default=500)
+    ap.add_argument("--d", "--dimension", dest="d", type=int, default=500)
     ap.add_argument("--iters", type=int, default=15)
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--precision", type=int, default=56)
@@ -60,11 +60,17 @@ def main():
 
     if not torch.cuda.is_available() or lgc.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (no HIP device visible; there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    device_index = local_rank % max(1, ndev)     # one rank per GPU; wraps only in single-GPU dry runs
+    torch.cuda.set_device(device_index)
     dist = None
+    backend = os.environ.get("LGC_BENCH_BACKEND", "nccl")   # "gloo" only to dry-run N > 1 on one GPU
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     d, iters, w, p = args.d, args.iters, args.width, args.precision
     T = d * (d + 1) // 2
@@ -89,7 +95,7 @@ def main():
         shares &= np.uint64(0xffffffff)
 
     sysm = lgc.make_system(d, w, p, "cgd", iters, 0.0, 2, 0, 0, 0)
-    solver = lgc.Solver(sysm, seed=bytes((rank + i) & 0xff for i in range(16)), device=local_rank)
+    solver = lgc.Solver(sysm, seed=bytes((rank + i) & 0xff for i in range(16)), device=device_index)
     solver.set_shares(shares)
 
     def barrier():
@@ -110,7 +116,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     st = solver.stats()
@@ -141,7 +147,7 @@ def main():
         avg_dur = mac_g / max(1, mac_launches)
         alg_bytes_per_launch = alg_bytes_per_solve / n_launch_per_solve
         achieved = alg_bytes_per_launch / avg_dur / 1e9 if avg_dur > 0 else 0.0
-        aes_rate, _ = lgc.aes_bench(65536, 256, device=local_rank)
+        aes_rate, _ = lgc.aes_bench(65536, 256, device=device_index)
         # exclusive (serialised) pass: 4 AES per AND garbling, 2 evaluating
         xg, xe = stx["seconds_mac_garble"], stx["seconds_mac_eval"]
         aes_achieved = 4.0 * mac_gates / xg if xg > 0 else 0.0

@@ -126,6 +126,36 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4], con
     for (int b = 0; b < N; b++) {
         s[b][0] ^= rk[0]; s[b][1] ^= rk[1]; s[b][2] ^= rk[2]; s[b][3] ^= rk[3];
     }
+#if defined(GC_AES_COLWISE) && GC_AES_COLWISE
+    // column-wise rounds: only 4 lookups per block live at a time (fewer VGPRs, less ILP per block)
+#pragma unroll
+    for (int rnd = 1; rnd < 10; rnd++) {
+        uint32_t ns[N][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t v0[N], v1[N], v2[N], v3[N];
+#pragma unroll
+            for (int b = 0; b < N; b++) {
+                v0[b] = tab.lk(s[b][j], 0);
+                v1[b] = tab.lk(s[b][(j + 1) & 3], 1);
+                v2[b] = T::kTwoTables ? tab.lk2(s[b][(j + 2) & 3], 2) : tab.lk(s[b][(j + 2) & 3], 2);
+                v3[b] = T::kTwoTables ? tab.lk2(s[b][(j + 3) & 3], 3) : tab.lk(s[b][(j + 3) & 3], 3);
+            }
+#pragma unroll
+            for (int b = 0; b < N; b++) {
+                if (T::kTwoTables) {
+                    uint32_t x = xor3(v1[b], v3[b], rk24[4 * rnd + j]);
+                    ns[b][j] = xor3(v0[b], v2[b], rotl32(x, 8));
+                } else {
+                    uint32_t t = xor3(v0[b], rotl32(v2[b], 16), rk[4 * rnd + j]);
+                    ns[b][j] = xor3(t, rotl32(v1[b], 8), rotl32(v3[b], 24));
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < N; b++) { s[b][0] = ns[b][0]; s[b][1] = ns[b][1]; s[b][2] = ns[b][2]; s[b][3] = ns[b][3]; }
+    }
+#else
 #pragma unroll
     for (int rnd = 1; rnd < 10; rnd++) {
         uint32_t v[N][16];
@@ -155,6 +185,7 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4], con
             }
         }
     }
+#endif
     {
         uint32_t v[N][16];
 #pragma unroll
