@@ -160,6 +160,55 @@ struct Circ {
         csa(be, AS, AC, Y, w);
     }
 
+    // ---- two independent 32-bit products per wavefront (lanes 0..31 and 32..63): the 32-bit
+    // build's multiply-accumulate would otherwise leave half of every wave idle.  Same circuit
+    // as mul_core / mul_xy / csa with w = 32, every lane move confined to its 32-lane segment.
+    static GC_HD uint64_t m2(uint64_t m32) { return (m32 & 0xffffffffull) | (m32 << 32); }
+    static GC_HD W shr2(B &be, W x, int k) { return be.sel(m2(lanes(32 - k)), be.shr(x, k), be.zero()); }
+    static GC_HD W shl2(B &be, W x, int k) { return be.sel(m2(lanes(32) & ~lanes(k)), be.shl(x, k), be.zero()); }
+    static GC_HD void mul_core2(B &be, W a, W b, int p, W &L, W &S, W &C) {
+        const int w = 32, M = w + p;
+        S = be.zero();
+        L = be.zero();
+        C = (p >= 1) ? be.konst(m2(1ull << (w - 1))) : be.zero();
+        for (int r = 0; r < w; r++) {
+            const int na = (M - r) < w ? (M - r) : w;
+            const uint64_t act = m2(lanes(na));
+            W bb = be.bcast2(b, r);
+            W pp = be.AND(a, bb, act);
+            uint64_t inv = m2((r == w - 1) ? lanes(w - 1) : (1ull << (w - 1)));
+            pp = be.NOTm(pp, inv & act);
+            if (r == 0) {
+                S = pp;
+            } else {
+                W t = be.AND(be.XOR(S, pp), be.XOR(C, pp), act);
+                W Sn = be.XOR(be.XOR(S, C), pp);
+                C = be.XOR(t, pp);
+                S = Sn;
+            }
+            L = be.sel(m2(1ull << r), be.bcast2(S, 0), L);
+            S = shr2(be, S, 1);
+        }
+        S = be.sel(m2(lanes(p)), S, be.zero());
+        C = be.sel(m2(lanes(p)), C, be.zero());
+    }
+    // both segments: (AS, AC) += wrap_32((a*b) >> p), carry-save
+    static GC_HD void mac2(B &be, W &AS, W &AC, W a, W b, int p) {
+        W L, S, C;
+        mul_core2(be, a, b, p, L, S, C);
+        W X = be.XOR(shr2(be, L, p), shl2(be, S, 32 - p));
+        W Y = shl2(be, C, 32 - p);
+        const uint64_t all = ~0ull;
+        W t = be.AND(be.XOR(AS, X), be.XOR(AC, X), all);
+        W carry = be.XOR(t, X);
+        AS = be.XOR(be.XOR(AS, AC), X);
+        AC = shl2(be, carry, 1);
+        t = be.AND(be.XOR(AS, Y), be.XOR(AC, Y), all);
+        carry = be.XOR(t, Y);
+        AS = be.XOR(be.XOR(AS, AC), Y);
+        AC = shl2(be, carry, 1);
+    }
+
     // ---- wide inner-product accumulator: sum of exact products mod 2^(w+p)
     struct IpAcc { W LS, LC, HS, HC; };
     static GC_HD void ip_zero(B &be, IpAcc &A) { A.LS = A.LC = A.HS = A.HC = be.zero(); }
@@ -270,6 +319,10 @@ struct PlainBackend {
     GC_HD W shl(W a, int k) const { return k >= 64 ? 0 : a << k; }
     GC_HD W shr(W a, int k) const { return k >= 64 ? 0 : a >> k; }
     GC_HD W bcast(W a, int lane) const { return ((a >> lane) & 1) ? ~0ull : 0ull; }
+    // per 32-lane segment: lanes 0..31 <- lane r, lanes 32..63 <- lane 32 + r
+    GC_HD W bcast2(W a, int r) const {
+        return (((a >> r) & 1) ? 0xffffffffull : 0ull) | (((a >> (32 + r)) & 1) ? 0xffffffff00000000ull : 0ull);
+    }
     GC_HD W sel(uint64_t m, W a, W b) const { return (a & m) | (b & ~m); }
 };
 

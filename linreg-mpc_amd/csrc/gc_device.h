@@ -19,7 +19,10 @@ namespace gc {
 
 __constant__ uint32_t c_rk[44];
 __constant__ uint32_t c_te0[256];
-__constant__ uint32_t c_rk24[44];   // rotl24 of the round keys (two-table AES rounds)
+__constant__ uint32_t c_rk24[44];
+#ifdef GC_STAMP
+__device__ unsigned long long *g_stamp = 0;   // diagnostic build only: [hash, barrier, glue, last, count, tail]
+#endif   // rotl24 of the round keys (two-table AES rounds)
 
 static constexpr int kLdsTabWords = 256 * 64;   // 64 KiB: entry x occupies the 256-byte row x
 
@@ -96,6 +99,13 @@ __device__ __forceinline__ void st_lbl(Lbl *p, Lbl v) {
 //            launches (dividers, adders, max trees).
 enum { MODE_MAC = 0, MODE_SOLO = 1, MODE_QUAD = 2 };
 
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the
+// vector-memory queue (vmcnt), so table stores / prefetched table loads stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 template <bool GARBLER, int MODE, class TAB = LdsTab>
 struct GpuBackend {
     typedef Lbl W;
@@ -125,6 +135,10 @@ struct GpuBackend {
         W r = {(uint32_t)__builtin_amdgcn_readlane((int)a.x, src), (uint32_t)__builtin_amdgcn_readlane((int)a.y, src),
                (uint32_t)__builtin_amdgcn_readlane((int)a.z, src), (uint32_t)__builtin_amdgcn_readlane((int)a.w, src)};
         return r;
+    }
+    __device__ __forceinline__ W bcast2(W a, int r) const {
+        W lo = bcast(a, r), hi = bcast(a, 32 + r);
+        return sel(0xffffffffull, lo, hi);
     }
     __device__ __forceinline__ W pull(W a, int from, bool ok) const {
         int addr = (from & 63) << 2;
@@ -190,6 +204,9 @@ struct GpuBackend {
     // exchange area is double-buffered by step parity.
     static __device__ __noinline__ W and_quad(TAB lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on,
                                               int wave, Lbl *xbuf, int lane) {
+#ifdef GC_STAMP
+        unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
         const int nh = GARBLER ? 4 : 2;
         Lbl TGe = lzero(), TEe = lzero();
         if (!GARBLER && on) { TGe = ld_lbl(slot); TEe = ld_lbl(slot + 64); }   // in flight during the hash
@@ -203,7 +220,20 @@ struct GpuBackend {
             }
             xbuf[wave * 64 + lane] = h;
         }
-        __syncthreads();
+#ifdef GC_STAMP
+        unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+        lds_barrier();
+#ifdef GC_STAMP
+        unsigned long long st2 = __builtin_amdgcn_s_memtime();
+        if (wave == 0 && lane == 0 && g_stamp) {
+            unsigned long long prev = g_stamp[3];
+            g_stamp[0] += st1 - st0;                 // hash
+            g_stamp[1] += st2 - st1;                 // barrier wait
+            if (prev) g_stamp[2] += st0 - prev;      // caller glue since the previous gate step returned
+            g_stamp[4] += 1;
+        }
+#endif
         W c = lzero();
         if (on) {
             if (GARBLER) {
@@ -226,6 +256,9 @@ struct GpuBackend {
                 c = lxor(WG, WE);
             }
         }
+#ifdef GC_STAMP
+        if (wave == 0 && lane == 0 && g_stamp) { g_stamp[3] = __builtin_amdgcn_s_memtime(); g_stamp[5] += g_stamp[3] - st2; }
+#endif
         return c;
     }
     // two gate steps (gid, gid + 64) at once: 8 (garbler) / 4 (evaluator) hashes over 4 waves
@@ -255,7 +288,7 @@ struct GpuBackend {
             if ((wave < 2) ? on1 : on2) hash_n<1, TAB>(lt, c_rk, &x, &tw, &h);
             xbuf[(wave >> 1) * 256 + (wave & 1) * 64 + lane] = h;
         }
-        __syncthreads();
+        lds_barrier();
         c1 = lzero();
         c2 = lzero();
         if (GARBLER) {
@@ -293,6 +326,12 @@ struct GpuBackend {
         }
     }
     __device__ __forceinline__ W load(uint32_t id) const { return ld_lbl(words + (size_t)id * 64 + lane); }
+    __device__ __forceinline__ W load2(uint32_t lo, uint32_t hi) const {
+        return ld_lbl(words + (size_t)(lane < 32 ? lo : hi) * 64 + (lane & 31));
+    }
+    __device__ __forceinline__ void store2(uint32_t lo, uint32_t hi, W v) {
+        if (MODE != MODE_QUAD || wave == 0) st_lbl(words + (size_t)(lane < 32 ? lo : hi) * 64 + (lane & 31), v);
+    }
     __device__ __forceinline__ void store(uint32_t id, W v) {
         if (MODE != MODE_QUAD || wave == 0) st_lbl(words + (size_t)id * 64 + lane, v);
     }
@@ -335,6 +374,14 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
     be.step = ((uint64_t)s_hi << 32) | s_lo;
     typedef Circ<B> C;
     Lbl S = lzero(), Cc = lzero();
+    if (__builtin_amdgcn_readfirstlane(r.op) == OP_MAC2) {
+        for (uint32_t k = 0; k < r.cnt; k++)
+            C::mac2(be, S, Cc, be.load2(r.a + (int32_t)k * r.sa, r.a + (int32_t)(r.cnt + k) * r.sa),
+                    be.load2(r.b + (int32_t)k * r.sb, r.b + (int32_t)(r.cnt + k) * r.sb), p);
+        be.store2(r.dst, r.dst + 2, S);
+        be.store2(r.dst + 1, r.dst + 3, Cc);
+        return;
+    }
     for (uint32_t k = 0; k < r.cnt; k++)
         C::mac(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
     be.store(r.dst, S);

@@ -36,6 +36,8 @@ enum Op : uint32_t {
     OP_CONST,   // dst = public constant (a = low 32 bits, b = high 32 bits)
     OP_COPY,    // dst = a
     OP_REVEAL,  // decode[dst] = colour bits of word a (cnt unused)
+    OP_MAC2,    // 32-bit only: two OP_MAC chunks per wave; products k (lanes 0..31) and cnt+k (lanes 32..63);
+                // (S,C) of the first chunk -> dst, dst+1, of the second -> dst+2, dst+3
     OP_COUNT_
 };
 
@@ -61,6 +63,14 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
             C::mac(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
         be.store(r.dst, S);
         be.store(r.dst + 1, Cc);
+    } break;
+    case OP_MAC2: {
+        W S = be.zero(), Cc = be.zero();
+        for (uint32_t k = 0; k < r.cnt; k++)
+            C::mac2(be, S, Cc, be.load2(r.a + (int32_t)k * r.sa, r.a + (int32_t)(r.cnt + k) * r.sa),
+                    be.load2(r.b + (int32_t)k * r.sb, r.b + (int32_t)(r.cnt + k) * r.sb), p);
+        be.store2(r.dst, r.dst + 2, S);
+        be.store2(r.dst + 1, r.dst + 3, Cc);
     } break;
     case OP_SUM:
     case OP_SUBSUM: {
@@ -147,6 +157,9 @@ struct PlainMachine : PlainBackend {
     PlainMachine(uint64_t *w_, uint64_t *d_) : words(w_), decode(d_) {}
     W load(uint32_t id) const { return words[id]; }
     void store(uint32_t id, W v) { words[id] = v; }
+    // lanes 0..31 of word lo | lanes 0..31 of word hi moved to lanes 32..63 (and back)
+    W load2(uint32_t lo, uint32_t hi) const { return (words[lo] & 0xffffffffull) | (words[hi] << 32); }
+    void store2(uint32_t lo, uint32_t hi, W v) { words[lo] = v & 0xffffffffull; words[hi] = v >> 32; }
     void reveal(uint32_t slot, W v) { if (decode) decode[slot] = v; }
 };
 
@@ -155,7 +168,9 @@ struct PlainMachine : PlainBackend {
 inline void rec_cost(const Rec &r, int w, int p, uint64_t &steps, uint64_t &gates) {
     struct CostMachine : PlainBackend {
         W load(uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
+        W load2(uint32_t, uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
         void store(uint32_t, W) {}
+        void store2(uint32_t, uint32_t, W) {}
         void reveal(uint32_t, W) {}
     } m;
     exec_record(m, r, w, p);

@@ -75,7 +75,7 @@ struct Program {
     void emit(Rec r) {
         uint64_t s, g;
         cost(r, s, g);
-        bool mac = (r.op == OP_MAC);
+        bool mac = (r.op == OP_MAC || r.op == OP_MAC2);
         if (!open || launches.back().steps + s > cap_steps || launches.back().mac_only != mac) {
             Launch L;
             L.first_rec = (uint32_t)recs.size();
@@ -148,11 +148,22 @@ struct Program {
             const DotJob &J = jobs[i];
             parts[i].first = cur;
             uint32_t nparts = 0;
-            for (uint32_t k0 = 0; k0 < J.len; k0 += (uint32_t)chunk) {
-                uint32_t len = J.len - k0 < chunk ? J.len - k0 : (uint32_t)chunk;
-                emit(mk(OP_MAC, cur, J.a + k0, J.b + k0, 0, len));
-                cur += 2;
-                nparts += 2;
+            for (uint32_t k0 = 0; k0 < J.len;) {
+                uint32_t left = J.len - k0;
+                if (w == 32 && left >= 2) {
+                    // two chunks of `len` products side by side in one wave (lanes 0..31 / 32..63)
+                    uint32_t len = left / 2 < chunk ? left / 2 : (uint32_t)chunk;
+                    emit(mk(OP_MAC2, cur, J.a + k0, J.b + k0, 0, len));
+                    cur += 4;
+                    nparts += 4;
+                    k0 += 2 * len;
+                } else {
+                    uint32_t len = left < chunk ? left : (uint32_t)chunk;
+                    emit(mk(OP_MAC, cur, J.a + k0, J.b + k0, 0, len));
+                    cur += 2;
+                    nparts += 2;
+                    k0 += len;
+                }
             }
             parts[i].second = nparts;
         }
@@ -179,7 +190,7 @@ struct Program {
     }
     size_t dots_scratch(size_t total_products, size_t njobs, size_t target_waves) {
         size_t chunk = dots_chunk(total_products, target_waves);
-        return 2 * (total_products / chunk + njobs + 2) + 16;
+        return 2 * (total_products / chunk + njobs + 2) + 4 * njobs + 16;   // + tails of dual 32-bit records
     }
 
     // wide inner products (fixed.oc:124-147), several independent ones level-synchronously:

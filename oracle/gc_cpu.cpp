@@ -84,6 +84,7 @@ struct CpuBackend {
     }
     W sel(uint64_t m, const W &a, const W &b) const { W r; for (int i = 0; i < 64; i++) r.l[i] = ((m >> i) & 1) ? a.l[i] : b.l[i]; return r; }
     W bcast(const W &a, int src) const { W r; for (int i = 0; i < 64; i++) r.l[i] = a.l[src]; return r; }
+    W bcast2(const W &a, int r) const { W o; for (int i = 0; i < 64; i++) o.l[i] = a.l[(i < 32 ? 0 : 32) + r]; return o; }
     W shl(const W &a, int k) const { W r; for (int i = 0; i < 64; i++) r.l[i] = (i - k >= 0 && k < 64) ? a.l[i - k] : _mm_setzero_si128(); return r; }
     W shr(const W &a, int k) const { W r; for (int i = 0; i < 64; i++) r.l[i] = (i + k < 64 && k < 64) ? a.l[i + k] : _mm_setzero_si128(); return r; }
     W AND(const W &a, const W &b, uint64_t act) {
@@ -130,6 +131,8 @@ struct CpuBackend {
         c2 = AND(a2, b2, act2);
     }
     W load(uint32_t id) const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_loadu_si128(words + (size_t)id * 64 + i); return r; }
+    W load2(uint32_t lo, uint32_t hi) const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_loadu_si128(words + (size_t)(i < 32 ? lo : hi) * 64 + (i & 31)); return r; }
+    void store2(uint32_t lo, uint32_t hi, const W &v) { for (int i = 0; i < 64; i++) _mm_storeu_si128(words + (size_t)(i < 32 ? lo : hi) * 64 + (i & 31), v.l[i]); }
     void store(uint32_t id, const W &v) { for (int i = 0; i < 64; i++) _mm_storeu_si128(words + (size_t)id * 64 + i, v.l[i]); }
     void reveal(uint32_t slot, const W &v) {
         uint64_t m = 0;
