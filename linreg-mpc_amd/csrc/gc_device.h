@@ -202,7 +202,15 @@ struct GpuBackend {
     // cooperative gate step (one out-of-line copy: code size, compile time).  Every wave of
     // the workgroup calls this with identical operands; exactly one barrier per step, the
     // exchange area is double-buffered by step parity.
-    static __device__ __noinline__ W and_quad(TAB lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on,
+#ifndef GC_QUAD_INLINE
+#define GC_QUAD_INLINE 1   /* inlined: no call ABI spills around every gate step (DIV 3.5 -> 2.4 ms) */
+#endif
+#if GC_QUAD_INLINE
+#define GC_QUAD_ATTR __forceinline__
+#else
+#define GC_QUAD_ATTR __noinline__
+#endif
+    static __device__ GC_QUAD_ATTR W and_quad(TAB lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on,
                                               int wave, Lbl *xbuf, int lane) {
 #ifdef GC_STAMP
         unsigned long long st0 = __builtin_amdgcn_s_memtime();
@@ -226,12 +234,9 @@ struct GpuBackend {
         lds_barrier();
 #ifdef GC_STAMP
         unsigned long long st2 = __builtin_amdgcn_s_memtime();
-        if (wave == 0 && lane == 0 && g_stamp) {
-            unsigned long long prev = g_stamp[3];
-            g_stamp[0] += st1 - st0;                 // hash
-            g_stamp[1] += st2 - st1;                 // barrier wait
-            if (prev) g_stamp[2] += st0 - prev;      // caller glue since the previous gate step returned
-            g_stamp[4] += 1;
+        if (wave == 0 && lane == 0 && g_stamp) {     // store-only trace: [entry, after hash, after barrier, exit]
+            unsigned long long *t = g_stamp + (((gid >> 6) & 0xffffull) << 2);
+            t[0] = st0; t[1] = st1; t[2] = st2;
         }
 #endif
         W c = lzero();
@@ -257,13 +262,16 @@ struct GpuBackend {
             }
         }
 #ifdef GC_STAMP
-        if (wave == 0 && lane == 0 && g_stamp) { g_stamp[3] = __builtin_amdgcn_s_memtime(); g_stamp[5] += g_stamp[3] - st2; }
+        if (wave == 0 && lane == 0 && g_stamp) g_stamp[((((gid >> 6) & 0xffffull) << 2)) + 3] = __builtin_amdgcn_s_memtime();
 #endif
         return c;
     }
     // two gate steps (gid, gid + 64) at once: 8 (garbler) / 4 (evaluator) hashes over 4 waves
-    static __device__ __noinline__ void and2_quad(TAB lt, Lbl R, W a1, W b1, W a2, W b2, uint64_t gid, Lbl *slot,
+    static __device__ GC_QUAD_ATTR void and2_quad(TAB lt, Lbl R, W a1, W b1, W a2, W b2, uint64_t gid, Lbl *slot,
                                                   bool on1, bool on2, int wave, Lbl *xbuf, int lane, W &c1, W &c2) {
+#ifdef GC_STAMP
+        unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
         const uint64_t gid2 = gid + 64;
         Lbl *slot2 = slot + 128;
         Lbl TG1 = lzero(), TE1 = lzero(), TG2 = lzero(), TE2 = lzero();
@@ -288,7 +296,17 @@ struct GpuBackend {
             if ((wave < 2) ? on1 : on2) hash_n<1, TAB>(lt, c_rk, &x, &tw, &h);
             xbuf[(wave >> 1) * 256 + (wave & 1) * 64 + lane] = h;
         }
+#ifdef GC_STAMP
+        unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
         lds_barrier();
+#ifdef GC_STAMP
+        unsigned long long st2 = __builtin_amdgcn_s_memtime();
+        if (wave == 0 && lane == 0 && g_stamp) {
+            unsigned long long *t = g_stamp + (((gid >> 6) & 0xffffull) << 2);
+            t[0] = st0; t[1] = st1; t[2] = st2;
+        }
+#endif
         c1 = lzero();
         c2 = lzero();
         if (GARBLER) {
@@ -324,6 +342,9 @@ struct GpuBackend {
                 c2 = lxor(lxor(h0, lmask(TG2, sa)), lxor(h1, lmask(lxor(TE2, a2), sb)));
             }
         }
+#ifdef GC_STAMP
+        if (wave == 0 && lane == 0 && g_stamp) g_stamp[((((gid >> 6) & 0xffffull) << 2)) + 3] = __builtin_amdgcn_s_memtime();
+#endif
     }
     __device__ __forceinline__ W load(uint32_t id) const { return ld_lbl(words + (size_t)id * 64 + lane); }
     __device__ __forceinline__ W load2(uint32_t lo, uint32_t hi) const {

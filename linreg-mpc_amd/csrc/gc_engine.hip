@@ -316,9 +316,12 @@ static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
 // generic launches with at least this many records run one wave per record (throughput);
 // narrower ones run one 4-wave workgroup per record (latency)
 static constexpr uint32_t kWideLaunch = 2048;
+// MAC launches with fewer records than this are latency-bound too (Cholesky / LDL^T stages at
+// small d): they run in the 4-wave mode instead of the throughput-oriented MAC kernel
+static constexpr uint32_t kNarrowMac = 1024;
 template <bool G>
 static void launch_exec(lgc_solver *s, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, hipStream_t st) {
-    if (L.mac_only) {
+    if (L.mac_only && L.nrec >= kNarrowMac) {
         constexpr int TPB = G ? kTpbMacG : kTpbMacE;
         const unsigned per = TPB / 64;
         dim3 grid((L.nrec + per - 1) / per), block(TPB);

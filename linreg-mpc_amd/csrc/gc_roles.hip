@@ -168,12 +168,12 @@ extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint
 
 template <bool G>
 static void party_launch(lgc_party *p, const Launch &L) {
-    if (L.mac_only) {
+    if (L.mac_only && L.nrec >= kNarrowMac) {
         constexpr int TPB = G ? kTpbMacG : kTpbMacE;
         const unsigned per = TPB / 64;
         hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(TPB), 0, 0, p->recs + L.first_rec, L.nrec,
                            p->words, p->tab, L.step0, p->R, p->P.w, p->P.p);
-    } else if (L.nrec >= 2048) {
+    } else if (L.nrec >= kWideLaunch) {
         hipLaunchKernelGGL((gc_exec_kernel<G, false>), dim3((L.nrec + 3) / 4), dim3(256), 0, 0, p->recs + L.first_rec, L.nrec,
                            p->words, p->tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
     } else {
