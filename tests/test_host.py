@@ -185,3 +185,25 @@ def test_test_linear_system_binary(tmp_path, oracle, alg, w, p):
     assert "Number of gates:" in ev and "Time elapsed:" in ev and "Algorithm: %s" % alg in ev
     if alg != "ldlt":                                 # sanity: close to the floating-point solution
         assert np.allclose([float(x) for x in got], sol, atol=1e-3 if alg == "cgd" else 1e-6)
+
+
+def test_config_parser_and_owner_map(hostlib, golden_dir):
+    """header of the input file (reference src/config.c:24-44) and get_owner (src/phase1.c:25-33)"""
+    class Cfg(C.Structure):
+        _fields_ = [("party", C.c_int), ("num_parties", C.c_int), ("endpoint", C.POINTER(C.c_char_p)),
+                    ("index_owned", C.POINTER(C.c_ssize_t)), ("n", C.c_size_t), ("d", C.c_size_t), ("input", C.c_void_p)]
+    hostlib.config_new.argtypes = [C.POINTER(C.POINTER(Cfg)), C.c_char_p]
+    hostlib.config_destroy.argtypes = [C.POINTER(C.POINTER(Cfg))]
+    hostlib.config_owner.argtypes = [C.POINTER(Cfg), C.c_size_t]
+    pc = C.POINTER(Cfg)()
+    assert hostlib.config_new(C.byref(pc), os.path.join(golden_dir, "readme_example.in").encode()) == 0
+    c = pc.contents
+    assert (c.n, c.d, c.num_parties) == (10, 5, 5)
+    assert [c.endpoint[i].decode() for i in range(5)] == ["localhost:%d" % p for p in range(1234, 1239)]
+    assert [c.index_owned[i] for i in range(5)] == [-1, -1, 0, 1, 2]
+    # columns 0 | 1 | 2,3,4 + target (row 5) -> 0-based party indices 2, 3, 4
+    assert [hostlib.config_owner(pc, r) for r in range(6)] == [2, 3, 4, 4, 4, 4]
+    hostlib.config_destroy(C.byref(pc))
+    assert not pc
+    bad = C.POINTER(Cfg)()
+    assert hostlib.config_new(C.byref(bad), b"/nonexistent/file") != 0
