@@ -71,6 +71,9 @@ int recv_blob(node *self, int from, void *buf, uint64_t len) {
 int run_trusted_initializer(node *self, config *c, int w1, int device) {
     uint8_t seed[16];
     RAND_bytes(seed, sizeof seed);                       /* newBCipherRandomGen (src/phase1.c:243) */
+    const char *fixed = getenv("LINREG_TI_SEED");        /* tests only: 32 hex digits pin the TI stream */
+    if (fixed && strlen(fixed) == 32)
+        for (int i = 0; i < 16; i++) { unsigned v = 0; sscanf(fixed + 2 * i, "%2x", &v); seed[i] = (uint8_t)v; }
     const size_t n = c->n;
     uint64_t *x = malloc(n * 8), *y = malloc(n * 8), r, xyr;
     uint64_t pair = 0;

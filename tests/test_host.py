@@ -207,3 +207,35 @@ def test_config_parser_and_owner_map(hostlib, golden_dir):
     assert not pc
     bad = C.POINTER(Cfg)()
     assert hostlib.config_new(C.byref(bad), b"/nonexistent/file") != 0
+
+
+@pytest.mark.gpu
+def test_five_process_64_32_split_share_level(tmp_path, golden_dir, oracle, gccpu):
+    """BASELINE config 4's build: phase 1 in 64 bits, phase 2 in 32 bits (--prec_phase2).  Every
+    share is shifted on its own (src/phase1.c:609-638), so the result depends on the TI's
+    randomness: the TI seed is pinned and the oracle replays the same AES-CTR stream."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    src = os.path.join(golden_dir, "readme_example.in")
+    infile = str(tmp_path / "readme.in")
+    P = _rewrite_ports(src, infile)
+    p1, p2, lam, iters = 56, 24, 0.001, 6
+    seed = bytes(range(0x40, 0x50))
+    os.environ["LINREG_TI_SEED"] = seed.hex()
+    try:
+        outs = _run_all(infile, P, ["%d" % p1, "cgd", str(iters), str(lam), "--width_phase2=32", "--prec_phase2=%d" % p2])
+    finally:
+        del os.environ["LINREG_TI_SEED"]
+    got = re.findall("-?[0-9]+\\.[0-9]+", outs[1].strip().splitlines()[-1])
+    inp = oracle.read_input(src)
+    n, d = inp["n"], inp["d"]
+    Xq = oracle.quantize(inp["X"], p1, n, 32); yq = oracle.quantize(inp["y"], p1, n, 32)   # cast through the 32-bit fixed_t
+    words = gccpu.ti_stream_words(seed, 0, 64 * (2 * n + 1), 64)
+    sA, sb, used = oracle.ti_shares(Xq.reshape(n, d), yq, n, d, p1, 64, inp["start"], words)
+    cA = np.stack([oracle.convert_shares(r, p1, p2, 64, 32) for r in sA])
+    cb = np.stack([oracle.convert_shares(r, p1, p2, 64, 32) for r in sb])
+    a, bb = oracle.circuit_input(oracle.sum_shares(cA, 32), oracle.sum_shares(cb, 32), d, lam, p2, 32)
+    beta = oracle.cgd(a, bb, d, p2, 32, iters)
+    assert got == ["%.15f" % (int(v) / 2.0 ** p2) for v in beta]
+    # and the per-share shift really matters here: shifting the total instead gives another input
+    tot = oracle.aggregate(Xq.reshape(n, d), yq, n, d, p1, 64)
+    assert not np.array_equal(oracle.sum_shares(cA, 32), oracle.sum_shares(oracle.convert_shares(tot[0], p1, p2, 64, 32)[None, :], 32))
