@@ -75,20 +75,34 @@ int run_trusted_initializer(node *self, config *c, int w1, int device) {
     if (fixed && strlen(fixed) == 32)
         for (int i = 0; i < 16; i++) { unsigned v = 0; sscanf(fixed + 2 * i, "%2x", &v); seed[i] = (uint8_t)v; }
     const size_t n = c->n;
-    uint64_t *x = malloc(n * 8), *y = malloc(n * 8), r, xyr;
-    uint64_t pair = 0;
-    int rc = 1;
+    /* enumerate the cross-party pairs in the loop order of src/phase1.c:256-258, then generate the
+     * randomness in batches on the GPU and send the two messages of every pair in that order */
+    size_t cap = 0, np = 0;
+    int *pa_of = NULL, *pb_of = NULL;
     for (size_t i = 0; i <= c->d; i++)
         for (size_t j = 0; j <= i && j < c->d; j++) {
             int pa = config_owner(c, i), pb = config_owner(c, j);
             if (pa == pb) continue;
-            LGC(lgc_ti_generate(device, seed, pair++, 1, n, w1, x, y, &r, &xyr));
-            check(!send_pmsg(self, pa + 1, y, n, xyr), "Could not send message to party A (%d)", pa);   /* (y, <x,y> - r) */
-            check(!send_pmsg(self, pb + 1, x, n, r), "Could not send message to party B (%d)", pb);     /* (x, r) */
+            if (np == cap) { cap = cap ? 2 * cap : 1024; pa_of = realloc(pa_of, cap * sizeof(int)); pb_of = realloc(pb_of, cap * sizeof(int)); }
+            pa_of[np] = pa; pb_of[np] = pb; np++;
         }
+    size_t batch = ((size_t)64 << 20) / (n * 8);          /* about 64 MiB of x (and of y) per batch */
+    if (batch < 1) batch = 1;
+    if (batch > 1024) batch = 1024;
+    uint64_t *x = malloc(batch * n * 8), *y = malloc(batch * n * 8), *r = malloc(batch * 8), *xyr = malloc(batch * 8);
+    int rc = 1;
+    for (size_t q0 = 0; q0 < np; q0 += batch) {
+        size_t nb = np - q0 < batch ? np - q0 : batch;
+        LGC(lgc_ti_generate(device, seed, q0, nb, n, w1, x, y, r, xyr));
+        for (size_t q = 0; q < nb; q++) {
+            int pa = pa_of[q0 + q], pb = pb_of[q0 + q];
+            check(!send_pmsg(self, pa + 1, y + q * n, n, xyr[q]), "Could not send message to party A (%d)", pa);   /* (y, <x,y> - r) */
+            check(!send_pmsg(self, pb + 1, x + q * n, n, r[q]), "Could not send message to party B (%d)", pb);     /* (x, r) */
+        }
+    }
     rc = 0;
 error:
-    free(x); free(y);
+    free(x); free(y); free(r); free(xyr); free(pa_of); free(pb_of);
     return rc;
 }
 
@@ -176,33 +190,44 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
                     if (pj == last) { ri[q] = i; rj[q++] = d; }
                 }
                 if (pi == last) for (size_t j = j0; j < j1; j++) { ri[q] = d; rj[q++] = j; }
-                uint64_t *vals = malloc(npairs * n * 8), *shares = malloc(npairs * 8);
-                const uint64_t m = (uint64_t)npairs * n * (uint64_t)w1;
-                size_t ub = lgc_ot_u_bytes(m);
-                uint8_t *u = malloc(ub);
-                uint64_t *yv = malloc(m * 8);
+                /* batches of pairs: at most 2^26 OTs (1 GiB of u) in flight */
+                size_t per = ((size_t)1 << 26) / (n * (size_t)w1);
+                if (per < 1) per = 1;
+                if (per > npairs) per = npairs;
+                uint64_t *vals = malloc(per * n * 8), *shares = malloc(npairs * 8);
+                const uint64_t mmax = (uint64_t)per * n * (uint64_t)w1;
+                uint8_t *u = malloc(lgc_ot_u_bytes(mmax));
+                uint64_t *yv = malloc(mmax * 8);
+                lgc_ot_sender *S = 0;
+                lgc_ot_receiver *R = 0;
                 if (i_am_sender) {
                     uint8_t delta[16], seeds[128][16];
                     check(!baseot_ext_sender(self, peer + 1, delta, seeds), "base OT failed");
-                    lgc_ot_sender *S = 0;
                     LGC(lgc_ot_sender_create(&S, device, delta, seeds));
-                    for (q = 0; q < npairs; q++) column_of(Xq, yq, n, d, ri[q], vals + q * n);
-                    check(!recv_blob(self, peer + 1, u, ub), "OT: could not receive u");
-                    LGC(lgc_ot_gilboa_send(S, vals, npairs, n, w1, u, yv, shares));
-                    check(!send_blob(self, peer + 1, yv, m * 8), "OT: could not send y");
-                    lgc_ot_sender_destroy(S);
                 } else {
                     uint8_t s0[128][16], s1[128][16];
                     check(!baseot_ext_receiver(self, peer + 1, s0, s1), "base OT failed");
-                    lgc_ot_receiver *R = 0;
                     LGC(lgc_ot_receiver_create(&R, device, s0, s1));
-                    for (q = 0; q < npairs; q++) column_of(Xq, yq, n, d, rj[q], vals + q * n);
-                    LGC(lgc_ot_gilboa_recv_start(R, vals, npairs, n, w1, u));
-                    check(!send_blob(self, peer + 1, u, ub), "OT: could not send u");
-                    check(!recv_blob(self, peer + 1, yv, m * 8), "OT: could not receive y");
-                    LGC(lgc_ot_gilboa_recv_finish(R, yv, shares));
-                    lgc_ot_receiver_destroy(R);
                 }
+                for (size_t q0 = 0; q0 < npairs; q0 += per) {
+                    size_t nb = npairs - q0 < per ? npairs - q0 : per;
+                    const uint64_t m = (uint64_t)nb * n * (uint64_t)w1;
+                    size_t ub = lgc_ot_u_bytes(m);
+                    if (i_am_sender) {
+                        for (q = 0; q < nb; q++) column_of(Xq, yq, n, d, ri[q0 + q], vals + q * n);
+                        check(!recv_blob(self, peer + 1, u, ub), "OT: could not receive u");
+                        LGC(lgc_ot_gilboa_send(S, vals, nb, n, w1, u, yv, shares + q0));
+                        check(!send_blob(self, peer + 1, yv, m * 8), "OT: could not send y");
+                    } else {
+                        for (q = 0; q < nb; q++) column_of(Xq, yq, n, d, rj[q0 + q], vals + q * n);
+                        LGC(lgc_ot_gilboa_recv_start(R, vals, nb, n, w1, u));
+                        check(!send_blob(self, peer + 1, u, ub), "OT: could not send u");
+                        check(!recv_blob(self, peer + 1, yv, m * 8), "OT: could not receive y");
+                        LGC(lgc_ot_gilboa_recv_finish(R, yv, shares + q0));
+                    }
+                }
+                if (S) lgc_ot_sender_destroy(S);
+                if (R) lgc_ot_receiver_destroy(R);
                 for (q = 0; q < npairs; q++) {
                     if (ri[q] < d && rj[q] < d) share_A[idx(ri[q], rj[q])] += shares[q];
                     else share_b[ri[q] < d ? ri[q] : rj[q]] += shares[q];

@@ -1,0 +1,62 @@
+"""BASELINE.json configs 2-4 end to end through bin/linreg (all parties on this box, one GPU):
+generates the synthetic instance (experiments/generate_tests.py:159-169 distribution), runs the
+processes, checks party 2's Result line against the oracle, reports wall-clock."""
+import sys, os, re, time, socket, subprocess, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import orc
+oracle = orc.load()
+HOST = os.path.join(ROOT, "linreg-mpc_amd", "host")
+
+def free_ports(k):
+    socks = [socket.socket() for _ in range(k)]
+    for s in socks: s.bind(("127.0.0.1", 0))
+    ports = [s.getsockname()[1] for s in socks]
+    for s in socks: s.close()
+    return ports
+
+def write_instance(path, n, d, starts, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d)); X /= np.abs(X).max(axis=0)
+    beta = rng.random(d); y = X @ beta + 0.1 * rng.standard_normal(n)
+    ports = free_ports(len(starts) + 2)
+    with open(path, "w") as f:
+        f.write("%d %d %d\n" % (n, d, len(starts)))
+        f.write("127.0.0.1:%d\n127.0.0.1:%d\n" % (ports[0], ports[1]))
+        for k, st in enumerate(starts): f.write("127.0.0.1:%d %d\n" % (ports[2 + k], st))
+        f.write("%d %d\n" % (n, d))
+        for i in range(n): f.write(" ".join(repr(float(v)) for v in X[i]) + "\n")
+        f.write("%d\n" % n + " ".join(repr(float(v)) for v in y) + "\n")
+    return X, y
+
+def run(name, n, d, starts, alg, iters, lam, extra, w2=64, p1=56, p2=None, seed=0):
+    path = "/tmp/%s.in" % name
+    t0 = time.time(); X, y = write_instance(path, n, d, starts, seed); t1 = time.time()
+    exe = os.path.join(HOST, "bin", "linreg")
+    P = len(starts)
+    args = [str(p1), alg, str(iters), repr(lam)] + extra
+    t2 = time.time()
+    procs = [subprocess.Popen([exe, path, args[0], str(k)] + args[1:], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for k in range(1, P + 3)]
+    outs = [p.communicate(timeout=3000) for p in procs]
+    t3 = time.time()
+    for p, (o, e) in zip(procs, outs):
+        if p.returncode != 0: print("FAILED", e.decode()[-500:]); return
+    ev = outs[1][0].decode()
+    got = re.findall("-?[0-9]+\\.[0-9]+", ev.strip().splitlines()[-1])
+    elapsed = float(re.search("Time elapsed: ([0-9.]+)", ev).group(1))
+    gates = int(re.search("Number of gates: ([0-9]+)", ev).group(1))
+    exact = None
+    if w2 == 64:
+        inp = oracle.read_input(path)
+        beta = oracle.linreg_file(path, p1, -1, 64, 64, {"cholesky": 0, "ldlt": 1, "cgd": 2}[alg], iters, lam)
+        exact = got == ["%.15f" % (int(v) / 2.0 ** p1) for v in beta]
+    print(json.dumps(dict(config=name, n=n, d=d, P=P, alg=alg, iters=iters, opts=extra, wall_all_processes_s=round(t3 - t2, 2),
+                          evaluator_time_elapsed_s=elapsed, and_gates=gates, exact_vs_oracle=exact)), flush=True)
+
+which = sys.argv[1:] or ["c2", "c3"]
+subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+if "c2" in which: run("c2", 1000, 20, [0, 10], "cholesky", 0, 0.001, [])
+if "c3ti" in which: run("c3ti", 10000, 100, [0, 50], "cgd", 15, 0.001, [])
+if "c3" in which: run("c3", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--use_ot"])
+if "c4" in which: run("c4", 50000, 500, [0, 100, 200, 300, 400], "cgd", 20, 0.001, ["--width_phase2=32", "--prec_phase2=30"], w2=32)
