@@ -104,6 +104,7 @@ enum { MODE_MAC = 0, MODE_SOLO = 1, MODE_QUAD = 2 };
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");   // no LDS access of the next phase may be scheduled above the barrier
 }
 
 template <bool GARBLER, int MODE, class TAB = LdsTab>
