@@ -103,6 +103,10 @@ int lgc_solver_get_inputs(lgc_solver *s, int64_t *ab);
 int lgc_solver_get_stats(lgc_solver *s, lgc_stats *st);
 /* per-launch kernel times of the last profiled run (seconds; n = number of launches) */
 int lgc_solver_get_profile(lgc_solver *s, double *garble_s, double *eval_s, size_t n);
+/* cgd only, n = num_iterations: AND gates emitted and device seconds elapsed (since the start of
+ * lgc_solver_run) when iteration t's reveals were evaluated -- the values cgd.oc:190-194 prints as
+ * "Iteration t gate count" / "Iteration t time".  Either output pointer may be NULL. */
+int lgc_solver_get_iterations(lgc_solver *s, uint64_t *and_gates, double *seconds, size_t n);
 
 /* Introspection (host only, no GPU needed): the lowered program.  Used by the
  * CPU test-suite to run the very same records on the CPU checker. */
@@ -149,6 +153,9 @@ size_t lgc_party_table_bytes(const lgc_party *p, size_t launch);
 size_t lgc_party_input_bits(const lgc_party *p);      /* (T + d) * width, per share */
 size_t lgc_party_num_reveal(const lgc_party *p);
 uint64_t lgc_party_and_gates(const lgc_party *p);
+/* cgd only, n = num_iterations: the launch that completes iteration t and the AND gates emitted up
+ * to and including it (cgd.oc:190-194 prints both per iteration).  Either pointer may be NULL. */
+int lgc_party_iteration_marks(const lgc_party *p, uint32_t *launch, uint64_t *and_gates, size_t n);
 /* garbler: per input bit of share k (word-major, LSB first: sel[i*intsize+j], src/input.c:41) the
  * label pair (m0, m1), 16 bytes each -- the sender messages of dcrRecvBitArray's OT (input.c:94-108) */
 int lgc_party_input_pairs(lgc_party *p, size_t share, uint8_t *m0, uint8_t *m1);

@@ -215,6 +215,8 @@ struct lgc_solver {
     std::vector<hipEvent_t> evs;
     std::vector<uint64_t> hG, hE;
     std::vector<double> tG, tE;
+    std::vector<hipEvent_t> ev_iter;     // end of each cgd iteration on the evaluator chain
+    std::vector<double> t_iter;
     bool have_shares, ran;
     lgc_stats st;
     lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), streamE(0), ev0(0), ev1(0), slot_bytes(0), nslots(1),
@@ -232,6 +234,7 @@ extern "C" void lgc_solver_destroy(lgc_solver *s) {
     if (s->vals) (void)hipFree(s->vals);
     if (s->recs) (void)hipFree(s->recs);
     for (size_t i = 0; i < s->evs.size(); i++) (void)hipEventDestroy(s->evs[i]);
+    for (size_t i = 0; i < s->ev_iter.size(); i++) (void)hipEventDestroy(s->ev_iter[i]);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (int i = 0; i < 2; i++) { if (s->evG[i]) (void)hipEventDestroy(s->evG[i]); if (s->evE[i]) (void)hipEventDestroy(s->evE[i]); }
@@ -358,6 +361,12 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
     // garble(k + nslots) waits for evaluate(k) (table slot reuse).  With profile != 0 the two
     // chains are serialised so that per-kernel times are exclusive.
     hipStream_t sG = s->stream, sE = profile ? s->stream : s->streamE;
+    while (s->ev_iter.size() < P.iter_launch.size()) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        s->ev_iter.push_back(e);
+    }
+    size_t next_iter = 0;
     HIPCHK(hipEventRecord(s->ev0, sG));
     HIPCHK(hipMemsetAsync(s->wordsG, 0, wbytes, sG));
     HIPCHK(hipMemsetAsync(s->wordsE, 0, wbytes, sG));
@@ -393,6 +402,8 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
             launch_exec<false>(s, L, s->wordsE, s->decE, tab, sE);
             HIPCHK(hipEventRecord(s->evE[slot], sE));
         }
+        while (next_iter < P.iter_launch.size() && P.iter_launch[next_iter] == i)
+            HIPCHK(hipEventRecord(s->ev_iter[next_iter++], sE));
     }
     if (!profile) {   // join the evaluator chain back into the main stream
         hipEvent_t last = s->evE[(nl - 1) % (size_t)s->nslots];
@@ -431,6 +442,12 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
             st.mac_gates += L.gates;
             st.mac_launches++;
         }
+    }
+    s->t_iter.assign(P.iter_launch.size(), 0.0);
+    for (size_t t = 0; t < P.iter_launch.size(); t++) {
+        float e = 0;
+        HIPCHK(hipEventElapsedTime(&e, s->ev0, s->ev_iter[t]));
+        s->t_iter[t] = e * 1e-3;
     }
     s->ran = true;
     return LGC_OK;
@@ -473,6 +490,18 @@ extern "C" int lgc_solver_get_profile(lgc_solver *s, double *garble_s, double *e
     if (!s || !garble_s || !eval_s) return lgc_fail(LGC_EINVAL, "null argument");
     if (n != s->tG.size()) return lgc_fail(LGC_EINVAL, "n must equal the number of launches (%zu)", s->tG.size());
     for (size_t i = 0; i < n; i++) { garble_s[i] = s->tG[i]; eval_s[i] = s->tE[i]; }
+    return LGC_OK;
+}
+
+extern "C" int lgc_solver_get_iterations(lgc_solver *s, uint64_t *and_gates, double *seconds, size_t n) {
+    if (!s) return lgc_fail(LGC_EINVAL, "null solver");
+    if (!s->ran) return lgc_fail(LGC_ESTATE, "solver has not run");
+    if (n != s->P.iter_launch.size())
+        return lgc_fail(LGC_EINVAL, "n must equal the number of cgd iterations (%zu)", s->P.iter_launch.size());
+    for (size_t t = 0; t < n; t++) {
+        if (and_gates) and_gates[t] = s->P.iter_gates[t];
+        if (seconds) seconds[t] = s->t_iter[t];
+    }
     return LGC_OK;
 }
 

@@ -43,6 +43,10 @@ struct Program {
     uint32_t rv_ab;              // decode slot of the debug reveal of a, b (T + d), or ~0u
     uint64_t total_steps, total_gates;
     uint64_t max_launch_steps;
+    // cgd: per iteration, the last launch of the iteration and the AND gates emitted up to there
+    // (the points where cgd.oc:190-194 prints yaoGateCount() and the running time)
+    std::vector<uint32_t> iter_launch;
+    std::vector<uint64_t> iter_gates;
 
     // ---- builder state
     uint64_t cap_steps;          // split launches above this many steps
@@ -348,6 +352,8 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
                 P.emit(Program::mk(OP_REVEAL, base + D + 3, ng));
                 P.new_launch();
             }
+            P.iter_launch.push_back((uint32_t)(P.launches.size() - 1));
+            P.iter_gates.push_back(P.total_gates);
         }
         P.rv_beta = P.alloc_reveal(d);
         for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_REVEAL, P.rv_beta + (uint32_t)i, x + (uint32_t)i));

@@ -122,6 +122,16 @@ extern "C" size_t lgc_party_table_bytes(const lgc_party *p, size_t launch) {
 extern "C" size_t lgc_party_input_bits(const lgc_party *p) { return p ? (p->P.T + p->P.d) * (size_t)p->P.w : 0; }
 extern "C" size_t lgc_party_num_reveal(const lgc_party *p) { return p ? p->P.n_reveal : 0; }
 extern "C" uint64_t lgc_party_and_gates(const lgc_party *p) { return p ? p->P.total_gates : 0; }
+extern "C" int lgc_party_iteration_marks(const lgc_party *p, uint32_t *launch, uint64_t *and_gates, size_t n) {
+    if (!p) return lgc_fail(LGC_EINVAL, "null party");
+    if (n != p->P.iter_launch.size())
+        return lgc_fail(LGC_EINVAL, "n must equal the number of cgd iterations (%zu)", p->P.iter_launch.size());
+    for (size_t t = 0; t < n; t++) {
+        if (launch) launch[t] = p->P.iter_launch[t];
+        if (and_gates) and_gates[t] = p->P.iter_gates[t];
+    }
+    return LGC_OK;
+}
 
 static int export_labels(lgc_party *p, size_t share, const uint64_t *values, uint8_t *m0, uint8_t *m1) {
     if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "only the garbler owns label pairs");

@@ -146,10 +146,18 @@ int main(int argc, char **argv) {
         double t_ot = wall_clock() - time_start;
         size_t nl = lgc_party_num_launches(party_obj);
         uint8_t *tab = malloc(kTableChunk + 4096);
+        /* where cgd.oc:190-194 prints yaoGateCount() and the running time: after the launch that
+         * completes each iteration */
+        size_t n_marks = sys.algorithm == LGC_ALG_CGD ? (size_t)num_iterations : 0, next_mark = 0;
+        uint32_t *mark_launch = malloc((n_marks + 1) * sizeof *mark_launch);
+        uint64_t *mark_gates = malloc((n_marks + 1) * sizeof *mark_gates);
+        double *mark_time = malloc((n_marks + 1) * sizeof *mark_time);
+        if (n_marks) LGC(lgc_party_iteration_marks(party_obj, mark_launch, mark_gates, n_marks));
         for (size_t i = 0; i < nl; i++) {
             size_t tb = lgc_party_table_bytes(party_obj, i);
             check(!recv_blob(self, 1, tab, tb), "could not receive garbled tables");
             LGC(lgc_party_evaluate(party_obj, i, tab));
+            while (next_mark < n_marks && mark_launch[next_mark] == i) mark_time[next_mark++] = wall_clock() - time_start;
         }
         free(tab);
         size_t nr = lgc_party_num_reveal(party_obj);
@@ -170,7 +178,6 @@ int main(int argc, char **argv) {
         printf("Time taken for OT: %f\n", t_ot);
         if (sys.algorithm == LGC_ALG_CGD) {
             printf("OT time: %f\nStarting iterations.\n", t_ot);
-            long long gates = (long long)lgc_party_and_gates(party_obj);
             for (int t = 0; t < num_iterations; t++) {                /* src/cgd.oc:167-194 */
                 const int64_t *row = trace + (size_t)t * (d + 4);
                 printf("Iteration %d (x):\n", t);
@@ -179,8 +186,8 @@ int main(int argc, char **argv) {
                 printf("\nEta: %30.20f ", fixed_to_double(row[d + 1], precision));
                 printf("\nq: %30.20f ", fixed_to_double(row[d + 2], precision));
                 printf("\nng: %30.20f ", fixed_to_double(row[d + 3], precision));
-                printf("\nIteration %d gate count: %lld", t, gates * (t + 1) / (num_iterations ? num_iterations : 1));
-                printf("\nIteration %d time: %f\n", t, wall_clock() - time_start);
+                printf("\nIteration %d gate count: %llu", t, (unsigned long long)mark_gates[t]);
+                printf("\nIteration %d time: %f\n", t, mark_time[t]);
             }
         } else {
             printf("OT time: %f\n", t_ot);
@@ -190,7 +197,7 @@ int main(int argc, char **argv) {
         printf("Result: ");                                                                 /* linreg.c:184-187 */
         for (size_t i = 0; i < d; i++) printf("%20.15f ", fixed_to_double(beta[i], precision));
         printf("\n");
-        free(beta); free(ab); free(trace);
+        free(beta); free(ab); free(trace); free(mark_launch); free(mark_gates); free(mark_time);
     } else {                                                         /* data provider (linreg.c:192-198, input.c:23-50) */
         printf("party %d connecting to CSP and Evaluator\n", party);
         uint8_t s0[128][16], s1[128][16];

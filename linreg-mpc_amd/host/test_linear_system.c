@@ -123,9 +123,17 @@ int main(int argc, char **argv) {
         free(lab); free(sel); free(u); free(e);
         double t_ot = wall_clock() - t0;
         uint8_t *tab = malloc(chunk + 4096);
+        const int is_cgd = sys.algorithm == LGC_ALG_CGD;
+        size_t n_marks = is_cgd ? (size_t)num_iterations : 0, next_mark = 0;
+        uint32_t *mark_launch = malloc((n_marks + 1) * sizeof *mark_launch);
+        uint64_t *mark_gates = malloc((n_marks + 1) * sizeof *mark_gates);
+        double *mark_time = malloc((n_marks + 1) * sizeof *mark_time);
+        if (is_cgd) LGC(lgc_party_iteration_marks(po, mark_launch, mark_gates, n_marks));
+        double t_iters = wall_clock();                                          /* cgd.oc: time_start */
         for (size_t i = 0; i < lgc_party_num_launches(po); i++) {
             check(!recv_blob(self, 1, tab, lgc_party_table_bytes(po, i)), "could not receive garbled tables");
             LGC(lgc_party_evaluate(po, i, tab));
+            while (next_mark < n_marks && mark_launch[next_mark] == i) mark_time[next_mark++] = wall_clock() - t_iters;
         }
         free(tab);
         size_t nr = lgc_party_num_reveal(po);
@@ -145,8 +153,8 @@ int main(int argc, char **argv) {
                 printf("\nEta: %30.20f ", fixed_to_double(row[d + 1], precision));
                 printf("\nq: %30.20f ", fixed_to_double(row[d + 2], precision));
                 printf("\nng: %30.20f ", fixed_to_double(row[d + 3], precision));
-                printf("\nIteration %d gate count: %lld", t, gates * (t + 1) / (num_iterations ? num_iterations : 1));
-                printf("\nIteration %d time: %f\n", t, wall_clock() - t0);
+                printf("\nIteration %d gate count: %llu", t, (unsigned long long)mark_gates[t]);
+                printf("\nIteration %d time: %f\n", t, mark_time[t]);
             }
         } else {
             printf("OT time: %f\n", t_ot);
@@ -156,7 +164,7 @@ int main(int argc, char **argv) {
         printf("Result: ");
         for (size_t i = 0; i < d; i++) printf("%20.15f ", fixed_to_double(beta[i], precision));
         printf("\n");
-        free(beta); free(trace);
+        free(beta); free(trace); free(mark_launch); free(mark_gates); free(mark_time);
     }
     lgc_party_destroy(po);
     node_destroy(&self);

@@ -74,7 +74,8 @@ def lib():
             ("lgc_solver_set_shares", [vp, vp]), ("lgc_solver_run", [vp, ci]),
             ("lgc_solver_get_beta", [vp, vp]), ("lgc_solver_get_trace", [vp, vp]),
             ("lgc_solver_get_inputs", [vp, vp]), ("lgc_solver_get_stats", [vp, C.POINTER(Stats)]),
-            ("lgc_solver_get_profile", [vp, vp, vp, sz]),
+            ("lgc_solver_get_profile", [vp, vp, vp, sz]), ("lgc_solver_get_iterations", [vp, vp, vp, sz]),
+            ("lgc_party_iteration_marks", [vp, vp, vp, sz]),
             ("lgc_program_build", [C.POINTER(vp), C.POINTER(System)]),
             ("lgc_program_info_get", [vp, C.POINTER(ProgramInfo)]),
             ("lgc_aes_bench", [ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
@@ -204,6 +205,14 @@ class Solver:
         g = np.zeros(nlaunches); e = np.zeros(nlaunches)
         _chk(lib().lgc_solver_get_profile(self._h, g.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p), nlaunches))
         return g, e
+
+    def iterations(self):
+        """cgd: (cumulative AND gates, device seconds since the start of run) per iteration -- the
+        values src/cgd.oc:190-194 prints as 'Iteration t gate count' / 'Iteration t time'."""
+        n = int(self.system.num_iterations) if int(self.system.algorithm) == ALG["cgd"] else 0
+        g = np.zeros(n, dtype=np.uint64); t = np.zeros(n)
+        _chk(lib().lgc_solver_get_iterations(self._h, g.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), n))
+        return g, t
 
     def close(self):
         if self._h:

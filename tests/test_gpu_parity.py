@@ -69,6 +69,11 @@ def test_gpu_readme_known_answer(lgc, golden_dir):
     assert got.tolist() == kat["beta_cgd"]
     assert ["%.15f" % (int(v) / 2.0 ** 56) for v in got] == kat["printed"]
     assert s.trace().tolist() == kat["trace"]
+    # per-iteration marks (cgd.oc:190-194): equal gate increments, increasing device time
+    g, t = s.iterations()
+    total = s.stats()["and_gates"]
+    assert len(g) == 10 and len(set(np.diff(g.astype(np.int64)).tolist())) == 1 and int(g[-1]) <= total
+    assert np.all(np.diff(t) > 0) and t[-1] <= s.stats()["seconds_total"] + 1e-6
 
 
 def test_gpu_matches_cpu_mirror_labels(lgc, gccpu, oracle):

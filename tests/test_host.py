@@ -185,6 +185,25 @@ def test_test_linear_system_binary(tmp_path, oracle, alg, w, p):
     assert "Number of gates:" in ev and "Time elapsed:" in ev and "Algorithm: %s" % alg in ev
     if alg != "ldlt":                                 # sanity: close to the floating-point solution
         assert np.allclose([float(x) for x in got], sol, atol=1e-3 if alg == "cgd" else 1e-6)
+    # the experiment driver's view of the same stdout (experiments/test_phase2_aws.py:70-186)
+    import results
+    run = results.parse_exec(ev, alg)
+    assert run["gate_count"] > 0 and run["time"] > 0 and len(run["result"]) == d
+    if alg == "cgd":
+        g, t = run["iter_gates"], run["iter_times"]
+        assert len(g) == len(t) == len(run["iter_solutions"]) == iters
+        assert all(b > a for a, b in zip(g, g[1:])) and g[-1] <= run["gate_count"]
+        assert len(set(np.diff(g))) == 1              # every iteration is the same circuit
+        assert all(b >= a for a, b in zip(t, t[1:])) and t[-1] <= run["time"]
+        assert run["iter_solutions"][-1] == run["result"]
+    out = str(tmp_path / "ls.out")
+    err = results.write_phase2_out(out, 40, d, alg, run, sol, condition_number=float(np.linalg.cond(A)))
+    rows = open(out).read().split("\n")
+    assert rows[0] == "n d algorithm ot_time time error gate_count"
+    assert rows[1].split()[:3] == ["40", str(d), alg] and abs(float(rows[1].split()[5]) - err) < 1e-12
+    if alg == "cgd":
+        assert rows[2] == "iter_i error_i obj_i time_i gate_count_i" and len(rows) == 3 + iters + 10
+        assert int(rows[2 + iters].split()[4]) == run["gate_count"]
 
 
 def test_config_parser_and_owner_map(hostlib, golden_dir):

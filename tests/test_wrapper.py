@@ -7,6 +7,8 @@ import socket
 import tempfile
 import threading
 
+import numpy as np
+
 import pytest
 
 import mpc_linear_regression as mlr
@@ -74,3 +76,40 @@ def test_msgpack_peer_link_roundtrip():
     t.join(timeout=10)
     assert got["srv"] == {"length": 3, "variances": [0.25, 2.0]}
     assert got["cli"] == {"is_last": True, "arith_means": [1.5], "owned_columns": [[0, 3, "x"]]}
+
+
+def test_result_file_layout(tmp_path):
+    """.out layout of experiments/test_phase2_aws.py:143-186 from a party-2 stdout transcript"""
+    import results
+    text = "\n".join([
+        "", "Algorithm: cgd", "OT time: 0.250000", "Starting iterations.",
+        "Iteration 0 (x):", "   0.500000000000000    0.250000000000000 ",
+        "Gamma:       0.10000000000000000000 ", "Eta:       0.20000000000000000000 ",
+        "q:       0.30000000000000000000 ", "ng:       0.40000000000000000000 ",
+        "Iteration 0 gate count: 1000", "Iteration 0 time: 0.100000",
+        "Iteration 1 (x):", "   1.000000000000000   -2.000000000000000 ",
+        "Gamma:       0.10000000000000000000 ", "Eta:       0.20000000000000000000 ",
+        "q:       0.30000000000000000000 ", "ng:       0.40000000000000000000 ",
+        "Iteration 1 gate count: 1900", "Iteration 1 time: 0.200000",
+        "Time elapsed: 0.450000", "Number of gates: 2000",
+        "Result:    1.000000000000000   -2.000000000000000 ", ""])
+    run = results.parse_exec(text, "cgd")
+    assert run["iter_solutions"] == [[0.5, 0.25], [1.0, -2.0]] and run["iter_gates"] == [1000, 1900]
+    assert run["iter_times"] == [0.1, 0.2] and run["gate_count"] == 2000 and run["ot_time"] == 0.25
+    X = np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]]); y = np.array([1.0, -2.0, -1.0])
+    path = str(tmp_path / "t.out")
+    err = results.write_phase2_out(path, 3, 2, "cgd", run, [1.0, -2.0], X=X, y=y, lam=0.5, condition_number=3.0)
+    rows = open(path).read().split("\n")
+    assert err == 0.0
+    assert rows[0] == "n d algorithm ot_time time error gate_count"
+    assert rows[1] == "3 2 cgd 0.25 0.45 0.0 2000"
+    assert rows[2] == "iter_i error_i obj_i time_i gate_count_i"
+    assert rows[3].split()[0] == "1" and rows[3].split()[4] == "1100" and rows[4].split()[4] == "2000"
+    assert float(rows[4].split()[1]) == 0.0 and abs(float(rows[4].split()[2]) - 2.5) < 1e-12
+    assert rows[5:] == ["solution:", "2", "1.0 -2.0", "Objective function on solution:", "2.5",
+                        "result:", "2", "1.0 -2.0", "Condition number:", "3.0"]
+    results.write_phase1_out(str(tmp_path / "p.out"), 10, 5, 3, 4, 1.5, 0.25, 2.0, sent=[0, 10], flushes=[0, 2])
+    rows = open(str(tmp_path / "p.out")).read().splitlines()
+    assert rows[0] == '{"n":"10", "d":"5", "p":"3"}'
+    assert rows[1] == '{"party":"4", "cputime":"1.500000", "wait_time":0.250000, "realtime":"2.000000"}'
+    assert rows[2:] == ["[0, 10]", "[0, 2]"]
