@@ -161,6 +161,20 @@ int lgc_party_iteration_marks(const lgc_party *p, uint32_t *launch, uint64_t *an
 int lgc_party_input_pairs(lgc_party *p, size_t share, uint8_t *m0, uint8_t *m1);
 /* garbler: labels of values it knows itself (feedOblivLLong for its own party, linear.oc:116-127) */
 int lgc_party_encode_inputs(lgc_party *p, size_t share, const uint64_t *values, uint8_t *labels_out);
+
+/* Device-resident table hand-off for a garbler and an evaluator PROCESS on the same node (same
+ * MI355X, or two GPUs of one xGMI hive): instead of the osend/orecv byte stream that carries
+ * the garbled tables in the reference (Obliv-C Yao runtime under execYaoProtocol, linreg.c:177)
+ * the garbler allocates a ring of `nslots` table slots in its HBM, exports it as a 64-byte
+ * hipIpc handle (sent over the existing socket), and the evaluator maps it.  Launch k lives in
+ * slot k % nslots.  The host keeps the ordering: the garbler may call lgc_party_garble_ring(k)
+ * only after the evaluator has finished launch k - nslots; the evaluator may call
+ * lgc_party_evaluate_ring(k) only after lgc_party_garble_ring(k) has returned.  Both calls block
+ * until their kernel has completed. */
+int lgc_party_ring_create(lgc_party *p, int nslots, uint8_t handle_out[64], size_t *slot_bytes);
+int lgc_party_ring_open(lgc_party *p, const uint8_t handle[64], int nslots, size_t slot_bytes);
+int lgc_party_garble_ring(lgc_party *p, size_t launch);
+int lgc_party_evaluate_ring(lgc_party *p, size_t launch);
 /* evaluator: the labels a data provider forwarded (dcsSendIntArray -> orecv, input.c:46, 84-92) */
 int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint8_t *labels);
 int lgc_party_garble(lgc_party *p, size_t launch, uint8_t *tables_out);

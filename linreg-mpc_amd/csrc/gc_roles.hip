@@ -35,6 +35,12 @@ struct lgc_party {
     Rec *recs;
     bool labels_ready;
     std::vector<uint64_t> hdec;
+    // device-resident table ring shared between a garbler and an evaluator process on one node
+    // (hipIpc: same GPU, or a peer GPU over xGMI): slot k % ring_slots holds launch k's tables
+    Lbl *ring;
+    int ring_slots;
+    size_t ring_slot_bytes;
+    bool ring_imported;
 };
 
 // (m0, m1) = (zero label, zero label ^ R) per input bit of one share: yaoKeyNewPair (input.c:94-101)
@@ -67,6 +73,7 @@ extern "C" void lgc_party_destroy(lgc_party *p) {
     if (p->tab) (void)hipFree(p->tab);
     if (p->dec) (void)hipFree(p->dec);
     if (p->recs) (void)hipFree(p->recs);
+    if (p->ring) { if (p->ring_imported) (void)hipIpcCloseMemHandle(p->ring); else (void)hipFree(p->ring); }
     delete p;
 }
 
@@ -84,6 +91,7 @@ extern "C" int lgc_party_create(lgc_party **out, int device, const lgc_system *s
     lgc_party *p = new lgc_party();
     p->sys = *sys; p->device = device; p->role = role;
     p->words = 0; p->tab = 0; p->dec = 0; p->recs = 0; p->labels_ready = false;
+    p->ring = 0; p->ring_slots = 0; p->ring_slot_bytes = 0; p->ring_imported = false;
     if (!max_launch_table_bytes) max_launch_table_bytes = (size_t)256 << 20;
     build(p->P, sys, max_launch_table_bytes / 2048 ? max_launch_table_bytes / 2048 : 1);
     memset(&p->R, 0, sizeof(Lbl)); memset(&p->seed, 0, sizeof(Lbl));
@@ -177,18 +185,19 @@ extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint
 }
 
 template <bool G>
-static void party_launch(lgc_party *p, const Launch &L) {
+static void party_launch(lgc_party *p, const Launch &L, Lbl *tab = 0) {
+    if (!tab) tab = p->tab;
     if (L.mac_only && L.nrec >= kNarrowMac) {
         constexpr int TPB = G ? kTpbMacG : kTpbMacE;
         const unsigned per = TPB / 64;
         hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(TPB), 0, 0, p->recs + L.first_rec, L.nrec,
-                           p->words, p->tab, L.step0, p->R, p->P.w, p->P.p);
+                           p->words, tab, L.step0, p->R, p->P.w, p->P.p);
     } else if (L.nrec >= kWideLaunch) {
         hipLaunchKernelGGL((gc_exec_kernel<G, false>), dim3((L.nrec + 3) / 4), dim3(256), 0, 0, p->recs + L.first_rec, L.nrec,
-                           p->words, p->tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
+                           p->words, tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
     } else {
         hipLaunchKernelGGL((gc_exec_kernel<G, true>), dim3(L.nrec), dim3(256), 0, 0, p->recs + L.first_rec, L.nrec, p->words,
-                           p->tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
+                           tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
     }
 }
 
@@ -216,6 +225,70 @@ extern "C" int lgc_party_evaluate(lgc_party *p, size_t launch, const uint8_t *ta
     RCHK(hipDeviceSynchronize());
     return LGC_OK;
 }
+// ---- table ring (device-resident hand-off; replaces the osend/orecv byte stream of the Yao
+// protocol when both roles run on one node)
+extern "C" int lgc_party_ring_create(lgc_party *p, int nslots, uint8_t handle_out[64], size_t *slot_bytes) {
+    if (!p || !handle_out || !slot_bytes) return lgc_fail(LGC_EINVAL, "null argument");
+    if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "the garbler owns the table ring");
+    if (nslots < 1 || nslots > 64) return lgc_fail(LGC_EINVAL, "nslots must be in 1..64");
+    if (p->ring) return lgc_fail(LGC_ESTATE, "the ring already exists");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    RCHK(hipSetDevice(p->device));
+    size_t sb = ((size_t)p->P.max_launch_steps * 2048 + 4095) & ~(size_t)4095;
+    if (!sb) sb = 4096;
+    hipError_t e = hipMalloc(&p->ring, sb * (size_t)nslots);
+    if (e != hipSuccess) return lgc_fail(LGC_ENOMEM, "hipMalloc(table ring, %zu bytes): %s", sb * (size_t)nslots, hipGetErrorString(e));
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, p->ring);
+    if (e != hipSuccess) {
+        (void)hipFree(p->ring); p->ring = 0;
+        return lgc_fail(LGC_EHIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
+    }
+    memcpy(handle_out, &h, 64);
+    p->ring_slots = nslots; p->ring_slot_bytes = sb; p->ring_imported = false;
+    *slot_bytes = sb;
+    return LGC_OK;
+}
+extern "C" int lgc_party_ring_open(lgc_party *p, const uint8_t handle[64], int nslots, size_t slot_bytes) {
+    if (!p || !handle) return lgc_fail(LGC_EINVAL, "null argument");
+    if (p->role != LGC_ROLE_EVALUATOR) return lgc_fail(LGC_ESTATE, "the evaluator opens the garbler's ring");
+    if (nslots < 1 || nslots > 64) return lgc_fail(LGC_EINVAL, "nslots must be in 1..64");
+    if (slot_bytes < (size_t)p->P.max_launch_steps * 2048) return lgc_fail(LGC_EINVAL, "ring slots are smaller than the largest launch");
+    if (p->ring) return lgc_fail(LGC_ESTATE, "the ring is already open");
+    RCHK(hipSetDevice(p->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    void *ptr = 0;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return lgc_fail(LGC_EHIP, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+    p->ring = (Lbl *)ptr; p->ring_slots = nslots; p->ring_slot_bytes = slot_bytes; p->ring_imported = true;
+    return LGC_OK;
+}
+static Lbl *ring_slot(lgc_party *p, size_t launch) {
+    return (Lbl *)((char *)p->ring + (launch % (size_t)p->ring_slots) * p->ring_slot_bytes);
+}
+extern "C" int lgc_party_garble_ring(lgc_party *p, size_t launch) {
+    if (!p) return lgc_fail(LGC_EINVAL, "null party");
+    if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "not the garbler");
+    if (!p->ring) return lgc_fail(LGC_ESTATE, "lgc_party_ring_create has not been called");
+    if (launch >= p->P.launches.size()) return lgc_fail(LGC_EINVAL, "launch out of range");
+    RCHK(hipSetDevice(p->device));
+    party_launch<true>(p, p->P.launches[launch], ring_slot(p, launch));
+    RCHK(hipDeviceSynchronize());      // kernel end = release: the tables are visible to the peer process
+    return LGC_OK;
+}
+extern "C" int lgc_party_evaluate_ring(lgc_party *p, size_t launch) {
+    if (!p) return lgc_fail(LGC_EINVAL, "null party");
+    if (p->role != LGC_ROLE_EVALUATOR) return lgc_fail(LGC_ESTATE, "not the evaluator");
+    if (!p->ring) return lgc_fail(LGC_ESTATE, "lgc_party_ring_open has not been called");
+    if (!p->labels_ready) return lgc_fail(LGC_ESTATE, "input labels have not been set");
+    if (launch >= p->P.launches.size()) return lgc_fail(LGC_EINVAL, "launch out of range");
+    RCHK(hipSetDevice(p->device));
+    party_launch<false>(p, p->P.launches[launch], ring_slot(p, launch));
+    RCHK(hipDeviceSynchronize());
+    return LGC_OK;
+}
+
 extern "C" int lgc_party_decode_bits(lgc_party *p, uint64_t *dec_out) {
     if (!p || !dec_out) return lgc_fail(LGC_EINVAL, "null argument");
     RCHK(hipSetDevice(p->device));

@@ -21,6 +21,12 @@
 #include "protocol.h"
 
 /* ------------------------------------------------------------------------------ main */
+typedef struct { size_t n, next; const uint32_t *launch; double *time; double t0; } iter_marks;
+static void note_launch(size_t i, void *ctx) {
+    iter_marks *m = ctx;
+    while (m->next < m->n && m->launch[m->next] == i) m->time[m->next++] = wall_clock() - m->t0;
+}
+
 int main(int argc, char **argv) {
     uint64_t *share_A = NULL, *share_b = NULL;
     config *c = NULL;
@@ -31,7 +37,8 @@ int main(int argc, char **argv) {
     check(argc > 6, "Usage: %s [Input_file] [Precision] [Party] [Algorithm] [Num. iterations CGD] [Lambda] [Options]\n"
           "Options: --use_ot: Enables the OT-based phase 1 protocol\n"
           "         --prec_phase2=<Precision phase 2>: Use different precision for phase 2 of the protocol\n"
-          "         --width_phase1=<32|64>, --width_phase2=<32|64>: bit widths (default 64)", argv[0]);
+          "         --width_phase1=<32|64>, --width_phase2=<32|64>: bit widths (default 64)\n"
+          "         --table_ring[=slots]: parties 1 and 2 share one node; garbled tables stay in HBM", argv[0]);
     char *end;
     errno = 0;
     int precision = (int)strtol(argv[2], &end, 10);
@@ -47,9 +54,11 @@ int main(int argc, char **argv) {
     check(!errno, "strtod: %s", strerror(errno));
     check(!*end, "lambda must be a number");
 
-    int use_ot = 0, precision_phase2 = -1, w1 = 64, w2 = 64;
+    int use_ot = 0, precision_phase2 = -1, w1 = 64, w2 = 64, ring_slots = 0;
     for (int i = 7; i < argc; i++) {
         if (!strcmp(argv[i], "--use_ot")) use_ot = 1;
+        else if (!strcmp(argv[i], "--table_ring")) ring_slots = 2;
+        else if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) {}
         else if (sscanf(argv[i], "--width_phase1=%i", &w1) == 1) {}
         else if (sscanf(argv[i], "--width_phase2=%i", &w2) == 1) {}
         else if (sscanf(argv[i], "--prec_phase2=%i", &precision_phase2) != 1) precision_phase2 = -1;
@@ -97,7 +106,9 @@ int main(int argc, char **argv) {
     sys.algorithm = !strcmp(algorithm, "cholesky") ? LGC_ALG_CHOLESKY : (!strcmp(algorithm, "ldlt") ? LGC_ALG_LDLT : LGC_ALG_CGD);
     sys.num_iterations = num_iterations; sys.lambda = lambda; sys.nshares = (size_t)P;
     sys.normalize = 1; sys.reveal_inputs = 1; sys.trace = 1;
-    const size_t kTableChunk = (size_t)64 << 20;
+    /* table bytes per launch: socket mode moves them through host buffers; ring mode keeps them
+     * in HBM (CSP and Evaluator on one node), so launches can be as large as the fused solver's */
+    const size_t kTableChunk = ring_slots > 0 ? (size_t)2 << 30 : (size_t)64 << 20;
 
     if (party == 1) {                                                /* CSP: garbler */
         uint8_t seed[16];
@@ -117,14 +128,7 @@ int main(int argc, char **argv) {
             lgc_ot_sender_destroy(S);
         }
         free(m0); free(m1); free(u); free(e);
-        size_t nl = lgc_party_num_launches(party_obj);
-        uint8_t *tab = malloc(kTableChunk + 4096);
-        for (size_t i = 0; i < nl; i++) {
-            size_t tb = lgc_party_table_bytes(party_obj, i);
-            LGC(lgc_party_garble(party_obj, i, tab));
-            check(!send_blob(self, 2, tab, tb), "could not send garbled tables");
-        }
-        free(tab);
+        check(!tables_send(self, 2, party_obj, ring_slots, kTableChunk), "could not stream the garbled tables");
         size_t nr = lgc_party_num_reveal(party_obj);
         uint64_t *dec = malloc((nr + 1) * 8);
         LGC(lgc_party_decode_bits(party_obj, dec));
@@ -144,22 +148,15 @@ int main(int argc, char **argv) {
         }
         free(labels);
         double t_ot = wall_clock() - time_start;
-        size_t nl = lgc_party_num_launches(party_obj);
-        uint8_t *tab = malloc(kTableChunk + 4096);
         /* where cgd.oc:190-194 prints yaoGateCount() and the running time: after the launch that
          * completes each iteration */
-        size_t n_marks = sys.algorithm == LGC_ALG_CGD ? (size_t)num_iterations : 0, next_mark = 0;
+        size_t n_marks = sys.algorithm == LGC_ALG_CGD ? (size_t)num_iterations : 0;
         uint32_t *mark_launch = malloc((n_marks + 1) * sizeof *mark_launch);
         uint64_t *mark_gates = malloc((n_marks + 1) * sizeof *mark_gates);
         double *mark_time = malloc((n_marks + 1) * sizeof *mark_time);
         if (n_marks) LGC(lgc_party_iteration_marks(party_obj, mark_launch, mark_gates, n_marks));
-        for (size_t i = 0; i < nl; i++) {
-            size_t tb = lgc_party_table_bytes(party_obj, i);
-            check(!recv_blob(self, 1, tab, tb), "could not receive garbled tables");
-            LGC(lgc_party_evaluate(party_obj, i, tab));
-            while (next_mark < n_marks && mark_launch[next_mark] == i) mark_time[next_mark++] = wall_clock() - time_start;
-        }
-        free(tab);
+        iter_marks marks = {n_marks, 0, mark_launch, mark_time, time_start};
+        check(!tables_recv(self, 1, party_obj, ring_slots, kTableChunk, note_launch, &marks), "could not receive garbled tables");
         size_t nr = lgc_party_num_reveal(party_obj);
         uint64_t *dec = malloc((nr + 1) * 8);
         check(!recv_blob(self, 1, dec, nr * 8), "could not receive decode bits");

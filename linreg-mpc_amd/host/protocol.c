@@ -67,6 +67,65 @@ int recv_blob(node *self, int from, void *buf, uint64_t len) {
     return len ? net_recv(self, from, buf, len) : 0;
 }
 
+/* ---------------------------------------------------------------- phase 2: table stream */
+#define TCHK(x) do { if ((x) != 0) { fprintf(stderr, "%s: %s\n", #x, lgc_last_error()); return 1; } } while (0)
+typedef struct { uint8_t handle[64]; uint64_t nslots, slot_bytes; } ring_hello;
+
+int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk) {
+    const size_t nl = lgc_party_num_launches(po);
+    if (ring_slots > 0) {
+        ring_hello h;
+        size_t sb = 0;
+        memset(&h, 0, sizeof h);
+        TCHK(lgc_party_ring_create(po, ring_slots, h.handle, &sb));
+        h.nslots = (uint64_t)ring_slots; h.slot_bytes = sb;
+        if (send_blob(self, peer, &h, sizeof h)) return 1;
+        uint8_t tok = 0;
+        for (size_t i = 0; i < nl; i++) {
+            if (i >= (size_t)ring_slots && recv_blob(self, peer, &tok, 1)) return 1;   /* slot is free again */
+            TCHK(lgc_party_garble_ring(po, i));
+            tok = 1;
+            if (send_blob(self, peer, &tok, 1)) return 1;
+        }
+        return 0;
+    }
+    uint8_t *tab = malloc(chunk + 4096);
+    if (!tab) return 1;
+    for (size_t i = 0; i < nl; i++) {
+        if (lgc_party_garble(po, i, tab) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); free(tab); return 1; }
+        if (send_blob(self, peer, tab, lgc_party_table_bytes(po, i))) { free(tab); return 1; }
+    }
+    free(tab);
+    return 0;
+}
+
+int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk,
+                void (*after_launch)(size_t launch, void *ctx), void *ctx) {
+    const size_t nl = lgc_party_num_launches(po);
+    if (ring_slots > 0) {
+        ring_hello h;
+        if (recv_blob(self, peer, &h, sizeof h)) return 1;
+        TCHK(lgc_party_ring_open(po, h.handle, (int)h.nslots, (size_t)h.slot_bytes));
+        uint8_t tok = 0;
+        for (size_t i = 0; i < nl; i++) {
+            if (recv_blob(self, peer, &tok, 1)) return 1;                               /* launch i is in its slot */
+            TCHK(lgc_party_evaluate_ring(po, i));
+            if (after_launch) after_launch(i, ctx);
+            if (i + (size_t)h.nslots < nl && send_blob(self, peer, &tok, 1)) return 1;
+        }
+        return 0;
+    }
+    uint8_t *tab = malloc(chunk + 4096);
+    if (!tab) return 1;
+    for (size_t i = 0; i < nl; i++) {
+        if (recv_blob(self, peer, tab, lgc_party_table_bytes(po, i))) { free(tab); return 1; }
+        if (lgc_party_evaluate(po, i, tab) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); free(tab); return 1; }
+        if (after_launch) after_launch(i, ctx);
+    }
+    free(tab);
+    return 0;
+}
+
 /* ---------------------------------------------------------------- phase 1: trusted initializer */
 int run_trusted_initializer(node *self, config *c, int w1, int device) {
     uint8_t seed[16];

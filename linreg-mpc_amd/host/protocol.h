@@ -25,6 +25,15 @@ int send_pmsg(node *self, int to, const uint64_t *vec, size_t n, uint64_t value)
 int recv_pmsg(node *self, int from, uint64_t **vec, size_t *n, uint64_t *value);
 int send_blob(node *self, int to, const void *buf, uint64_t len);
 int recv_blob(node *self, int from, void *buf, uint64_t len);
+
+/* The garbled-table stream of phase 2 (garbler -> evaluator; the reference's Yao runtime does this
+ * with osend/orecv inside execYaoProtocol, linreg.c:177).  ring_slots == 0: the table bytes of each
+ * launch travel over the socket.  ring_slots > 0: both processes are on one node; the tables stay
+ * in a device-resident ring shared through hipIpc and only one-byte ready/ack tokens travel.
+ * after_launch (may be NULL) is called once launch i has been evaluated. */
+int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk);
+int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk,
+                void (*after_launch)(size_t launch, void *ctx), void *ctx);
 int run_trusted_initializer(node *self, config *c, int w1, int device);
 int run_party(node *self, config *c, int precision, int precision_p2, int w1, int w2, int use_ot, int device,
               uint64_t **res_A, uint64_t **res_b);

@@ -4,7 +4,8 @@
  * Both parties read the same clear system (A, b); the "shares" are fabricated with the constant
  * masks 123456 / 0xDEADBEEF (:34-44); party 1 (server, garbler) holds the masks, party 2
  * (evaluator) the masked values; the circuit adds them (src/linear.oc:96-135).  Party 2 prints the
- * lines experiments/test_phase2_aws.py parses.  Options: --width=<32|64>, --host=<server>. */
+ * lines experiments/test_phase2_aws.py parses.  Options: --width=<32|64>, --host=<server>,
+ * --table_ring[=slots] (both parties on one node: garbled tables stay in HBM, shared by hipIpc). */
 #define _GNU_SOURCE
 #include <errno.h>
 #include <openssl/rand.h>
@@ -14,6 +15,12 @@
 
 #include "baseot.h"
 #include "protocol.h"
+
+typedef struct { size_t n, next; const uint32_t *launch; double *time; double t0; } iter_marks;
+static void note_launch(size_t i, void *ctx) {
+    iter_marks *m = ctx;
+    while (m->next < m->n && m->launch[m->next] == i) m->time[m->next++] = wall_clock() - m->t0;
+}
 
 int main(int argc, char **argv) {
     node *self = NULL;
@@ -28,10 +35,12 @@ int main(int argc, char **argv) {
     check(!errno && !*end, "Precision must be a number");
     int party = !strcmp(argv[2], "1") ? 1 : (!strcmp(argv[2], "2") ? 2 : 0);
     check(party > 0, "Party must be either 1 or 2.");
-    int w = 64;
+    int w = 64, ring_slots = 0;
     const char *host = "localhost";
     for (int i = 7; i < argc; i++) {
         if (sscanf(argv[i], "--width=%i", &w) == 1) continue;
+        if (!strcmp(argv[i], "--table_ring")) { ring_slots = 2; continue; }
+        if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) continue;
         if (!strncmp(argv[i], "--host=", 7)) host = argv[i] + 7;
     }
     int num_iterations = !strcmp(algorithm, "cgd") ? atoi(argv[5]) : 0;
@@ -71,7 +80,7 @@ int main(int argc, char **argv) {
     sys.d = d; sys.width = w; sys.precision = precision;
     sys.algorithm = !strcmp(algorithm, "cholesky") ? LGC_ALG_CHOLESKY : (!strcmp(algorithm, "ldlt") ? LGC_ALG_LDLT : LGC_ALG_CGD);
     sys.num_iterations = num_iterations; sys.nshares = 2; sys.normalize = 0; sys.trace = 1;
-    const size_t chunk = (size_t)64 << 20;
+    const size_t chunk = ring_slots > 0 ? (size_t)2 << 30 : (size_t)64 << 20;
     if (party == 1) {
         uint8_t seed[16];
         RAND_bytes(seed, sizeof seed);
@@ -90,12 +99,7 @@ int main(int argc, char **argv) {
         check(!send_blob(self, 2, e, bits * 32), "OT: could not send");
         lgc_ot_sender_destroy(S);
         free(lab); free(m0); free(m1); free(u); free(e);
-        uint8_t *tab = malloc(chunk + 4096);
-        for (size_t i = 0; i < lgc_party_num_launches(po); i++) {
-            LGC(lgc_party_garble(po, i, tab));
-            check(!send_blob(self, 2, tab, lgc_party_table_bytes(po, i)), "could not send garbled tables");
-        }
-        free(tab);
+        check(!tables_send(self, 2, po, ring_slots, chunk), "could not stream the garbled tables");
         size_t nr = lgc_party_num_reveal(po);
         uint64_t *dec = malloc((nr + 1) * 8);
         LGC(lgc_party_decode_bits(po, dec));
@@ -122,20 +126,15 @@ int main(int argc, char **argv) {
         lgc_ot_receiver_destroy(R);
         free(lab); free(sel); free(u); free(e);
         double t_ot = wall_clock() - t0;
-        uint8_t *tab = malloc(chunk + 4096);
         const int is_cgd = sys.algorithm == LGC_ALG_CGD;
-        size_t n_marks = is_cgd ? (size_t)num_iterations : 0, next_mark = 0;
+        size_t n_marks = is_cgd ? (size_t)num_iterations : 0;
         uint32_t *mark_launch = malloc((n_marks + 1) * sizeof *mark_launch);
         uint64_t *mark_gates = malloc((n_marks + 1) * sizeof *mark_gates);
         double *mark_time = malloc((n_marks + 1) * sizeof *mark_time);
         if (is_cgd) LGC(lgc_party_iteration_marks(po, mark_launch, mark_gates, n_marks));
         double t_iters = wall_clock();                                          /* cgd.oc: time_start */
-        for (size_t i = 0; i < lgc_party_num_launches(po); i++) {
-            check(!recv_blob(self, 1, tab, lgc_party_table_bytes(po, i)), "could not receive garbled tables");
-            LGC(lgc_party_evaluate(po, i, tab));
-            while (next_mark < n_marks && mark_launch[next_mark] == i) mark_time[next_mark++] = wall_clock() - t_iters;
-        }
-        free(tab);
+        iter_marks marks = {n_marks, 0, mark_launch, mark_time, t_iters};
+        check(!tables_recv(self, 1, po, ring_slots, chunk, note_launch, &marks), "could not receive garbled tables");
         size_t nr = lgc_party_num_reveal(po);
         uint64_t *dec = malloc((nr + 1) * 8);
         check(!recv_blob(self, 1, dec, nr * 8), "could not receive decode bits");

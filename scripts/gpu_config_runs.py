@@ -43,6 +43,11 @@ def run(name, n, d, starts, alg, iters, lam, extra, w2=64, p1=56, p2=None, seed=
     for p, (o, e) in zip(procs, outs):
         if p.returncode != 0: print("FAILED", e.decode()[-500:]); return
     ev = outs[1][0].decode()
+    if os.environ.get("CONFIG_RUNS_DUMP"):
+        os.makedirs(os.environ["CONFIG_RUNS_DUMP"], exist_ok=True)
+        for k, (o, e) in enumerate(outs):
+            keep = [l for l in o.decode().splitlines() if len(l) < 300 and re.search("time|Time|finished|OT|party", l)]
+            open(os.path.join(os.environ["CONFIG_RUNS_DUMP"], "%s_party%d.txt" % (name, k + 1)), "w").write("\n".join(keep[-60:]) + "\n--- stderr\n" + e.decode()[-3000:])
     got = re.findall("-?[0-9]+\\.[0-9]+", ev.strip().splitlines()[-1])
     elapsed = float(re.search("Time elapsed: ([0-9.]+)", ev).group(1))
     gates = int(re.search("Number of gates: ([0-9]+)", ev).group(1))
@@ -51,8 +56,17 @@ def run(name, n, d, starts, alg, iters, lam, extra, w2=64, p1=56, p2=None, seed=
         inp = oracle.read_input(path)
         beta = oracle.linreg_file(path, p1, -1, 64, 64, {"cholesky": 0, "ldlt": 1, "cgd": 2}[alg], iters, lam)
         exact = got == ["%.15f" % (int(v) / 2.0 ** p1) for v in beta]
+    # distance to the double-precision ridge solution of the same (normalised) system
+    import numpy as np
+    A = X.T @ X / (n * d); A[np.diag_indices(d)] += lam
+    ref = np.linalg.solve(A, X.T @ y / (n * d))
+    err = float(np.max(np.abs(np.array([float(v) for v in got]) - ref)))
+    ot = re.search("Time taken for OT: ([0-9.]+)", ev)
+    its = [float(v) for v in re.findall("Iteration [0-9]+ time: ([0-9.]+)", ev)]
     print(json.dumps(dict(config=name, n=n, d=d, P=P, alg=alg, iters=iters, opts=extra, wall_all_processes_s=round(t3 - t2, 2),
-                          evaluator_time_elapsed_s=elapsed, and_gates=gates, exact_vs_oracle=exact)), flush=True)
+                          evaluator_time_elapsed_s=elapsed, evaluator_inputs_received_s=float(ot.group(1)) if ot else None,
+                          last_iteration_s=its[-1] if its else None, input_file_write_s=round(t1 - t0, 1),
+                          and_gates=gates, exact_vs_oracle=exact, max_abs_err_vs_float_solve=err)), flush=True)
 
 which = sys.argv[1:] or ["c2", "c3"]
 subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
@@ -60,3 +74,11 @@ if "c2" in which: run("c2", 1000, 20, [0, 10], "cholesky", 0, 0.001, [])
 if "c3ti" in which: run("c3ti", 10000, 100, [0, 50], "cgd", 15, 0.001, [])
 if "c3" in which: run("c3", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--use_ot"])
 if "c4" in which: run("c4", 50000, 500, [0, 100, 200, 300, 400], "cgd", 20, 0.001, ["--width_phase2=32", "--prec_phase2=30"], w2=32)
+# --table_ring: CSP and Evaluator processes share the garbled tables in HBM (hipIpc) instead of the socket
+if "c2r" in which: run("c2-ring", 1000, 20, [0, 10], "cholesky", 0, 0.001, ["--table_ring"])
+if "c3tir" in which: run("c3ti-ring", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--table_ring"])
+if "c3r" in which: run("c3-ring", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--use_ot", "--table_ring"])
+if "c4s" in which: run("c4-small-n-ring", 1000, 500, [0, 100, 200, 300, 400], "cgd", 20, 0.001,
+                       ["--width_phase2=32", "--prec_phase2=30", "--table_ring"], w2=32)
+if "c4r" in which: run("c4-ring", 50000, 500, [0, 100, 200, 300, 400], "cgd", 20, 0.001,
+                       ["--width_phase2=32", "--prec_phase2=30", "--table_ring"], w2=32)

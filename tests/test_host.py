@@ -49,6 +49,32 @@ def test_pmsg_wire_format(hostlib):
     assert hostlib.pmsg_unpack(buf.ctypes.data, len(buf), C.byref(pv), C.byref(n), C.byref(val)) == 0
     assert n.value == 1000 and val.value == 12345678901234567890
     assert np.array_equal(np.ctypeslib.as_array(pv, (1000,)), vec)
+    # every varint length (1..10 bytes), every tail position of the word-at-a-time fast path
+    def enc(v):
+        out = bytearray()
+        while v >= 0x80:
+            out.append((v & 0x7f) | 0x80); v >>= 7
+        out.append(v)
+        return bytes(out)
+    for n_el in list(range(0, 40)) + [63, 64, 65, 257, 1000]:
+        bits = rng.integers(0, 65, size=n_el)
+        vals = [int(rng.integers(0, 2 ** 63, dtype=np.uint64)) * 2 + 1 for _ in range(n_el)]
+        vals = [v & ((1 << int(b)) - 1) for v, b in zip(vals, bits)]
+        v2 = int(rng.integers(0, 2 ** 63, dtype=np.uint64))
+        payload = b"".join(enc(v) for v in vals)
+        expect = (b"\x0a" + enc(len(payload)) + payload if n_el else b"") + b"\x10" + enc(v2)
+        blob = _pack(hostlib, np.array(vals, dtype=np.uint64), v2)
+        assert blob == expect, n_el
+        buf = np.frombuffer(blob, dtype=np.uint8).copy()
+        assert hostlib.pmsg_unpack(buf.ctypes.data, len(buf), C.byref(pv), C.byref(n), C.byref(val)) == 0
+        assert n.value == n_el and val.value == v2
+        if n_el:
+            assert np.ctypeslib.as_array(pv, (n_el,)).tolist() == vals
+    # an over-long varint (11 continuation bytes) is rejected by both decoders
+    for pad in (0, 100):
+        bad = bytes.fromhex("0a") + enc(pad + 11) + b"\x01" * pad + b"\xff" * 10 + b"\x01" + bytes.fromhex("1000")
+        bad = np.frombuffer(bad, dtype=np.uint8).copy()
+        assert hostlib.pmsg_unpack(bad.ctypes.data, len(bad), C.byref(pv), C.byref(n), C.byref(val)) != 0
     # a message without the required `value` is rejected (recv_pmsg's check, phase1.c:112)
     bad = np.frombuffer(bytes.fromhex("0a0101"), dtype=np.uint8).copy()
     assert hostlib.pmsg_unpack(bad.ctypes.data, len(bad), C.byref(pv), C.byref(n), C.byref(val)) != 0
@@ -92,7 +118,7 @@ README_RESULT = ["0.984331027786964", "0.792399824970372", "0.754117840176144", 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--use_ot"]], ids=["ti", "ot"])
+@pytest.mark.parametrize("extra", [[], ["--use_ot"], ["--table_ring"]], ids=["ti", "ot", "ti-ring"])
 def test_five_process_readme_example(tmp_path, golden_dir, extra):
     """bin/linreg examples/readme_example.in 56 $party cgd 10 0.001 (README.md:81) -> README.md:87"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
@@ -146,9 +172,11 @@ def test_secure_multiplication_binary(tmp_path, golden_dir, extra):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("alg,w,p", [("cgd", 64, 56), ("cholesky", 64, 54), ("ldlt", 32, 28)])
-def test_test_linear_system_binary(tmp_path, oracle, alg, w, p):
-    """two-party phase-2 benchmark (src/cmd/test/test_linear_system.c) vs the oracle on the same file"""
+@pytest.mark.parametrize("alg,w,p,ring", [("cgd", 64, 56, 0), ("cholesky", 64, 54, 0), ("ldlt", 32, 28, 0),
+                                          ("cgd", 64, 56, 2), ("cholesky", 32, 28, 1)])
+def test_test_linear_system_binary(tmp_path, oracle, alg, w, p, ring):
+    """two-party phase-2 benchmark (src/cmd/test/test_linear_system.c) vs the oracle on the same file;
+    ring > 0: the garbled tables stay in a device-resident ring shared between the two processes"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     rng = np.random.default_rng(17)
     d, iters = 4, 5
@@ -165,7 +193,7 @@ def test_test_linear_system_binary(tmp_path, oracle, alg, w, p):
         f.write("%d\n" % d + " ".join(repr(float(v)) for v in sol) + " ")
     port = _free_ports(1)[0]
     exe = os.path.join(HOST, "bin", "test_linear_system")
-    opt = ["--width=%d" % w, "--host=127.0.0.1"]
+    opt = ["--width=%d" % w, "--host=127.0.0.1"] + (["--table_ring=%d" % ring] if ring else [])
     procs = [subprocess.Popen([exe, str(port), str(k), path, alg, str(iters), str(p)] + opt,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE) for k in (1, 2)]
     outs = [q.communicate(timeout=300) for q in procs]
