@@ -257,56 +257,86 @@ extern "C" int lgc_p1_local(lgc_p1 *h, size_t c0, size_t c1, int with_y, uint64_
     return LGC_OK;
 }
 
+// Per-thread device scratch for the per-pair calls below (a data provider runs one worker thread
+// per peer; hipMalloc/hipFree per pair would dominate at small n).  Grown on demand, released
+// when the thread exits.
+struct P1Scratch {
+    void *ptr[4];
+    size_t cap[4];
+    int device;
+    P1Scratch() : device(-1) { for (int i = 0; i < 4; i++) { ptr[i] = 0; cap[i] = 0; } }
+    ~P1Scratch() { release(); }
+    void release() {
+        for (int i = 0; i < 4; i++) { if (ptr[i]) (void)hipFree(ptr[i]); ptr[i] = 0; cap[i] = 0; }
+    }
+    hipError_t get(int dev, int slot, size_t bytes, void **out) {
+        if (dev != device) { release(); device = dev; }
+        if (cap[slot] < bytes) {
+            if (ptr[slot]) (void)hipFree(ptr[slot]);
+            ptr[slot] = 0; cap[slot] = 0;
+            size_t want = bytes + bytes / 4 + 256;
+            hipError_t e = hipMalloc(&ptr[slot], want);
+            if (e != hipSuccess) return e;
+            cap[slot] = want;
+        }
+        *out = ptr[slot];
+        return hipSuccess;
+    }
+};
+static thread_local P1Scratch t_scratch;
+
 // out[q][k] = column cols[q] (d means y) +/- V[q][k]: the vectors a DP sends in inner_product_ti
-// (b + x at phase1.c:201-207, a - y at 186-191)
+// (b + x at phase1.c:201-207, a - y at 186-191).  Safe to call from several threads on one handle.
 extern "C" int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const uint64_t *V, int sign, uint64_t *out) {
     if (!h || !cols || !V || !out) return lgc_fail(LGC_EINVAL, "null argument");
     if (npairs == 0) return LGC_OK;
     for (size_t q = 0; q < npairs; q++) if (cols[q] > h->d) return lgc_fail(LGC_EINVAL, "column out of range");
     P1CHK(hipSetDevice(h->device));
+    hipStream_t st = hipStreamPerThread;
     uint32_t *dcols = 0; uint64_t *dV = 0, *dout = 0;
     size_t bytes = npairs * h->n * sizeof(uint64_t);
-    P1CHK(hipMalloc(&dcols, npairs * sizeof(uint32_t)));
-    P1CHK(hipMalloc(&dV, bytes));
-    P1CHK(hipMalloc(&dout, bytes));
-    P1CHK(hipMemcpy(dcols, cols, npairs * sizeof(uint32_t), hipMemcpyHostToDevice));
-    P1CHK(hipMemcpy(dV, V, bytes, hipMemcpyHostToDevice));
+    P1CHK(t_scratch.get(h->device, 0, npairs * sizeof(uint32_t), (void **)&dcols));
+    P1CHK(t_scratch.get(h->device, 1, bytes, (void **)&dV));
+    P1CHK(t_scratch.get(h->device, 2, bytes, (void **)&dout));
+    P1CHK(hipMemcpyAsync(dcols, cols, npairs * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    P1CHK(hipMemcpyAsync(dV, V, bytes, hipMemcpyHostToDevice, st));
     unsigned gx = (unsigned)((h->n + 255) / 256); if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(p1_mask_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, h->X, h->n, h->d + 1, dcols, dV, sign, dout);
-    P1CHK(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(p1_mask_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, st, h->X, h->n, h->d + 1, dcols, dV, sign, dout);
+    P1CHK(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
+    P1CHK(hipStreamSynchronize(st));
     const uint64_t m = maskw(h->w);
     if (h->w == 32) for (size_t i = 0; i < npairs * h->n; i++) out[i] &= m;
-    (void)hipFree(dcols); (void)hipFree(dV); (void)hipFree(dout);
     return LGC_OK;
 }
 
 // out[q] = <A[q], B[q]> (colsB == NULL) or <A[q], column colsB[q]>, minus sub[q]  (mod 2^w):
-// the share arithmetic of inner_product_ti (phase1.c:194-196, 220-222)
+// the share arithmetic of inner_product_ti (phase1.c:194-196, 220-222).  Thread-safe like lgc_p1_mask.
 extern "C" int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const uint32_t *colsB, size_t npairs,
                           const uint64_t *sub, uint64_t *out) {
     if (!h || !A || !out || (!B && !colsB)) return lgc_fail(LGC_EINVAL, "null argument");
     if (npairs == 0) return LGC_OK;
+    if (colsB) for (size_t q = 0; q < npairs; q++) if (colsB[q] > h->d) return lgc_fail(LGC_EINVAL, "column out of range");
     P1CHK(hipSetDevice(h->device));
+    hipStream_t st = hipStreamPerThread;
     size_t bytes = npairs * h->n * sizeof(uint64_t);
     uint64_t *dA = 0, *dB = 0, *dout = 0; uint32_t *dcols = 0;
-    P1CHK(hipMalloc(&dA, bytes));
-    P1CHK(hipMemcpy(dA, A, bytes, hipMemcpyHostToDevice));
+    P1CHK(t_scratch.get(h->device, 1, bytes, (void **)&dA));
+    P1CHK(hipMemcpyAsync(dA, A, bytes, hipMemcpyHostToDevice, st));
     if (colsB) {
-        for (size_t q = 0; q < npairs; q++) if (colsB[q] > h->d) return lgc_fail(LGC_EINVAL, "column out of range");
-        P1CHK(hipMalloc(&dcols, npairs * sizeof(uint32_t)));
-        P1CHK(hipMemcpy(dcols, colsB, npairs * sizeof(uint32_t), hipMemcpyHostToDevice));
+        P1CHK(t_scratch.get(h->device, 0, npairs * sizeof(uint32_t), (void **)&dcols));
+        P1CHK(hipMemcpyAsync(dcols, colsB, npairs * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     } else {
-        P1CHK(hipMalloc(&dB, bytes));
-        P1CHK(hipMemcpy(dB, B, bytes, hipMemcpyHostToDevice));
+        P1CHK(t_scratch.get(h->device, 2, bytes, (void **)&dB));
+        P1CHK(hipMemcpyAsync(dB, B, bytes, hipMemcpyHostToDevice, st));
     }
-    P1CHK(hipMalloc(&dout, npairs * sizeof(uint64_t)));
-    P1CHK(hipMemset(dout, 0, npairs * sizeof(uint64_t)));
+    P1CHK(t_scratch.get(h->device, 3, npairs * sizeof(uint64_t), (void **)&dout));
+    P1CHK(hipMemsetAsync(dout, 0, npairs * sizeof(uint64_t), st));
     unsigned gx = (unsigned)((h->n + 255) / 256); if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(p1_dot_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, dA, dB, h->X, h->d + 1, dcols, h->n, dout);
-    P1CHK(hipMemcpy(out, dout, npairs * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(p1_dot_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, st, dA, dB, h->X, h->d + 1, dcols, h->n, dout);
+    P1CHK(hipMemcpyAsync(out, dout, npairs * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    P1CHK(hipStreamSynchronize(st));
     const uint64_t m = maskw(h->w);
     for (size_t q = 0; q < npairs; q++) out[q] = (out[q] - (sub ? sub[q] : 0)) & m;
-    (void)hipFree(dA); if (dB) (void)hipFree(dB); if (dcols) (void)hipFree(dcols); (void)hipFree(dout);
     return LGC_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <errno.h>
 #include <math.h>
 #include <openssl/rand.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -127,6 +128,22 @@ int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
 }
 
 /* ---------------------------------------------------------------- phase 1: trusted initializer */
+typedef struct {
+    node *self;
+    int owner;                 /* 0-based party index of the destination data provider */
+    size_t n, nb;
+    const int *pa, *pb;        /* owners of the two rows of each pair of the batch */
+    const uint64_t *x, *y, *r, *xyr;
+    int failed;
+} ti_sender;
+static void *ti_sender_main(void *arg) {
+    ti_sender *t = arg;
+    for (size_t q = 0; q < t->nb && !t->failed; q++) {
+        if (t->pa[q] == t->owner) t->failed |= send_pmsg(t->self, t->owner + 1, t->y + q * t->n, t->n, t->xyr[q]);   /* (y, <x,y> - r) */
+        if (t->pb[q] == t->owner) t->failed |= send_pmsg(t->self, t->owner + 1, t->x + q * t->n, t->n, t->r[q]);     /* (x, r) */
+    }
+    return NULL;
+}
 int run_trusted_initializer(node *self, config *c, int w1, int device) {
     uint8_t seed[16];
     RAND_bytes(seed, sizeof seed);                       /* newBCipherRandomGen (src/phase1.c:243) */
@@ -150,22 +167,109 @@ int run_trusted_initializer(node *self, config *c, int w1, int device) {
     if (batch > 1024) batch = 1024;
     uint64_t *x = malloc(batch * n * 8), *y = malloc(batch * n * 8), *r = malloc(batch * 8), *xyr = malloc(batch * 8);
     int rc = 1;
+    /* Each data provider reads its TI socket in its own pair order, so the per-destination message
+     * sequences are independent: one sender thread per data provider encodes and sends that
+     * provider's messages of the batch, in order. */
+    const int P = c->num_parties - 2;
+    ti_sender *snd = calloc((size_t)P, sizeof *snd);
+    pthread_t *tid = calloc((size_t)P, sizeof *tid);
     for (size_t q0 = 0; q0 < np; q0 += batch) {
         size_t nb = np - q0 < batch ? np - q0 : batch;
         LGC(lgc_ti_generate(device, seed, q0, nb, n, w1, x, y, r, xyr));
-        for (size_t q = 0; q < nb; q++) {
-            int pa = pa_of[q0 + q], pb = pb_of[q0 + q];
-            check(!send_pmsg(self, pa + 1, y + q * n, n, xyr[q]), "Could not send message to party A (%d)", pa);   /* (y, <x,y> - r) */
-            check(!send_pmsg(self, pb + 1, x + q * n, n, r[q]), "Could not send message to party B (%d)", pb);     /* (x, r) */
+        for (int k = 0; k < P; k++) {
+            ti_sender t = {self, k + 2, n, nb, pa_of + q0, pb_of + q0, x, y, r, xyr, 0};
+            snd[k] = t;
+            check(!pthread_create(&tid[k], NULL, ti_sender_main, &snd[k]), "pthread_create failed");
         }
+        int failed = 0;
+        for (int k = 0; k < P; k++) { pthread_join(tid[k], NULL); failed |= snd[k].failed; }
+        check(!failed, "Could not send message to a data provider");
     }
     rc = 0;
 error:
-    free(x); free(y); free(r); free(xyr); free(pa_of); free(pb_of);
+    free(x); free(y); free(r); free(xyr); free(pa_of); free(pb_of); free(snd); free(tid);
     return rc;
 }
 
 /* ---------------------------------------------------------------- phase 1: data provider */
+/* TI-mode plumbing: a bounded queue of decoded TI messages per peer, and the per-peer worker */
+typedef struct { uint64_t *vec; uint64_t val; } ti_item;
+typedef struct {
+    ti_item *items;
+    size_t cap, head, count;
+    int closed;                 /* no more pushes (reader done) or no more pops (worker failed) */
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} ti_queue;
+static void ti_queue_init(ti_queue *q, size_t cap) {
+    q->items = calloc(cap, sizeof *q->items); q->cap = cap; q->head = q->count = 0; q->closed = 0;
+    pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL);
+}
+static void ti_queue_destroy(ti_queue *q) {
+    for (size_t i = 0; i < q->count; i++) free(q->items[(q->head + i) % q->cap].vec);
+    free(q->items); pthread_mutex_destroy(&q->mu); pthread_cond_destroy(&q->cv);
+}
+static void ti_queue_close(ti_queue *q) {
+    pthread_mutex_lock(&q->mu); q->closed = 1; pthread_cond_broadcast(&q->cv); pthread_mutex_unlock(&q->mu);
+}
+static int ti_queue_push(ti_queue *q, ti_item it) {
+    pthread_mutex_lock(&q->mu);
+    while (q->count == q->cap && !q->closed) pthread_cond_wait(&q->cv, &q->mu);
+    if (q->closed) { pthread_mutex_unlock(&q->mu); return 1; }
+    q->items[(q->head + q->count++) % q->cap] = it;
+    pthread_cond_broadcast(&q->cv);
+    pthread_mutex_unlock(&q->mu);
+    return 0;
+}
+static int ti_queue_pop(ti_queue *q, ti_item *it) {
+    pthread_mutex_lock(&q->mu);
+    while (q->count == 0 && !q->closed) pthread_cond_wait(&q->cv, &q->mu);
+    if (q->count == 0) { pthread_mutex_unlock(&q->mu); return 1; }
+    *it = q->items[q->head]; q->head = (q->head + 1) % q->cap; q->count--;
+    pthread_cond_broadcast(&q->cv);
+    pthread_mutex_unlock(&q->mu);
+    return 0;
+}
+typedef struct { int peer; int is_a; uint32_t col; uint64_t *dst; } ti_pair;
+typedef struct {
+    node *self; lgc_p1 *p1; size_t n; int peer;
+    const ti_pair *pairs; size_t npairs;
+    ti_queue *q;
+    int failed;
+} ti_worker;
+static void *ti_worker_main(void *arg) {
+    ti_worker *w = arg;
+    const size_t n = w->n;
+    const int to = w->peer + 1;
+    uint64_t *tmp = malloc(n * 8);
+    for (size_t k = 0; k < w->npairs && !w->failed; k++) {
+        const ti_pair *pr = &w->pairs[k];
+        if (pr->peer != w->peer) continue;
+        ti_item it = {0, 0};
+        uint64_t *in = 0, inval = 0, share = 0, sub;
+        size_t in_n = 0;
+        if (ti_queue_pop(w->q, &it)) { w->failed = 1; break; }
+        uint32_t col = pr->col;
+        sub = it.val;
+        if (pr->is_a) {                                   /* party a (phase1.c:171-197) */
+            if (recv_pmsg(w->self, to, &in, &in_n, &inval) || in_n != n) { fprintf(stderr, "Could not receive message from party B (%d)\n", w->peer); w->failed = 1; }
+            else if (lgc_p1_mask(w->p1, &col, 1, it.vec, -1, tmp)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* a - y */
+            else if (send_pmsg(w->self, to, tmp, n, 0)) { fprintf(stderr, "Could not send message to party B (%d)\n", w->peer); w->failed = 1; }
+            else if (lgc_p1_dot(w->p1, in, it.vec, 0, 1, &sub, &share)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* <b+x, y> - (xy - r) */
+        } else {                                          /* party b (phase1.c:198-223) */
+            if (lgc_p1_mask(w->p1, &col, 1, it.vec, +1, tmp)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }        /* b + x */
+            else if (send_pmsg(w->self, to, tmp, n, 0)) { fprintf(stderr, "Could not send message to party A (%d)\n", w->peer); w->failed = 1; }
+            else if (recv_pmsg(w->self, to, &in, &in_n, &inval) || in_n != n) { fprintf(stderr, "Could not receive message from party A (%d)\n", w->peer); w->failed = 1; }
+            else if (lgc_p1_dot(w->p1, in, 0, &col, 1, &sub, &share)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* <a-y, b> - r */
+        }
+        free(in); free(it.vec);
+        if (!w->failed) *pr->dst = share;
+    }
+    free(tmp);
+    if (w->failed) ti_queue_close(w->q);                  /* unblock the reader */
+    return NULL;
+}
+
 static void column_of(const int64_t *Xq, const int64_t *yq, size_t n, size_t d, size_t row, uint64_t *out) {
     for (size_t k = 0; k < n; k++) out[k] = (uint64_t)(row < d ? Xq[k * d + row] : yq[k]);
 }
@@ -200,37 +304,52 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
     }
     va = malloc(n * 8); vb = malloc(n * 8); tmp = malloc(n * 8); tmp2 = malloc(n * 8);
     if (!use_ot) {
-        /* TI mode, loop order of src/phase1.c:534-586 */
+        /* TI mode.  The pairs are those of the loops at src/phase1.c:534-586 and every socket
+         * carries its messages in that order (the TI socket: this party's pairs in loop order; a
+         * peer socket: the pairs shared with that peer in loop order), so the byte streams are the
+         * reference's.  Pairs with different peers are independent: one worker thread per peer runs
+         * inner_product_ti for its pairs, fed by a reader thread that takes the TI messages off the
+         * TI socket in loop order and hands each to the worker of the pair's peer. */
+        const int np_all = c->num_parties;
+        ti_pair *pairs = NULL;
+        size_t npairs = 0, cap = 0;
         for (size_t i = 0; i <= d; i++)
             for (size_t j = 0; j <= i && j < d; j++) {
                 int oi = config_owner(c, i), oj = config_owner(c, j);
                 if (oi == oj || (oi != me && oj != me)) continue;
-                uint64_t *tv = 0, tval = 0, share = 0, sub;
-                size_t tn = 0;
-                check(!recv_pmsg(self, 1, &tv, &tn, &tval) && tn == n, "Could not receive message from TI");
-                uint32_t col;
-                if (oi == me) {                                  /* party a (phase1.c:171-197) */
-                    uint64_t *in = 0, inval; size_t in_n = 0;
-                    check(!recv_pmsg(self, oj + 1, &in, &in_n, &inval) && in_n == n, "Could not receive message from party B (%d)", oj);
-                    col = (uint32_t)i;
-                    LGC(lgc_p1_mask(p1, &col, 1, tv, -1, tmp));               /* a - y */
-                    check(!send_pmsg(self, oj + 1, tmp, n, 0), "Could not send message to party B (%d)", oj);
-                    sub = tval;
-                    LGC(lgc_p1_dot(p1, in, tv, 0, 1, &sub, &share));          /* <b+x, y> - (xy - r) */
-                    free(in);
-                } else {                                         /* party b (phase1.c:198-223) */
-                    uint64_t *in = 0, inval; size_t in_n = 0;
-                    col = (uint32_t)j;
-                    LGC(lgc_p1_mask(p1, &col, 1, tv, +1, tmp));               /* b + x */
-                    check(!send_pmsg(self, oi + 1, tmp, n, 0), "Could not send message to party A (%d)", oi);
-                    check(!recv_pmsg(self, oi + 1, &in, &in_n, &inval) && in_n == n, "Could not receive message from party A (%d)", oi);
-                    sub = tval;
-                    LGC(lgc_p1_dot(p1, in, 0, &col, 1, &sub, &share));        /* <a-y, b> - r */
-                    free(in);
-                }
-                free(tv);
-                if (i < d) share_A[idx(i, j)] = share; else share_b[j] = share;
+                if (npairs == cap) { cap = cap ? 2 * cap : 1024; pairs = realloc(pairs, cap * sizeof *pairs); }
+                ti_pair pr = {oi == me ? oj : oi, oi == me, (uint32_t)(oi == me ? i : j),
+                              i < d ? share_A + idx(i, j) : share_b + j};
+                pairs[npairs++] = pr;
             }
+        ti_queue *queues = calloc((size_t)np_all, sizeof *queues);
+        ti_worker *workers = calloc((size_t)np_all, sizeof *workers);
+        pthread_t *tids = calloc((size_t)np_all, sizeof *tids);
+        int started[64] = {0}, failed = 0;
+        check(np_all <= 64, "too many parties");
+        for (int k = 2; k < np_all; k++) {
+            if (k == me) continue;
+            size_t cnt = 0;
+            for (size_t q = 0; q < npairs; q++) cnt += pairs[q].peer == k;
+            if (!cnt) continue;
+            ti_queue_init(&queues[k], 8);
+            ti_worker w = {self, p1, n, k, pairs, npairs, &queues[k], 0};
+            workers[k] = w;
+            if (pthread_create(&tids[k], NULL, ti_worker_main, &workers[k])) { failed = 1; break; }
+            started[k] = 1;
+        }
+        /* reader: this thread */
+        for (size_t q = 0; q < npairs && !failed; q++) {
+            ti_item it = {0, 0};
+            size_t tn = 0;
+            if (recv_pmsg(self, 1, &it.vec, &tn, &it.val) || tn != n) { fprintf(stderr, "Could not receive message from TI\n"); failed = 1; free(it.vec); break; }
+            if (ti_queue_push(&queues[pairs[q].peer], it)) { failed = 1; free(it.vec); break; }   /* the worker gave up */
+        }
+        for (int k = 2; k < np_all; k++) if (started[k]) ti_queue_close(&queues[k]);
+        for (int k = 2; k < np_all; k++)
+            if (started[k]) { pthread_join(tids[k], NULL); failed |= workers[k].failed; ti_queue_destroy(&queues[k]); }
+        free(pairs); free(queues); free(workers); free(tids);
+        check(!failed, "TI-mode aggregation failed");
     } else {
         /* OT mode (src/phase1.c:353-450): one Gilboa batch per peer, peers in a global order */
         for (int lo = 2; lo < c->num_parties; lo++)
