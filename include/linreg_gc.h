@@ -95,7 +95,17 @@ int lgc_solver_set_shares(lgc_solver *s, const uint64_t *shares);
  * profile != 0 brackets every kernel with HIP events (slower; fills the per-kernel times). */
 int lgc_solver_run(lgc_solver *s, int profile);
 
-/* Results (sign-extended to int64 when width == 32).  beta: d.
+/* Per-lambda sweep (BASELINE config 5): `count` independent circuits that differ only in the public
+ * regularisation constant added to the diagonal (src/linear.oc:52-57), garbled and evaluated as one
+ * program -- the launches of all circuits are merged, so the latency-bound stages (dividers,
+ * reveals) of different circuits fill the GPU together.  sys->lambda is ignored; sys->normalize
+ * must be 1, trace and reveal_inputs 0.  All circuits read the shares given to
+ * lgc_solver_set_shares; lgc_solver_get_beta returns count x d words (circuit-major). */
+int lgc_solver_create_sweep(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16],
+                            size_t count, const double *lambdas);
+size_t lgc_solver_num_circuits(const lgc_solver *s);
+
+/* Results (sign-extended to int64 when width == 32).  beta: d (sweep: count x d).
  * trace: num_iterations x (d + 4) (x, gamma, eta, q, ng), inputs: T + d. */
 int lgc_solver_get_beta(lgc_solver *s, int64_t *beta);
 int lgc_solver_get_trace(lgc_solver *s, int64_t *trace);
@@ -124,9 +134,12 @@ typedef struct {
     size_t n_records, n_launches;
     uint32_t n_words, n_reveal, in_base, rv_beta, rv_trace, rv_inputs;
     uint64_t total_steps, total_gates, max_launch_steps;
+    uint32_t replicas, word_stride, reveal_stride;   /* sweep programs: circuit t uses words x + t * word_stride
+                                                        (x != 0) and decode slots r + t * reveal_stride */
 } lgc_program_info;
 typedef struct lgc_program lgc_program;
 int lgc_program_build(lgc_program **out, const lgc_system *sys);
+int lgc_program_build_sweep(lgc_program **out, const lgc_system *sys, size_t count, const double *lambdas);
 void lgc_program_destroy(lgc_program *p);
 int lgc_program_info_get(const lgc_program *p, lgc_program_info *info);
 const lgc_record *lgc_program_records(const lgc_program *p);

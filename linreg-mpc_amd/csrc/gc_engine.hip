@@ -167,6 +167,23 @@ extern "C" int lgc_program_build(lgc_program **out, const lgc_system *sys) {
     *out = p;
     return LGC_OK;
 }
+extern "C" int lgc_program_build_sweep(lgc_program **out, const lgc_system *sys, size_t count, const double *lambdas) {
+    int rc = check_system(sys);
+    if (rc) return rc;
+    if (!out || !lambdas) return lgc_fail(LGC_EINVAL, "null argument");
+    if (count < 1 || count > 4096) return lgc_fail(LGC_EINVAL, "count must be in 1..4096");
+    if (!sys->normalize || sys->trace || sys->reveal_inputs)
+        return lgc_fail(LGC_EINVAL, "a sweep needs normalize = 1 (lambda enters there), trace = 0, reveal_inputs = 0");
+    Program base;
+    build(base, sys);
+    if ((uint64_t)base.n_words * count >= (1ull << 31)) return lgc_fail(LGC_EINVAL, "sweep too large");
+    std::vector<uint64_t> lf(count);
+    for (size_t t = 0; t < count; t++) lf[t] = lambda_to_fixed(lambdas[t], sys->precision, sys->width);
+    lgc_program *p = new lgc_program();
+    replicate_program(p->P, base, count, lf.data());
+    *out = p;
+    return LGC_OK;
+}
 extern "C" void lgc_program_destroy(lgc_program *p) { delete p; }
 extern "C" int lgc_program_info_get(const lgc_program *p, lgc_program_info *info) {
     if (!p || !info) return lgc_fail(LGC_EINVAL, "null argument");
@@ -182,6 +199,9 @@ extern "C" int lgc_program_info_get(const lgc_program *p, lgc_program_info *info
     info->total_steps = P.total_steps;
     info->total_gates = P.total_gates;
     info->max_launch_steps = P.max_launch_steps;
+    info->replicas = P.replicas;
+    info->word_stride = P.word_stride;
+    info->reveal_stride = P.reveal_stride;
     return LGC_OK;
 }
 static_assert(sizeof(lgc_record) == sizeof(Rec), "record layout");
@@ -243,7 +263,22 @@ extern "C" void lgc_solver_destroy(lgc_solver *s) {
     delete s;
 }
 
+static int solver_create(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16], size_t count,
+                         const double *lambdas);
 extern "C" int lgc_solver_create(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16]) {
+    return solver_create(out, device, sys, seed, 1, 0);
+}
+extern "C" int lgc_solver_create_sweep(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16],
+                                       size_t count, const double *lambdas) {
+    if (!lambdas) return lgc_fail(LGC_EINVAL, "null lambdas");
+    if (count < 1 || count > 4096) return lgc_fail(LGC_EINVAL, "count must be in 1..4096");
+    if (sys && (!sys->normalize || sys->trace || sys->reveal_inputs))
+        return lgc_fail(LGC_EINVAL, "a sweep needs normalize = 1 (lambda enters there), trace = 0, reveal_inputs = 0");
+    return solver_create(out, device, sys, seed, count, lambdas);
+}
+extern "C" size_t lgc_solver_num_circuits(const lgc_solver *s) { return s ? s->P.replicas : 0; }
+static int solver_create(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16], size_t count,
+                         const double *lambdas) {
     int rc = check_system(sys);
     if (rc) return rc;
     if (!out || !seed) return lgc_fail(LGC_EINVAL, "null argument");
@@ -254,7 +289,19 @@ extern "C" int lgc_solver_create(lgc_solver **out, int device, const lgc_system 
     lgc_solver *s = new lgc_solver();
     s->sys = *sys;
     s->device = device;
-    build(s->P, sys);
+    if (lambdas) {
+        Program base;
+        build(base, sys);
+        if ((uint64_t)base.n_words * count >= (1ull << 31)) {
+            delete s;
+            return lgc_fail(LGC_EINVAL, "sweep too large: %zu circuits x %u words", count, base.n_words);
+        }
+        std::vector<uint64_t> lf(count);
+        for (size_t t = 0; t < count; t++) lf[t] = lambda_to_fixed(lambdas[t], sys->precision, sys->width);
+        replicate_program(s->P, base, count, lf.data());
+    } else {
+        build(s->P, sys);
+    }
     memcpy(&s->seed, seed, 16);
     s->R = host_hash(s->seed, 0x52ull << 56);   // 'R'
     s->R.x |= 1u;                               // point-and-permute: lsb(R) = 1
@@ -372,10 +419,10 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
     HIPCHK(hipMemsetAsync(s->wordsE, 0, wbytes, sG));
     HIPCHK(hipMemsetAsync(s->decG, 0, (P.n_reveal + 1) * sizeof(uint64_t), sG));
     HIPCHK(hipMemsetAsync(s->decE, 0, (P.n_reveal + 1) * sizeof(uint64_t), sG));
-    {
+    for (uint32_t t = 0; t < P.replicas; t++) {   // every circuit of a sweep gets its own labels for the same shares
         dim3 grid((unsigned)((nin + 3) / 4)), block(256);
-        hipLaunchKernelGGL(gc_input_kernel, grid, block, 0, sG, s->wordsG, s->wordsE, s->vals, P.in_base,
-                           (uint32_t)nin, s->R, s->seed, P.w);
+        hipLaunchKernelGGL(gc_input_kernel, grid, block, 0, sG, s->wordsG, s->wordsE, s->vals,
+                           P.in_base + t * P.word_stride, (uint32_t)nin, s->R, s->seed, P.w);
     }
     if (!profile) {   // the evaluator chain starts after the input labels are in place
         HIPCHK(hipEventRecord(s->evG[0], sG));
@@ -462,7 +509,9 @@ static int64_t decode_word(const lgc_solver *s, uint32_t slot) {
 extern "C" int lgc_solver_get_beta(lgc_solver *s, int64_t *beta) {
     if (!s || !beta) return lgc_fail(LGC_EINVAL, "null argument");
     if (!s->ran) return lgc_fail(LGC_ESTATE, "solver has not run");
-    for (size_t i = 0; i < s->P.d; i++) beta[i] = decode_word(s, s->P.rv_beta + (uint32_t)i);
+    for (uint32_t t = 0; t < s->P.replicas; t++)
+        for (size_t i = 0; i < s->P.d; i++)
+            beta[(size_t)t * s->P.d + i] = decode_word(s, s->P.rv_beta + t * s->P.reveal_stride + (uint32_t)i);
     return LGC_OK;
 }
 extern "C" int lgc_solver_get_trace(lgc_solver *s, int64_t *trace) {

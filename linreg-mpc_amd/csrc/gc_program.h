@@ -47,6 +47,10 @@ struct Program {
     // (the points where cgd.oc:190-194 prints yaoGateCount() and the running time)
     std::vector<uint32_t> iter_launch;
     std::vector<uint64_t> iter_gates;
+    // lambda sweep (replicate_program): `replicas` copies of one circuit in one program; copy t
+    // uses words x + t * word_stride (x != 0) and decode slots r + t * reveal_stride
+    uint32_t replicas, word_stride, reveal_stride;
+    uint32_t lam_rec;            // index of the OP_CONST record holding lambda, or ~0u
 
     // ---- builder state
     uint64_t cap_steps;          // split launches above this many steps
@@ -56,6 +60,7 @@ struct Program {
 
     Program() : w(64), p(56), d(0), T(0), nshares(0), n_words(1), n_reveal(0), in_base(0), rv_beta(0),
                 rv_trace(~0u), rv_ab(~0u), total_steps(0), total_gates(0), max_launch_steps(0),
+                replicas(1), word_stride(0), reveal_stride(0), lam_rec(~0u),
                 cap_steps(1ull << 22), step_cursor(0), open(false) {}
 
     uint32_t alloc(size_t n) { uint32_t r = n_words; n_words += (uint32_t)n; return r; }
@@ -273,6 +278,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
     P.new_launch();
     if (normalize) {
         const uint32_t lam = P.alloc(1);
+        P.lam_rec = (uint32_t)P.recs.size();
         P.emit(Program::mk(OP_CONST, lam, (uint32_t)lambda_fixed, (uint32_t)(lambda_fixed >> 32)));
         P.new_launch();
         for (size_t i = 0; i < d; i++)
@@ -444,4 +450,48 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
     }
 }
 
+
+// `count` independent copies of the circuit `P0` in one program: the per-lambda sweep (SURVEY.md
+// 8(e); lambda is a public constant added to the diagonal, linear.oc:52-57).  All copies read the
+// same input shares (each through its own fresh input labels) and differ only in the OP_CONST
+// record that holds lambda.  The records of all copies of one launch of P0 share launches, so the
+// dependent chains (dividers, reveals) of different circuits fill the GPU together.
+inline void replicate_program(Program &P, const Program &P0, size_t count, const uint64_t *lambda_fixed) {
+    P.w = P0.w; P.p = P0.p; P.d = P0.d; P.T = P0.T; P.nshares = P0.nshares;
+    P.cap_steps = P0.cap_steps;
+    P.word_stride = P0.n_words - 1;             // word 0 (constant zero) is shared
+    P.reveal_stride = P0.n_reveal;
+    P.replicas = (uint32_t)count;
+    P.n_words = 1 + (uint32_t)count * P.word_stride;
+    P.n_reveal = (uint32_t)count * P.reveal_stride;
+    P.in_base = P0.in_base; P.rv_beta = P0.rv_beta; P.rv_trace = P0.rv_trace; P.rv_ab = P0.rv_ab;
+    P.lam_rec = ~0u;
+    size_t next_iter = 0;
+    for (size_t li = 0; li < P0.launches.size(); li++) {
+        const Launch &L = P0.launches[li];
+        for (size_t t = 0; t < count; t++) {
+            const uint32_t wo = (uint32_t)t * P.word_stride, ro = (uint32_t)t * P.reveal_stride;
+            for (uint32_t k = 0; k < L.nrec; k++) {
+                Rec r = P0.recs[L.first_rec + k];
+                auto mv = [wo](uint32_t x) { return x ? x + wo : 0u; };
+                switch (r.op) {
+                case OP_CONST:
+                    r.dst = mv(r.dst);
+                    if (L.first_rec + k == P0.lam_rec) { r.a = (uint32_t)lambda_fixed[t]; r.b = (uint32_t)(lambda_fixed[t] >> 32); }
+                    break;
+                case OP_IDIVC: r.dst = mv(r.dst); r.a = mv(r.a); break;          // c is an immediate
+                case OP_REVEAL: r.dst += ro; r.a = mv(r.a); break;               // dst is a decode slot
+                default: r.dst = mv(r.dst); r.a = mv(r.a); r.b = mv(r.b); r.c = mv(r.c); break;
+                }
+                P.emit(r);
+            }
+        }
+        P.new_launch();
+        while (next_iter < P0.iter_launch.size() && P0.iter_launch[next_iter] == li) {
+            P.iter_launch.push_back((uint32_t)(P.launches.size() - 1));
+            P.iter_gates.push_back(P.total_gates);
+            next_iter++;
+        }
+    }
+}
 }  // namespace gc

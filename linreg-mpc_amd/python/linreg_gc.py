@@ -52,7 +52,8 @@ class ProgramInfo(C.Structure):
     _fields_ = [("n_records", C.c_size_t), ("n_launches", C.c_size_t), ("n_words", C.c_uint32),
                 ("n_reveal", C.c_uint32), ("in_base", C.c_uint32), ("rv_beta", C.c_uint32),
                 ("rv_trace", C.c_uint32), ("rv_inputs", C.c_uint32), ("total_steps", C.c_uint64),
-                ("total_gates", C.c_uint64), ("max_launch_steps", C.c_uint64)]
+                ("total_gates", C.c_uint64), ("max_launch_steps", C.c_uint64),
+                ("replicas", C.c_uint32), ("word_stride", C.c_uint32), ("reveal_stride", C.c_uint32)]
 
 
 _lib = None
@@ -77,6 +78,8 @@ def lib():
             ("lgc_solver_get_profile", [vp, vp, vp, sz]), ("lgc_solver_get_iterations", [vp, vp, vp, sz]),
             ("lgc_party_iteration_marks", [vp, vp, vp, sz]),
             ("lgc_program_build", [C.POINTER(vp), C.POINTER(System)]),
+            ("lgc_program_build_sweep", [C.POINTER(vp), C.POINTER(System), sz, vp]),
+            ("lgc_solver_create_sweep", [C.POINTER(vp), ci, C.POINTER(System), C.c_char_p, sz, vp]),
             ("lgc_program_info_get", [vp, C.POINTER(ProgramInfo)]),
             ("lgc_aes_bench", [ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
             ("lgc_p1_create", [C.POINTER(vp), ci, sz, sz, ci, ci]), ("lgc_p1_set_data", [vp, vp, vp]),
@@ -134,9 +137,13 @@ def make_system(d, width=64, precision=56, algorithm="cgd", num_iterations=0, la
 class Program:
     """The lowered circuit program (host only; needs no GPU)."""
 
-    def __init__(self, system):
+    def __init__(self, system, lambdas=None):
         self._h = C.c_void_p()
-        _chk(lib().lgc_program_build(C.byref(self._h), C.byref(system)))
+        if lambdas is None:
+            _chk(lib().lgc_program_build(C.byref(self._h), C.byref(system)))
+        else:                                    # per-lambda sweep: len(lambdas) circuits in one program
+            lam = np.ascontiguousarray(lambdas, dtype=np.float64)
+            _chk(lib().lgc_program_build_sweep(C.byref(self._h), C.byref(system), lam.size, lam.ctypes.data_as(C.c_void_p)))
         self.info = ProgramInfo()
         _chk(lib().lgc_program_info_get(self._h, C.byref(self.info)))
         self.system = system
@@ -165,11 +172,20 @@ class Solver:
 
     Replaces `execYaoProtocol(pd, solver, &ls)` (reference src/cmd/linreg.c:177)."""
 
-    def __init__(self, system, seed=b"\x01" * 16, device=0):
+    def __init__(self, system, seed=b"\x01" * 16, device=0, lambdas=None):
+        """lambdas: per-lambda sweep -- len(lambdas) circuits on the same shares in one program
+        (lgc_solver_create_sweep); beta() then returns (len(lambdas), d)."""
         assert len(seed) == 16
         self._h = C.c_void_p()
         self.system = system
-        _chk(lib().lgc_solver_create(C.byref(self._h), device, C.byref(system), seed))
+        self.count = None
+        if lambdas is None:
+            _chk(lib().lgc_solver_create(C.byref(self._h), device, C.byref(system), seed))
+        else:
+            lam = np.ascontiguousarray(lambdas, dtype=np.float64)
+            self.count = int(lam.size)
+            _chk(lib().lgc_solver_create_sweep(C.byref(self._h), device, C.byref(system), seed, lam.size,
+                                               lam.ctypes.data_as(C.c_void_p)))
 
     def set_shares(self, shares):
         d = self.system.d
@@ -181,7 +197,7 @@ class Solver:
         _chk(lib().lgc_solver_run(self._h, 1 if profile else 0))
 
     def beta(self):
-        out = np.zeros(self.system.d, dtype=np.int64)
+        out = np.zeros(self.system.d if self.count is None else (self.count, self.system.d), dtype=np.int64)
         _chk(lib().lgc_solver_get_beta(self._h, out.ctypes.data_as(C.c_void_p)))
         return out
 

@@ -21,13 +21,16 @@ def c5_lambdas(count=64):
     return [10.0 ** (-6.0 + 6.0 * k / (count - 1)) for k in range(count)]
 
 
-def gpu_solve_factory(d, width, precision, algorithm, num_iterations, nshares, device):
-    """per-lambda solve on this rank's GPU through the C ABI (data-provider input path)"""
+def gpu_solve_factory(d, width, precision, algorithm, num_iterations, nshares, device, seed=None):
+    """solve of this rank's block of lambdas on its GPU through the C ABI (data-provider input
+    path): all circuits of the block are garbled and evaluated as ONE program
+    (lgc_solver_create_sweep), so their latency-bound stages share launches"""
+    import os
     import linreg_gc as lgc
 
-    def solve(shares, lam, index):
-        sysm = lgc.make_system(d, width, precision, algorithm, num_iterations, lam, nshares, 1, 0, 0)
-        s = lgc.Solver(sysm, seed=bytes((index + i) & 0xff for i in range(16)), device=device)
+    def solve(shares, lams, first_index):
+        sysm = lgc.make_system(d, width, precision, algorithm, num_iterations, 0.0, nshares, 1, 0, 0)
+        s = lgc.Solver(sysm, seed=seed or os.urandom(16), device=device, lambdas=lams)
         s.set_shares(shares)
         s.run()
         beta = s.beta()
@@ -37,7 +40,8 @@ def gpu_solve_factory(d, width, precision, algorithm, num_iterations, nshares, d
 
 
 def lambda_sweep(shares, lambdas, d, solve, dist=None, tensor_device="cpu"):
-    """Solve one circuit per lambda; rank r takes the contiguous block partition(len, world, r).
+    """Solve one circuit per lambda; rank r takes the contiguous block partition(len, world, r) and
+    hands it to solve(shares, block_of_lambdas, first_index) -> (len(block), d) int64.
     Returns an (len(lambdas), d) int64 array with every rank's results (gathered on all ranks)."""
     import torch
     world = dist.get_world_size() if dist is not None else 1
@@ -45,8 +49,8 @@ def lambda_sweep(shares, lambdas, d, solve, dist=None, tensor_device="cpu"):
     lo, hi = partition(len(lambdas), world, rank)
     per = (len(lambdas) + world - 1) // world
     mine = np.zeros((per, d), dtype=np.int64)
-    for t, k in enumerate(range(lo, hi)):
-        mine[t] = solve(shares, lambdas[k], k)
+    if hi > lo:
+        mine[:hi - lo] = solve(shares, list(lambdas[lo:hi]), lo)
     if dist is None:
         return mine[:hi - lo]
     buf = torch.from_numpy(mine).to(tensor_device)

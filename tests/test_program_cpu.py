@@ -103,6 +103,40 @@ def test_cpu_garble_eval_matches_oracle(lgc, gccpu, oracle, w, p):
         assert sx(dec[prog.info.rv_beta:prog.info.rv_beta + d], w).tolist() == exp.tolist()
 
 
+@pytest.mark.parametrize("w,p,alg", [(64, 56, "cgd"), (32, 28, "cholesky"), (64, 54, "ldlt")])
+def test_sweep_program_matches_oracle_per_lambda(lgc, gccpu, oracle, w, p, alg):
+    """per-lambda sweep: several circuits replicated into one program (merged launches), each
+    bit-exact against the oracle run with its own lambda"""
+    rng = np.random.default_rng(77 + w)
+    d, n, nsh, iters = 4, 30, 3, 4
+    A, b = synth_system(oracle, rng, n, d, w, p)
+    shares = split_shares(rng, A, b, nsh, w)
+    lams = [0.0, 1e-6, 0.001, 0.37, 1.0]
+    sysm = lgc.make_system(d, w, p, alg, iters, 123.0, nsh, 1, 0, 0)        # sys.lambda is ignored
+    base = lgc.Program(lgc.make_system(d, w, p, alg, iters, lams[0], nsh, 1, 0, 0))
+    prog = lgc.Program(sysm, lambdas=lams)
+    info = prog.info
+    assert info.replicas == len(lams) and info.word_stride == base.info.n_words - 1
+    assert info.reveal_stride == base.info.n_reveal and info.n_reveal == len(lams) * base.info.n_reveal
+    assert info.n_words == 1 + len(lams) * (base.info.n_words - 1)
+    assert info.total_gates == len(lams) * base.info.total_gates
+    assert info.n_launches == base.info.n_launches                          # launches are merged, not appended
+    words = np.zeros(info.n_words, dtype=np.uint64)
+    m = np.uint64((1 << w) - 1)
+    for t in range(len(lams)):
+        lo = info.in_base + t * info.word_stride
+        words[lo:lo + shares.size] = shares.ravel() & m
+    dec = np.zeros(info.n_reveal + 1, dtype=np.uint64)
+    steps, gates = gccpu.plain_run(prog.records(), info.n_records, w, p, words, dec)
+    assert steps == info.total_steps and gates == info.total_gates
+    for t, lam in enumerate(lams):
+        exp = oracle_solve(oracle, A, b, d, w, p, alg, iters, lam, 1)[0]
+        lo = info.rv_beta + t * info.reveal_stride
+        assert sx(dec[lo:lo + d], w).tolist() == exp.tolist(), (t, lam)
+    with pytest.raises(RuntimeError):                                       # lambda only enters the DP input path
+        lgc.Program(lgc.make_system(d, w, p, alg, iters, 0.0, 2, 0, 0, 0), lambdas=lams)
+
+
 def test_library_exports_and_fails_loudly_without_gpu(lgc):
     import ctypes, re, os
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "linreg_gc.h")).read()

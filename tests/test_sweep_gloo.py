@@ -29,10 +29,11 @@ def _worker(rank, world, port, q):
     lams = sweep.c5_lambdas(7)                       # ragged: 7 circuits over 2 ranks -> 4 + 3
     calls = []
 
-    def solve(sh, lam, index):
-        calls.append(index)
+    def solve(sh, block, first):
+        calls.extend(range(first, first + len(block)))
         tot = sh.sum(axis=0, dtype=np.uint64)
-        return oracle_solve(oracle, tot[:d * (d + 1) // 2], tot[d * (d + 1) // 2:], d, w, p, "cgd", 3, lam, 1)[0]
+        return np.array([oracle_solve(oracle, tot[:d * (d + 1) // 2], tot[d * (d + 1) // 2:], d, w, p, "cgd", 3, lam, 1)[0]
+                         for lam in block])
     res = sweep.lambda_sweep(shares, lams, d, solve, dist=dist)
     dist.barrier()
     dist.destroy_process_group()
@@ -92,3 +93,14 @@ def test_gpu_sweep_single_rank(lgc, oracle):
     res = sweep.lambda_sweep(shares, lams, d, solve)
     exp = [oracle_solve(oracle, A, b, d, w, p, "cgd", 4, lam, 1)[0].tolist() for lam in lams]
     assert res.tolist() == exp
+    # 32-bit direct solver, merged program
+    w, p = 32, 28
+    A, b = synth_system(oracle, rng, n, d, w, p)
+    shares = split_shares(rng, A, b, 3, w)
+    lams = [0.0, 0.01, 0.5]
+    s = lgc.Solver(lgc.make_system(d, w, p, "cholesky", 0, 9.0, 3, 1, 0, 0), seed=bytes(range(16)), lambdas=lams)
+    s.set_shares(shares); s.run()
+    exp = [oracle_solve(oracle, A, b, d, w, p, "cholesky", 0, lam, 1)[0].tolist() for lam in lams]
+    assert s.beta().tolist() == exp
+    with pytest.raises(RuntimeError):
+        lgc.Solver(lgc.make_system(d, w, p, "cgd", 2, 0.0, 2, 0, 0, 0), lambdas=lams)

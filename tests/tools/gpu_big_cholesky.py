@@ -1,6 +1,6 @@
 """one-off: d=500 Cholesky / LDL^T (64-bit) and d=500 Cholesky 32-bit vs the oracle, with timing"""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import linreg_gc as lgc, orc

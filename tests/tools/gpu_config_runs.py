@@ -2,7 +2,7 @@
 generates the synthetic instance (experiments/generate_tests.py:159-169 distribution), runs the
 processes, checks party 2's Result line against the oracle, reports wall-clock."""
 import sys, os, re, time, socket, subprocess, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import orc
