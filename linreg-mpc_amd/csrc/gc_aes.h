@@ -163,6 +163,13 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4], con
         for (int b = 0; b < N; b++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                if (T::kFourTables) {
+                    v[b][4 * j + 0] = tab.lkt(0, s[b][j], 0);
+                    v[b][4 * j + 1] = tab.lkt(1, s[b][(j + 1) & 3], 1);
+                    v[b][4 * j + 2] = tab.lkt(2, s[b][(j + 2) & 3], 2);
+                    v[b][4 * j + 3] = tab.lkt(3, s[b][(j + 3) & 3], 3);
+                    continue;
+                }
                 v[b][4 * j + 0] = tab.lk(s[b][j], 0);
                 v[b][4 * j + 1] = tab.lk(s[b][(j + 1) & 3], 1);
                 v[b][4 * j + 2] = T::kTwoTables ? tab.lk2(s[b][(j + 2) & 3], 2) : tab.lk(s[b][(j + 2) & 3], 2);
@@ -173,7 +180,10 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4], con
         for (int b = 0; b < N; b++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (T::kTwoTables) {
+                if (T::kFourTables) {
+                    // Te_t = rotl(Te0, 8t) are all resident: no rotates
+                    s[b][j] = xor3(xor3(v[b][4 * j], v[b][4 * j + 1], rk[4 * rnd + j]), v[b][4 * j + 2], v[b][4 * j + 3]);
+                } else if (T::kTwoTables) {
                     // v2, v3 come from Te2 = rotl16(Te0): col = Te0[i0]^Te2[i2] ^ rotl8(Te0[i1]^Te2[i3]) ^ rk,
                     // with the round key folded in before the rotation (rk24 = rotl24(rk))
                     uint32_t x = xor3(v[b][4 * j + 1], v[b][4 * j + 3], rk24[4 * rnd + j]);
@@ -235,7 +245,9 @@ GC_HD void hash_n(const T &tab, const uint32_t *rk, const Lbl *x, const uint64_t
 // host table accessor (plain array)
 struct HostTab {
     static const bool kTwoTables = false;
+    static const bool kFourTables = false;
     const uint32_t *te0;
+    inline uint32_t lkt(int, uint32_t word, int k) const { return lk(word, k); }
     inline uint32_t lk(uint32_t word, int k) const { return te0[(word >> (8 * k)) & 0xffu]; }
     inline uint32_t lk2(uint32_t word, int k) const { return rotl32(lk(word, k), 16); }
 };

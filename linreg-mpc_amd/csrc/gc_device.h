@@ -24,10 +24,14 @@ __constant__ uint32_t c_rk24[44];
 __device__ unsigned long long *g_stamp = 0;   // diagnostic build only: [hash, barrier, glue, last, count, tail]
 #endif   // rotl24 of the round keys (two-table AES rounds)
 
+#ifndef GC_AES_TAB4
+#define GC_AES_TAB4 1   /* MAC kernels and the AES micro-benchmark: four rotated tables, 32 replicas each */
+#endif
 static constexpr int kLdsTabWords = 256 * 64;   // 64 KiB: entry x occupies the 256-byte row x
 
 struct LdsTab {
     static const bool kTwoTables = false;
+    static const bool kFourTables = false;
     const char *base;    // LDS byte address of the table
     uint32_t lane4;      // (lane << 2): fits one byte, merged into the address by v_perm_b32
     // Te0[byte k of word]: address = (byte << 8) | (lane << 2)
@@ -36,11 +40,13 @@ struct LdsTab {
         return *reinterpret_cast<const uint32_t *>(base + off);
     }
     __device__ __forceinline__ uint32_t lk2(uint32_t word, int k) const { return rotl32(lk(word, k), 16); }
+    __device__ __forceinline__ uint32_t lkt(int, uint32_t word, int k) const { return lk(word, k); }
 };
 
 // MAC kernels: Te0 and Te2 = rotl16(Te0) side by side (128 KiB): one rotate per column instead of three
 struct LdsTab2 {
     static const bool kTwoTables = true;
+    static const bool kFourTables = false;
     const char *base;
     uint32_t lane4;
     __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const {
@@ -53,6 +59,7 @@ struct LdsTab2 {
         uint32_t off = __builtin_amdgcn_perm(word, lane4, 0x0c020400u + ((uint32_t)k << 8));
         return *reinterpret_cast<const uint32_t *>(base + off);
     }
+    __device__ __forceinline__ uint32_t lkt(int, uint32_t word, int k) const { return lk(word, k); }
 };
 __device__ __forceinline__ void lds_tab2_fill(uint32_t *lds) {
     for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) {
@@ -69,6 +76,39 @@ __device__ __forceinline__ LdsTab2 lds_tab2_make(const uint32_t *lds) {
     return t;
 }
 
+// Four tables Te_t = rotl(Te0, 8t) in the same 128 KiB: a ds_read_b32 is serviced in two groups of
+// 32 lanes on 32 banks, so 32 replicas per entry are already conflict-free (lanes l and l + 32 share
+// a replica but never a cycle).  Row x (256 B) of the first half holds Te0[x] x 32 | Te1[x] x 32,
+// of the second half Te2[x] x 32 | Te3[x] x 32.  No rotates in the rounds.
+struct LdsTab4 {
+    static const bool kTwoTables = false;
+    static const bool kFourTables = true;
+    const char *base;
+    uint32_t c[4];       // per table: ((lane & 31) << 2) | (t & 1) << 7 | (t >> 1) << 16
+    __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const { return lkt(0, word, k); }
+    __device__ __forceinline__ uint32_t lk2(uint32_t word, int k) const { return lkt(2, word, k); }
+    __device__ __forceinline__ uint32_t lkt(int t, uint32_t word, int k) const {
+        uint32_t off = __builtin_amdgcn_perm(word, c[t], (t >= 2 ? 0x0c020400u : 0x0c0c0400u) + ((uint32_t)k << 8));
+        return *reinterpret_cast<const uint32_t *>(base + off);
+    }
+};
+__device__ __forceinline__ void lds_tab4_fill(uint32_t *lds) {
+    for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) {
+        uint32_t v = c_te0[i >> 6];
+        const bool odd = (i >> 5) & 1;
+        lds[i] = odd ? ((v << 8) | (v >> 24)) : v;
+        lds[kLdsTabWords + i] = odd ? ((v << 24) | (v >> 8)) : ((v << 16) | (v >> 16));
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ LdsTab4 lds_tab4_make(const uint32_t *lds) {
+    LdsTab4 t;
+    t.base = reinterpret_cast<const char *>(lds);
+    const uint32_t l5 = (threadIdx.x & 31u) << 2;
+    t.c[0] = l5; t.c[1] = l5 | 0x80u; t.c[2] = l5 | 0x10000u; t.c[3] = l5 | 0x10080u;
+    return t;
+}
+
 __device__ __forceinline__ void lds_tab_fill(uint32_t *lds) {
     for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) lds[i] = c_te0[i >> 6];
     __syncthreads();
@@ -79,6 +119,53 @@ __device__ __forceinline__ LdsTab lds_tab_make(const uint32_t *lds) {
     t.lane4 = (threadIdx.x & 63u) << 2;
     return t;
 }
+
+// Two tables in 64 KiB (32 replicas): row x = Te0[x] x 32 | Te2[x] x 32.  One rotate per column
+// (as LdsTab2) at half the footprint, so two 4-wave workgroups still fit a CU.
+struct LdsTab2h {
+    static const bool kTwoTables = true;
+    static const bool kFourTables = false;
+    const char *base;
+    uint32_t c0, c1;
+    __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const {
+        uint32_t off = __builtin_amdgcn_perm(word, c0, 0x0c0c0400u + ((uint32_t)k << 8));
+        return *reinterpret_cast<const uint32_t *>(base + off);
+    }
+    __device__ __forceinline__ uint32_t lk2(uint32_t word, int k) const {
+        uint32_t off = __builtin_amdgcn_perm(word, c1, 0x0c0c0400u + ((uint32_t)k << 8));
+        return *reinterpret_cast<const uint32_t *>(base + off);
+    }
+    __device__ __forceinline__ uint32_t lkt(int, uint32_t word, int k) const { return lk(word, k); }
+};
+__device__ __forceinline__ void lds_tab2h_fill(uint32_t *lds) {
+    for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) {
+        uint32_t v = c_te0[i >> 6];
+        lds[i] = ((i >> 5) & 1) ? ((v << 16) | (v >> 16)) : v;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ LdsTab2h lds_tab2h_make(const uint32_t *lds) {
+    LdsTab2h t;
+    t.base = reinterpret_cast<const char *>(lds);
+    t.c0 = (threadIdx.x & 31u) << 2;
+    t.c1 = t.c0 | 0x80u;
+    return t;
+}
+
+// table variant by number: 2 = LdsTab2h (64 KiB), 4 = LdsTab4 (128 KiB)
+template <int TABV> struct TabSel;
+template <> struct TabSel<2> {
+    typedef LdsTab2h T;
+    static constexpr int kWords = kLdsTabWords;
+    static __device__ __forceinline__ void fill(uint32_t *lds) { lds_tab2h_fill(lds); }
+    static __device__ __forceinline__ T make(const uint32_t *lds) { return lds_tab2h_make(lds); }
+};
+template <> struct TabSel<4> {
+    typedef LdsTab4 T;
+    static constexpr int kWords = 2 * kLdsTabWords;
+    static __device__ __forceinline__ void fill(uint32_t *lds) { lds_tab4_fill(lds); }
+    static __device__ __forceinline__ T make(const uint32_t *lds) { return lds_tab4_make(lds); }
+};
 
 __device__ __forceinline__ Lbl ld_lbl(const Lbl *p) {
     uint4 v = *reinterpret_cast<const uint4 *>(p);
@@ -225,7 +312,7 @@ struct GpuBackend {
                 Lbl x = (wave < (nh >> 1)) ? a : b;
                 if (GARBLER && (wave & 1)) x = lxor(x, R);
                 uint64_t tw = 2 * gid + (uint64_t)(wave >= (nh >> 1));
-                hash_n<1, TAB>(lt, c_rk, &x, &tw, &h);
+                hash_n<1, TAB>(lt, c_rk, &x, &tw, &h, c_rk24);
             }
             xbuf[wave * 64 + lane] = h;
         }
@@ -286,7 +373,7 @@ struct GpuBackend {
             if (wave & 1) { x[0] = lxor(x[0], R); x[1] = lxor(x[1], R); }
             uint64_t tw[2] = {2 * gid + (uint64_t)(wave >= 2), 2 * gid2 + (uint64_t)(wave >= 2)};
             Lbl h[2] = {lzero(), lzero()};
-            if (on1 || on2) hash_n<2, TAB>(lt, c_rk, x, tw, h);
+            if (on1 || on2) hash_n<2, TAB>(lt, c_rk, x, tw, h, c_rk24);
             xbuf[wave * 64 + lane] = h[0];
             xbuf[256 + wave * 64 + lane] = h[1];
         } else {
@@ -294,7 +381,7 @@ struct GpuBackend {
             Lbl x = (wave & 1) ? ((wave < 2) ? b1 : b2) : ((wave < 2) ? a1 : a2);
             uint64_t tw = 2 * ((wave < 2) ? gid : gid2) + (uint64_t)(wave & 1);
             Lbl h = lzero();
-            if ((wave < 2) ? on1 : on2) hash_n<1, TAB>(lt, c_rk, &x, &tw, &h);
+            if ((wave < 2) ? on1 : on2) hash_n<1, TAB>(lt, c_rk, &x, &tw, &h, c_rk24);
             xbuf[(wave >> 1) * 256 + (wave & 1) * 64 + lane] = h;
         }
 #ifdef GC_STAMP
@@ -368,11 +455,19 @@ template <bool GARBLER, int TPB>
 __global__ void __launch_bounds__(TPB)
 gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
     __shared__ uint32_t lds_te0[2 * kLdsTabWords];   // Te0 | Te2: 128 KiB, one workgroup per CU
+#if GC_AES_TAB4
+    lds_tab4_fill(lds_te0);
+#else
     lds_tab2_fill(lds_te0);
+#endif
     const int lane = threadIdx.x & 63;
     const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wid >= nrec) return;
+#if GC_AES_TAB4
+    typedef GpuBackend<GARBLER, MODE_MAC, LdsTab4> B;
+#else
     typedef GpuBackend<GARBLER, MODE_MAC, LdsTab2> B;
+#endif
     B be;
     be.R = R;
     be.words = words;
@@ -383,7 +478,11 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
     be.lane = lane;
     be.wave = 0;
     be.xch = 0;
+#if GC_AES_TAB4
+    be.lt = lds_tab4_make(lds_te0);
+#else
     be.lt = lds_tab2_make(lds_te0);
+#endif
     Rec r = recs[wid];
     r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);
     r.dst = __builtin_amdgcn_readfirstlane(r.dst);
@@ -411,17 +510,20 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
 }
 
 // every other record type.  QUAD = true: one 4-wave workgroup per record (narrow, latency-bound
-// launches); QUAD = false: one wave per record, 4 records per workgroup (wide launches).
-template <bool GARBLER, bool QUAD>
-__global__ void __launch_bounds__(256)
+// launches; TPB = 256); QUAD = false: one wave per record, TPB / 64 records per workgroup (wide
+// launches).  TABV picks the AES tables: 4 = four rotated tables in 128 KiB (fewest instructions
+// per round; one workgroup per CU), 2 = two tables in 64 KiB (two 4-wave workgroups per CU).
+template <bool GARBLER, bool QUAD, int TABV, int TPB>
+__global__ void __launch_bounds__(TPB)
 gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *decode,
                uint64_t launch_step0, Lbl R, int w, int p) {
-    __shared__ uint32_t lds_te0[kLdsTabWords];
-    __shared__ Lbl lds_xch[QUAD ? 2 * 512 : 1];   // 16 KiB: 80 KiB per workgroup, two workgroups per CU
-    lds_tab_fill(lds_te0);
-    const uint32_t wid = QUAD ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);
+    typedef TabSel<TABV> TS;
+    __shared__ uint32_t lds_te0[TS::kWords];
+    __shared__ Lbl lds_xch[QUAD ? 2 * 512 : 1];   // 16 KiB exchange area of the 4-wave steps
+    TS::fill(lds_te0);
+    const uint32_t wid = QUAD ? blockIdx.x : blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (wid >= nrec) return;
-    typedef GpuBackend<GARBLER, QUAD ? MODE_QUAD : MODE_SOLO> B;
+    typedef GpuBackend<GARBLER, QUAD ? MODE_QUAD : MODE_SOLO, typename TS::T> B;
     B be;
     be.R = R;
     be.words = words;
@@ -432,7 +534,7 @@ gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *d
     be.wave = QUAD ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     be.xch = lds_xch;
     be.xsel = 0;
-    be.lt = lds_tab_make(lds_te0);
+    be.lt = TS::make(lds_te0);
     Rec r = recs[wid];
     r.op = __builtin_amdgcn_readfirstlane(r.op);
     r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);

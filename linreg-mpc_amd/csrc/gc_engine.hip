@@ -96,29 +96,50 @@ gc_input_kernel(Lbl *wordsG, Lbl *wordsE, const uint64_t *vals, uint32_t base, u
 
 __global__ void __launch_bounds__(1024)
 gc_aes_bench_kernel(uint32_t *out, int blocks_per_lane) {
-    __shared__ uint32_t lds_te0[kLdsTabWords];
-    lds_tab_fill(lds_te0);
-    LdsTab lt = lds_tab_make(lds_te0);
+    // the table variant of the MAC kernels (the roof they are priced against)
+#if GC_AES_TAB4
+    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    lds_tab4_fill(lds_te0);
+    LdsTab4 lt = lds_tab4_make(lds_te0);
+    typedef LdsTab4 TabT;
+#else
+    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    lds_tab2_fill(lds_te0);
+    LdsTab2 lt = lds_tab2_make(lds_te0);
+    typedef LdsTab2 TabT;
+#endif
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s[4][4];
     for (int b = 0; b < 4; b++) { s[b][0] = gid; s[b][1] = b; s[b][2] = gid * 2654435761u; s[b][3] = 0x9e3779b9u ^ b; }
-    for (int i = 0; i < blocks_per_lane; i += 4) aes_encrypt_n<4, LdsTab>(lt, c_rk, s);
+    for (int i = 0; i < blocks_per_lane; i += 4) aes_encrypt_n<4, TabT>(lt, c_rk, s, c_rk24);
     uint32_t acc = 0;
     for (int b = 0; b < 4; b++) acc ^= s[b][0] ^ s[b][1] ^ s[b][2] ^ s[b][3];
     out[gid] = acc;
 }
 
+// known-answer path: even blocks through the MAC kernels' table variant, odd blocks through the
+// single-table variant of the generic kernels, so both are pinned by the FIPS-197 vectors
 __global__ void __launch_bounds__(256)
 gc_aes_encrypt_kernel(const uint4 *in, uint4 *out, uint32_t n) {
-    __shared__ uint32_t lds_te0[kLdsTabWords];
+    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint4 v = i < n ? in[i] : make_uint4(0, 0, 0, 0);
+    uint32_t s[1][4] = {{v.x, v.y, v.z, v.w}}, s1[1][4] = {{v.x, v.y, v.z, v.w}};
+#if GC_AES_TAB4
+    lds_tab4_fill(lds_te0);
+    LdsTab4 l4 = lds_tab4_make(lds_te0);
+    aes_encrypt_n<1, LdsTab4>(l4, c_rk, s, c_rk24);
+#else
+    lds_tab2_fill(lds_te0);
+    LdsTab2 l2 = lds_tab2_make(lds_te0);
+    aes_encrypt_n<1, LdsTab2>(l2, c_rk, s, c_rk24);
+#endif
+    __syncthreads();
     lds_tab_fill(lds_te0);
     LdsTab lt = lds_tab_make(lds_te0);
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    aes_encrypt_n<1, LdsTab>(lt, c_rk, s1);
     if (i >= n) return;
-    uint4 v = in[i];
-    uint32_t s[1][4] = {{v.x, v.y, v.z, v.w}};
-    aes_encrypt_n<1, LdsTab>(lt, c_rk, s);
-    out[i] = make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
+    out[i] = (i & 1) ? make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]) : make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
 }
 
 // ------------------------------------------------------------------ program
@@ -366,6 +387,14 @@ static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
 // generic launches with at least this many records run one wave per record (throughput);
 // narrower ones run one 4-wave workgroup per record (latency)
 static constexpr uint32_t kWideLaunch = 2048;
+// wide launches: 12 records (waves) per workgroup share one 128 KiB four-table image
+#ifndef GC_TPB_WIDE
+#define GC_TPB_WIDE 768
+#endif
+static constexpr int kTpbWide = GC_TPB_WIDE;
+// 4-wave launches with at most one workgroup per CU use the four-table image (144 KiB per
+// workgroup); larger ones the two-table 64 KiB image, so that two workgroups share a CU
+static constexpr uint32_t kQuadOnePerCu = 256;
 // MAC launches with fewer records than this are latency-bound too (Cholesky / LDL^T stages at
 // small d): they run in the 4-wave mode instead of the throughput-oriented MAC kernel
 static constexpr uint32_t kNarrowMac = 1024;
@@ -378,12 +407,17 @@ static void launch_exec(lgc_solver *s, const Launch &L, Lbl *words, uint64_t *de
         hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
                            tab, L.step0, s->R, s->P.w, s->P.p);
     } else if (L.nrec >= kWideLaunch) {
-        dim3 grid((L.nrec + 3) / 4), block(256);
-        hipLaunchKernelGGL((gc_exec_kernel<G, false>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
+        constexpr unsigned per = kTpbWide / 64;
+        dim3 grid((L.nrec + per - 1) / per), block(kTpbWide);
+        hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
+                           tab, dec, L.step0, s->R, s->P.w, s->P.p);
+    } else if (L.nrec <= kQuadOnePerCu) {
+        dim3 grid(L.nrec), block(256);
+        hipLaunchKernelGGL((gc_exec_kernel<G, true, 4, 256>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
                            tab, dec, L.step0, s->R, s->P.w, s->P.p);
     } else {
         dim3 grid(L.nrec), block(256);
-        hipLaunchKernelGGL((gc_exec_kernel<G, true>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
+        hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
                            tab, dec, L.step0, s->R, s->P.w, s->P.p);
     }
 }

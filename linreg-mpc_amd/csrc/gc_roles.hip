@@ -193,10 +193,14 @@ static void party_launch(lgc_party *p, const Launch &L, Lbl *tab = 0) {
         hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(TPB), 0, 0, p->recs + L.first_rec, L.nrec,
                            p->words, tab, L.step0, p->R, p->P.w, p->P.p);
     } else if (L.nrec >= kWideLaunch) {
-        hipLaunchKernelGGL((gc_exec_kernel<G, false>), dim3((L.nrec + 3) / 4), dim3(256), 0, 0, p->recs + L.first_rec, L.nrec,
-                           p->words, tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
+        constexpr unsigned per = kTpbWide / 64;
+        hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(kTpbWide), 0, 0,
+                           p->recs + L.first_rec, L.nrec, p->words, tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
+    } else if (L.nrec <= kQuadOnePerCu) {
+        hipLaunchKernelGGL((gc_exec_kernel<G, true, 4, 256>), dim3(L.nrec), dim3(256), 0, 0, p->recs + L.first_rec, L.nrec, p->words,
+                           tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
     } else {
-        hipLaunchKernelGGL((gc_exec_kernel<G, true>), dim3(L.nrec), dim3(256), 0, 0, p->recs + L.first_rec, L.nrec, p->words,
+        hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256>), dim3(L.nrec), dim3(256), 0, 0, p->recs + L.first_rec, L.nrec, p->words,
                            tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
     }
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-for v in A Q; do
+for v in A S0 E1024 E512 G768; do
   if [ "$v" = "A" ]; then unset LGC_LIB; else export LGC_LIB=$PWD/scripts/exp/libs/lib_$v.so; fi
-  echo "== variant $v"; python scripts/gpu_launch_profile.py 1 cgd 1 | grep -E "^DIV|^MAX|^IPMAC|^MULSUB|total"; python scripts/gpu_launch_profile.py 100 cgd 15 | grep -E "^DIV|total"; python scripts/gpu_launch_profile.py 20 cholesky 0 | grep -E "^DIV|^SQRT|total"
+  echo "== variant $v"; python scripts/gpu_probe.py big | tail -3
 done
