@@ -250,9 +250,14 @@ struct lgc_solver {
     uint64_t *decG, *decE, *vals;
     Rec *recs;
     hipStream_t stream, streamE;
-    hipEvent_t ev0, ev1, evG[2], evE[2];
-    size_t slot_bytes;
-    int nslots;
+    hipEvent_t ev0, ev1, ev_in;
+    // garbled-table ring: launch i writes / reads [tab_off[i], tab_off[i] + its table bytes); before
+    // overwriting, the garbler waits for the evaluation of launch tab_wait[i] (the newest earlier
+    // launch whose region overlaps; the evaluator chain is in order, so older ones are done too)
+    size_t ring_bytes;
+    std::vector<size_t> tab_off;
+    std::vector<int64_t> tab_wait;
+    std::vector<hipEvent_t> evG, evE;     // per launch: tables written / tables consumed
     std::vector<hipEvent_t> evs;
     std::vector<uint64_t> hG, hE;
     std::vector<double> tG, tE;
@@ -260,8 +265,8 @@ struct lgc_solver {
     std::vector<double> t_iter;
     bool have_shares, ran;
     lgc_stats st;
-    lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), streamE(0), ev0(0), ev1(0), slot_bytes(0), nslots(1),
-                   have_shares(false), ran(false) { memset(&st, 0, sizeof(st)); evG[0] = evG[1] = evE[0] = evE[1] = 0; }
+    lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), streamE(0), ev0(0), ev1(0), ev_in(0), ring_bytes(0),
+                   have_shares(false), ran(false) { memset(&st, 0, sizeof(st)); }
 };
 
 extern "C" void lgc_solver_destroy(lgc_solver *s) {
@@ -278,7 +283,9 @@ extern "C" void lgc_solver_destroy(lgc_solver *s) {
     for (size_t i = 0; i < s->ev_iter.size(); i++) (void)hipEventDestroy(s->ev_iter[i]);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
-    for (int i = 0; i < 2; i++) { if (s->evG[i]) (void)hipEventDestroy(s->evG[i]); if (s->evE[i]) (void)hipEventDestroy(s->evE[i]); }
+    for (size_t i = 0; i < s->evG.size(); i++) (void)hipEventDestroy(s->evG[i]);
+    for (size_t i = 0; i < s->evE.size(); i++) (void)hipEventDestroy(s->evE[i]);
+    if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->streamE) (void)hipStreamDestroy(s->streamE);
     delete s;
@@ -343,16 +350,38 @@ static int solver_create(lgc_solver **out, int device, const lgc_system *sys, co
     TRY(hipStreamCreate(&s->streamE));
     TRY(hipEventCreate(&s->ev0));
     TRY(hipEventCreate(&s->ev1));
-    for (int i = 0; i < 2; i++) {
-        TRY(hipEventCreateWithFlags(&s->evG[i], hipEventDisableTiming));
-        TRY(hipEventCreateWithFlags(&s->evE[i], hipEventDisableTiming));
+    TRY(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
+    // Table ring of twice the largest launch: the garbler of a large (MAC) launch overlaps the
+    // evaluator of the previous one, and runs many small (divider, reveal) launches ahead of it.
+    {
+        const size_t align = 4096;
+        s->ring_bytes = 2 * ((tbytes + align - 1) / align * align) + align;
+        const size_t nl = P.launches.size();
+        s->tab_off.resize(nl);
+        s->tab_wait.assign(nl, -1);
+        std::vector<size_t> len(nl);
+        size_t head = 0;
+        for (size_t i = 0; i < nl; i++) {
+            len[i] = ((size_t)P.launches[i].steps * 128 * sizeof(Lbl) + align - 1) / align * align;
+            if (head + len[i] > s->ring_bytes) head = 0;
+            s->tab_off[i] = head;
+            head += len[i];
+        }
+        // newest earlier launch overlapping launch i; scanning back stops once a full ring has been passed
+        for (size_t i = 0; i < nl; i++) {
+            size_t seen = 0;
+            for (size_t j = i; j-- > 0 && seen <= s->ring_bytes;) {
+                seen += len[j];
+                if (len[i] && len[j] && s->tab_off[j] < s->tab_off[i] + len[i] && s->tab_off[i] < s->tab_off[j] + len[j]) {
+                    s->tab_wait[i] = (int64_t)j;
+                    break;
+                }
+            }
+        }
     }
-    // two table slots: the garbler of launch k+1 overlaps the evaluator of launch k
-    s->slot_bytes = tbytes ? tbytes : 16;
-    s->nslots = 2;
     TRY(hipMalloc(&s->wordsG, wbytes));
     TRY(hipMalloc(&s->wordsE, wbytes));
-    TRY(hipMalloc(&s->tab, s->slot_bytes * s->nslots));
+    TRY(hipMalloc(&s->tab, s->ring_bytes));
     TRY(hipMalloc(&s->decG, (P.n_reveal + 1) * sizeof(uint64_t)));
     TRY(hipMalloc(&s->decE, (P.n_reveal + 1) * sizeof(uint64_t)));
     TRY(hipMalloc(&s->vals, nin * sizeof(uint64_t)));
@@ -438,9 +467,16 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
         HIPCHK(hipEventCreate(&e));
         s->evs.push_back(e);
     }
+    while (s->evG.size() < nl) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        s->evG.push_back(a);
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        s->evE.push_back(b);
+    }
     // Garbler chain on `stream`, evaluator chain on `streamE`.  Evaluate(k) waits for garble(k);
-    // garble(k + nslots) waits for evaluate(k) (table slot reuse).  With profile != 0 the two
-    // chains are serialised so that per-kernel times are exclusive.
+    // garble(k) waits for the evaluation of the launch whose ring region it overwrites.  With
+    // profile != 0 the two chains are serialised so that per-kernel times are exclusive.
     hipStream_t sG = s->stream, sE = profile ? s->stream : s->streamE;
     while (s->ev_iter.size() < P.iter_launch.size()) {
         hipEvent_t e;
@@ -459,21 +495,20 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
                            P.in_base + t * P.word_stride, (uint32_t)nin, s->R, s->seed, P.w);
     }
     if (!profile) {   // the evaluator chain starts after the input labels are in place
-        HIPCHK(hipEventRecord(s->evG[0], sG));
-        HIPCHK(hipStreamWaitEvent(sE, s->evG[0], 0));
+        HIPCHK(hipEventRecord(s->ev_in, sG));
+        HIPCHK(hipStreamWaitEvent(sE, s->ev_in, 0));
     }
     for (size_t i = 0; i < nl; i++) {
         const Launch &L = P.launches[i];
-        const int slot = (int)(i % (size_t)s->nslots);
-        Lbl *tab = reinterpret_cast<Lbl *>(reinterpret_cast<char *>(s->tab) + (size_t)slot * s->slot_bytes);
+        Lbl *tab = reinterpret_cast<Lbl *>(reinterpret_cast<char *>(s->tab) + s->tab_off[i]);
         bool timed = profile || L.mac_only;
-        if (!profile && i >= (size_t)s->nslots) HIPCHK(hipStreamWaitEvent(sG, s->evE[slot], 0));
+        if (!profile && s->tab_wait[i] >= 0) HIPCHK(hipStreamWaitEvent(sG, s->evE[(size_t)s->tab_wait[i]], 0));
         if (timed) HIPCHK(hipEventRecord(s->evs[3 * i], sG));
         launch_exec<true>(s, L, s->wordsG, s->decG, tab, sG);
         if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
         if (!profile) {
-            HIPCHK(hipEventRecord(s->evG[slot], sG));
-            HIPCHK(hipStreamWaitEvent(sE, s->evG[slot], 0));
+            HIPCHK(hipEventRecord(s->evG[i], sG));
+            HIPCHK(hipStreamWaitEvent(sE, s->evG[i], 0));
         }
         if (profile) {
             launch_exec<false>(s, L, s->wordsE, s->decE, tab, sE);
@@ -481,14 +516,13 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
         } else {
             if (L.mac_only) HIPCHK(hipEventRecord(s->evs[3 * i + 2], sE));   // start of the evaluate kernel
             launch_exec<false>(s, L, s->wordsE, s->decE, tab, sE);
-            HIPCHK(hipEventRecord(s->evE[slot], sE));
+            HIPCHK(hipEventRecord(s->evE[i], sE));
         }
         while (next_iter < P.iter_launch.size() && P.iter_launch[next_iter] == i)
             HIPCHK(hipEventRecord(s->ev_iter[next_iter++], sE));
     }
     if (!profile) {   // join the evaluator chain back into the main stream
-        hipEvent_t last = s->evE[(nl - 1) % (size_t)s->nslots];
-        if (nl > 0) HIPCHK(hipStreamWaitEvent(sG, last, 0));
+        if (nl > 0) HIPCHK(hipStreamWaitEvent(sG, s->evE[nl - 1], 0));
     }
     HIPCHK(hipMemcpyAsync(s->hG.data(), s->decG, (P.n_reveal + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, sG));
     HIPCHK(hipMemcpyAsync(s->hE.data(), s->decE, (P.n_reveal + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, sG));

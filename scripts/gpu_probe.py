@@ -40,3 +40,10 @@ if "big" in args:
     run(500, "cgd", 1, profile=True)
 if "w32" in args:
     run(100, "cgd", 2, w=32, p=30)
+if "mid" in args:      # overlap of the garbler and evaluator chains on latency-bound circuits
+    for prof in (False, True, False):
+        run(100, "cgd", 15, profile=prof)
+    for prof in (False, True):
+        run(20, "cholesky", 0, profile=prof)
+if "trace" in args:
+    run(100, "cgd", 2)
