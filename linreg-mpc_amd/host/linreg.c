@@ -57,7 +57,7 @@ int main(int argc, char **argv) {
     int use_ot = 0, precision_phase2 = -1, w1 = 64, w2 = 64, ring_slots = 0;
     for (int i = 7; i < argc; i++) {
         if (!strcmp(argv[i], "--use_ot")) use_ot = 1;
-        else if (!strcmp(argv[i], "--table_ring")) ring_slots = 2;
+        else if (!strcmp(argv[i], "--table_ring")) ring_slots = 8;
         else if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) {}
         else if (sscanf(argv[i], "--width_phase1=%i", &w1) == 1) {}
         else if (sscanf(argv[i], "--width_phase2=%i", &w2) == 1) {}
@@ -108,7 +108,7 @@ int main(int argc, char **argv) {
     sys.normalize = 1; sys.reveal_inputs = 1; sys.trace = 1;
     /* table bytes per launch: socket mode moves them through host buffers; ring mode keeps them
      * in HBM (CSP and Evaluator on one node), so launches can be as large as the fused solver's */
-    const size_t kTableChunk = ring_slots > 0 ? (size_t)2 << 30 : (size_t)64 << 20;
+    const size_t kTableChunk = ring_slots > 0 ? (size_t)1 << 30 : (size_t)64 << 20;
 
     if (party == 1) {                                                /* CSP: garbler */
         uint8_t seed[16];

@@ -20,7 +20,7 @@ with open(path, "w") as f:
     f.write("%d\n" % d + " ".join(repr(float(v)) for v in sol) + " ")
 results = {}
 modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["socket", "ring"]
-for mode, opt in (("socket", []), ("ring", ["--table_ring=2"])):
+for mode, opt in (("socket", []), ("ring", ["--table_ring=%s" % os.environ.get("RING_SLOTS", "8")])):
     if mode not in modes:
         continue
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
