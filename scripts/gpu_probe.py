@@ -47,3 +47,6 @@ if "mid" in args:      # overlap of the garbler and evaluator chains on latency-
         run(20, "cholesky", 0, profile=prof)
 if "trace" in args:
     run(100, "cgd", 2)
+if "w32big" in args:
+    run(500, "cgd", 20, w=32, p=30)
+    run(500, "cgd", 20, w=32, p=30)
