@@ -1,6 +1,8 @@
 """Edge cases of the domain on the GPU path vs the oracle: smallest dimensions, a single share,
 extreme precisions, convergence to a zero residual (division by zero, unspecified in the reference
 and defined identically in oracle and circuit), extreme operand values."""
+import os
+
 import numpy as np
 import pytest
 
@@ -95,3 +97,13 @@ def test_rejects_unsupported_parameters(lgc):
         s.run()                      # shares not set
     with pytest.raises(lgc.LgcError):
         s.beta()                     # not run
+
+
+def test_gpu_randomised_parity_sweep():
+    """40 random configurations (tests/tools/gpu_fuzz.py) against the oracle, bit for bit"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "gpu_fuzz.py"), "40", "99"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "40 cases, 0 mismatches" in r.stdout
