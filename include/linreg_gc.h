@@ -251,6 +251,13 @@ int lgc_ot_labels_recv_finish(lgc_ot_receiver *r, const uint8_t *e_in, uint8_t *
 /* Stand-alone LDS T-table AES throughput (the "AES roofline" of the north
  * star): blocks_per_lane AES-128 encryptions in every lane of `waves` waves.
  * Returns blocks/second in *rate; *check gets an XOR checksum. */
+/* Page-locked host memory for buffers that are handed to the entry points above (tables, OT
+ * messages, phase-1 vectors): the copies to and from the GPU then run as DMA at PCIe speed instead
+ * of through a pageable staging copy.  Optional -- every entry point accepts ordinary memory.
+ * Returns NULL (and sets lgc_last_error) on failure. */
+void *lgc_host_alloc(size_t bytes);
+void lgc_host_free(void *p);
+
 int lgc_aes_bench(int device, int waves, int blocks_per_lane, double *rate, uint32_t *check);
 /* AES-128 of `n` 16-byte blocks with the fixed key on the device (known-answer tests). */
 int lgc_aes_encrypt(int device, const uint8_t *in, uint8_t *out, size_t n);

@@ -658,6 +658,14 @@ extern "C" int lgc_debug_spin(int device, int blocks, double ms) {
     return LGC_OK;
 }
 
+extern "C" void *lgc_host_alloc(size_t bytes) {
+    void *p = 0;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { lgc_fail(LGC_ENOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return 0; }
+    return p;
+}
+extern "C" void lgc_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 // --------------------------------------------------------- micro-benchmarks
 extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double *rate, uint32_t *check) {
     int rc = lgc_need_device(device);

@@ -115,7 +115,9 @@ int main(int argc, char **argv) {
         RAND_bytes(seed, sizeof seed);
         LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk));
         size_t bits = lgc_party_input_bits(party_obj);
-        uint8_t *m0 = malloc(bits * 16), *m1 = malloc(bits * 16), *u = malloc(lgc_ot_u_bytes(bits)), *e = malloc(bits * 32);
+        uint8_t *m0 = lgc_host_alloc(bits * 16), *m1 = lgc_host_alloc(bits * 16), *u = lgc_host_alloc(lgc_ot_u_bytes(bits)),
+                *e = lgc_host_alloc(bits * 32);
+        check(m0 && m1 && u && e, "%s", lgc_last_error());
         for (int k = 3; k <= c->num_parties; k++) {                  /* data providers in order (linear.oc:31) */
             uint8_t delta[16], seeds[128][16];
             check(!baseot_ext_sender(self, k, delta, seeds), "base OT with party %d failed", k);
@@ -127,7 +129,7 @@ int main(int argc, char **argv) {
             check(!send_blob(self, k, e, bits * 32), "OT: could not send to party %d", k);
             lgc_ot_sender_destroy(S);
         }
-        free(m0); free(m1); free(u); free(e);
+        lgc_host_free(m0); lgc_host_free(m1); lgc_host_free(u); lgc_host_free(e);
         check(!tables_send(self, 2, party_obj, ring_slots, kTableChunk), "could not stream the garbled tables");
         size_t nr = lgc_party_num_reveal(party_obj);
         uint64_t *dec = malloc((nr + 1) * 8);

@@ -155,6 +155,8 @@ int run_trusted_initializer(node *self, config *c, int w1, int device) {
      * randomness in batches on the GPU and send the two messages of every pair in that order */
     size_t cap = 0, np = 0;
     int *pa_of = NULL, *pb_of = NULL;
+    ti_sender *snd = NULL;
+    pthread_t *tid = NULL;
     for (size_t i = 0; i <= c->d; i++)
         for (size_t j = 0; j <= i && j < c->d; j++) {
             int pa = config_owner(c, i), pb = config_owner(c, j);
@@ -171,8 +173,8 @@ int run_trusted_initializer(node *self, config *c, int w1, int device) {
      * sequences are independent: one sender thread per data provider encodes and sends that
      * provider's messages of the batch, in order. */
     const int P = c->num_parties - 2;
-    ti_sender *snd = calloc((size_t)P, sizeof *snd);
-    pthread_t *tid = calloc((size_t)P, sizeof *tid);
+    snd = calloc((size_t)P, sizeof *snd);
+    tid = calloc((size_t)P, sizeof *tid);
     for (size_t q0 = 0; q0 < np; q0 += batch) {
         size_t nb = np - q0 < batch ? np - q0 : batch;
         LGC(lgc_ti_generate(device, seed, q0, nb, n, w1, x, y, r, xyr));
@@ -372,10 +374,11 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
                 size_t per = ((size_t)1 << 26) / (n * (size_t)w1);
                 if (per < 1) per = 1;
                 if (per > npairs) per = npairs;
-                uint64_t *vals = malloc(per * n * 8), *shares = malloc(npairs * 8);
+                uint64_t *vals = lgc_host_alloc(per * n * 8), *shares = malloc(npairs * 8);
                 const uint64_t mmax = (uint64_t)per * n * (uint64_t)w1;
-                uint8_t *u = malloc(lgc_ot_u_bytes(mmax));
-                uint64_t *yv = malloc(mmax * 8);
+                uint8_t *u = lgc_host_alloc(lgc_ot_u_bytes(mmax));
+                uint64_t *yv = lgc_host_alloc(mmax * 8);
+                check(vals && u && yv, "%s", lgc_last_error());
                 lgc_ot_sender *S = 0;
                 lgc_ot_receiver *R = 0;
                 if (i_am_sender) {
@@ -410,7 +413,7 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
                     if (ri[q] < d && rj[q] < d) share_A[idx(ri[q], rj[q])] += shares[q];
                     else share_b[ri[q] < d ? ri[q] : rj[q]] += shares[q];
                 }
-                free(ri); free(rj); free(vals); free(shares); free(u); free(yv);
+                free(ri); free(rj); lgc_host_free(vals); free(shares); lgc_host_free(u); lgc_host_free(yv);
             }
         if (w1 == 32) { for (size_t k = 0; k < T; k++) share_A[k] &= 0xffffffffull; for (size_t k = 0; k < d; k++) share_b[k] &= 0xffffffffull; }
     }
