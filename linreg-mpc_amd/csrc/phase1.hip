@@ -82,30 +82,49 @@ p1_gram_kernel(const int64_t *X, size_t n, size_t ld, const uint32_t *cols, uint
 }
 
 // ---- diagonal: xy += pow(fixed_to_double(x_k, p), 2) * pow(2, p), k ascending, in IEEE double;
-// share = double_to_fixed(xy / d, p)  (src/phase1.c:562-567).  One thread per column; explicit
-// round-to-nearest multiplies/adds so that no FMA contraction can change the rounding.
-__global__ void p1_diag_kernel(const int64_t *X, size_t n, size_t ld, const uint32_t *cols, uint32_t L,
-                               int p, int w, double normalizer2, uint64_t *out) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= L) return;
-    const uint32_t c = cols[t];
+// share = double_to_fixed(xy / d, p)  (src/phase1.c:562-567).  Explicit round-to-nearest
+// multiplies/adds so that no FMA contraction can change the rounding.  Only the additions are
+// order-dependent: a workgroup owns 16 columns; 15 loader waves compute the terms of a 600-row
+// chunk in parallel into LDS while wave 0 adds the previous chunk's terms in k order (the bound
+// is n dependent double additions per column).
+#define P1_DC 16        /* columns per workgroup */
+#define P1_DR 600       /* rows per chunk: 15 waves x 4 row phases x 10 rows */
+__global__ void __launch_bounds__(1024)
+p1_diag_kernel(const int64_t *X, size_t n, size_t ld, const uint32_t *cols, uint32_t L,
+               int p, int w, double normalizer2, uint64_t *out) {
+    __shared__ double term[2][P1_DR][P1_DC];      // 150 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * P1_DC + (lane & 15);
+    const bool live = t < L;
+    const uint32_t c = live ? cols[t] : 0;
     const double scale = (double)(1ll << p);
+    const size_t nchunks = (n + P1_DR - 1) / P1_DR;
     double xy = 0.0;
-    size_t k = 0;
-    for (; k + 8 <= n; k += 8) {   // 8 independent loads in flight; the additions stay in k order
-        int64_t x[8];
+    for (size_t ch = 0; ch <= nchunks; ch++) {
+        if (wave > 0 && ch < nchunks) {             // loaders: chunk ch -> term[ch & 1]
+            const size_t k0 = ch * P1_DR;
+            const int r0 = (wave - 1) * 4 + (lane >> 4);          // 0..59
+            int64_t x[10];
 #pragma unroll
-        for (int u = 0; u < 8; u++) x[u] = X[(k + u) * ld + c];
+            for (int u = 0; u < 10; u++) {
+                size_t k = k0 + (size_t)(r0 + 60 * u);
+                x[u] = (live && k < n) ? X[k * ld + c] : 0;
+            }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            double v = __ddiv_rn((double)x[u], scale);
-            xy = __dadd_rn(xy, __dmul_rn(__dmul_rn(v, v), scale));
+            for (int u = 0; u < 10; u++) {
+                double v = __ddiv_rn((double)x[u], scale);
+                term[ch & 1][r0 + 60 * u][lane & 15] = __dmul_rn(__dmul_rn(v, v), scale);
+            }
         }
+        if (wave == 0 && ch > 0 && lane < P1_DC) {  // adder: chunk ch - 1, rows in k order
+            const size_t k0 = (ch - 1) * P1_DR;
+            const int rows = (int)((n - k0 < (size_t)P1_DR) ? n - k0 : (size_t)P1_DR);
+            const double *tp = &term[(ch - 1) & 1][0][lane];
+            for (int r = 0; r < rows; r++) xy = __dadd_rn(xy, tp[r * P1_DC]);
+        }
+        __syncthreads();
     }
-    for (; k < n; k++) {
-        double v = __ddiv_rn((double)X[k * ld + c], scale);
-        xy = __dadd_rn(xy, __dmul_rn(__dmul_rn(v, v), scale));
-    }
+    if (wave != 0 || lane >= P1_DC || !live) return;
     double tq = __dmul_rn(__ddiv_rn(xy, normalizer2), scale);
     uint64_t r;
     if (w == 32) {   // (int32_t) cast with the x86 "integer indefinite" result when out of range
@@ -242,7 +261,7 @@ extern "C" int lgc_p1_local(lgc_p1 *h, size_t c0, size_t c1, int with_y, uint64_
     ksplit = (h->n + kchunk - 1) / kchunk;
     hipLaunchKernelGGL(p1_gram_kernel, dim3(tiles, tiles, (unsigned)ksplit), dim3(256), 0, 0, h->X, h->n, h->d + 1, dcols, L,
                        dC, kchunk);
-    hipLaunchKernelGGL(p1_diag_kernel, dim3((own + 63) / 64), dim3(64), 0, 0, h->X, h->n, h->d + 1, dcols, own, h->p, h->w,
+    hipLaunchKernelGGL(p1_diag_kernel, dim3((own + P1_DC - 1) / P1_DC), dim3(1024), 0, 0, h->X, h->n, h->d + 1, dcols, own, h->p, h->w,
                        (double)h->d, ddiag);
     std::vector<uint64_t> C((size_t)L * L), diag(own);
     P1CHK(hipMemcpy(C.data(), dC, C.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
