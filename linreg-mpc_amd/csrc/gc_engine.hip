@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/linreg_gc.h"
+#include "hip_scope.h"
 #include "gc_device.h"
 #include "gc_program.h"
 
@@ -145,6 +146,7 @@ gc_aes_encrypt_kernel(const uint4 *in, uint4 *out, uint32_t n) {
 // ------------------------------------------------------------------ program
 struct lgc_program {
     Program P;
+    std::vector<lgc_launch> launch_view;   // filled by lgc_program_launches; lives as long as the program
 };
 
 static int check_system(const lgc_system *sys) {
@@ -229,8 +231,9 @@ static_assert(sizeof(lgc_record) == sizeof(Rec), "record layout");
 extern "C" const lgc_record *lgc_program_records(const lgc_program *p) {
     return reinterpret_cast<const lgc_record *>(p->P.recs.data());
 }
-static std::vector<lgc_launch> g_launch_tmp;
-extern "C" const lgc_launch *lgc_program_launches(const lgc_program *p) {
+extern "C" const lgc_launch *lgc_program_launches(const lgc_program *cp) {
+    lgc_program *p = const_cast<lgc_program *>(cp);
+    std::vector<lgc_launch> &g_launch_tmp = p->launch_view;
     g_launch_tmp.resize(p->P.launches.size());
     for (size_t i = 0; i < g_launch_tmp.size(); i++) {
         const Launch &L = p->P.launches[i];
@@ -668,6 +671,7 @@ extern "C" void lgc_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 // --------------------------------------------------------- micro-benchmarks
 extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double *rate, uint32_t *check) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     int rc = lgc_need_device(device);
     if (rc) return rc;
     rc = lgc_upload_constants();
@@ -676,7 +680,7 @@ extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double 
     blocks_per_lane &= ~3;
     int nblk = waves / 16;
     uint32_t *out = 0;
-    HIPCHK(hipMalloc(&out, (size_t)nblk * 1024 * 4));
+    HIPCHK(hipMalloc(&out, (size_t)nblk * 1024 * 4)); dev_guard.add(out);
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a));
     HIPCHK(hipEventCreate(&b));
@@ -693,24 +697,24 @@ extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double 
     for (size_t i = 0; i < h.size(); i++) c ^= h[i];
     if (check) *check = c;
     if (rate) *rate = (double)nblk * 1024.0 * (double)blocks_per_lane / (ms * 1e-3);
-    (void)hipFree(out);
+
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     return LGC_OK;
 }
 
 extern "C" int lgc_aes_encrypt(int device, const uint8_t *in, uint8_t *out, size_t n) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     int rc = lgc_need_device(device);
     if (rc) return rc;
     rc = lgc_upload_constants();
     if (rc) return rc;
     uint4 *di = 0, *dout = 0;
-    HIPCHK(hipMalloc(&di, n * 16));
-    HIPCHK(hipMalloc(&dout, n * 16));
+    HIPCHK(hipMalloc(&di, n * 16)); dev_guard.add(di);
+    HIPCHK(hipMalloc(&dout, n * 16)); dev_guard.add(dout);
     HIPCHK(hipMemcpy(di, in, n * 16, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(gc_aes_encrypt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, di, dout, (uint32_t)n);
     HIPCHK(hipMemcpy(out, dout, n * 16, hipMemcpyDeviceToHost));
-    (void)hipFree(di);
-    (void)hipFree(dout);
+
     return LGC_OK;
 }

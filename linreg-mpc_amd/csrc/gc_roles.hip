@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/linreg_gc.h"
+#include "hip_scope.h"
 #include "gc_device.h"
 #include "gc_program.h"
 
@@ -142,20 +143,21 @@ extern "C" int lgc_party_iteration_marks(const lgc_party *p, uint32_t *launch, u
 }
 
 static int export_labels(lgc_party *p, size_t share, const uint64_t *values, uint8_t *m0, uint8_t *m1) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "only the garbler owns label pairs");
     if (share >= p->P.nshares) return lgc_fail(LGC_EINVAL, "share index out of range");
     RCHK(hipSetDevice(p->device));
     const uint32_t n = (uint32_t)(p->P.T + p->P.d);
     const size_t bits = (size_t)n * p->P.w;
     Lbl *d0 = 0, *d1 = 0; uint64_t *dv = 0;
-    RCHK(hipMalloc(&d0, bits * 16));
-    if (m1) RCHK(hipMalloc(&d1, bits * 16));
-    if (values) { RCHK(hipMalloc(&dv, n * 8)); RCHK(hipMemcpy(dv, values, n * 8, hipMemcpyHostToDevice)); }
+    RCHK(hipMalloc(&d0, bits * 16)); dev_guard.add(d0);
+    if (m1) RCHK(hipMalloc(&d1, bits * 16)); dev_guard.add(d1);
+    if (values) { RCHK(hipMalloc(&dv, n * 8)); dev_guard.add(dv); RCHK(hipMemcpy(dv, values, n * 8, hipMemcpyHostToDevice)); }
     hipLaunchKernelGGL(gc_export_pairs_kernel, dim3((unsigned)((bits + 255) / 256)), dim3(256), 0, 0, p->words,
                        p->P.in_base + (uint32_t)(share * n), n, p->R, p->P.w, dv, d0, d1);
     RCHK(hipMemcpy(m0, d0, bits * 16, hipMemcpyDeviceToHost));
     if (m1) RCHK(hipMemcpy(m1, d1, bits * 16, hipMemcpyDeviceToHost));
-    (void)hipFree(d0); if (d1) (void)hipFree(d1); if (dv) (void)hipFree(dv);
+
     return LGC_OK;
 }
 extern "C" int lgc_party_input_pairs(lgc_party *p, size_t share, uint8_t *m0, uint8_t *m1) {
@@ -167,6 +169,7 @@ extern "C" int lgc_party_encode_inputs(lgc_party *p, size_t share, const uint64_
     return export_labels(p, share, values, labels_out, 0);
 }
 extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint8_t *labels) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     if (!p || !labels) return lgc_fail(LGC_EINVAL, "null argument");
     if (p->role != LGC_ROLE_EVALUATOR) return lgc_fail(LGC_ESTATE, "only the evaluator imports labels");
     if (share >= p->P.nshares) return lgc_fail(LGC_EINVAL, "share index out of range");
@@ -174,12 +177,12 @@ extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint
     const uint32_t n = (uint32_t)(p->P.T + p->P.d);
     const size_t bits = (size_t)n * p->P.w;
     Lbl *d = 0;
-    RCHK(hipMalloc(&d, bits * 16));
+    RCHK(hipMalloc(&d, bits * 16)); dev_guard.add(d);
     RCHK(hipMemcpy(d, labels, bits * 16, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(gc_import_labels_kernel, dim3((unsigned)((n * 64u + 255) / 256)), dim3(256), 0, 0, p->words,
                        p->P.in_base + (uint32_t)(share * n), n, p->P.w, d);
     RCHK(hipDeviceSynchronize());
-    (void)hipFree(d);
+
     p->labels_ready = true;
     return LGC_OK;
 }

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/linreg_gc.h"
+#include "hip_scope.h"
 #include "gc_device.h"
 
 using namespace gc;
@@ -288,10 +289,11 @@ static inline uint64_t round128(uint64_t m) { return (m + 127) / 128 * 128; }
 
 // receiver: columns + u + transpose for choice bits already on the device (cbits: padded to m128 blocks)
 static int recv_extend(lgc_ot_receiver *r, uint64_t m, uint8_t *u_out) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     const uint32_t m128 = (uint32_t)(round128(m) / 128);
     uint4 *T0 = 0, *U = 0;
-    OTCHK(hipMalloc(&T0, (size_t)128 * m128 * 16));
-    OTCHK(hipMalloc(&U, (size_t)128 * m128 * 16));
+    OTCHK(hipMalloc(&T0, (size_t)128 * m128 * 16)); dev_guard.add(T0);
+    OTCHK(hipMalloc(&U, (size_t)128 * m128 * 16)); dev_guard.add(U);
     OTCHK(hipMalloc(&r->rows, (size_t)m128 * 128 * 16));
     unsigned gx = (m128 + 1023) / 1024; if (gx > 64) gx = 64;
     hipLaunchKernelGGL((ot_cols_kernel<0>), dim3(gx, 128), dim3(1024), 0, 0, r->rk0, r->rk1, r->ctr, m128,
@@ -300,16 +302,17 @@ static int recv_extend(lgc_ot_receiver *r, uint64_t m, uint8_t *u_out) {
     hipLaunchKernelGGL(ot_transpose_kernel, dim3((unsigned)((mp / 64 + 3) / 4)), dim3(256), 0, 0, (const uint64_t *)T0, m128,
                        r->rows, mp);
     OTCHK(hipMemcpy(u_out, U, (size_t)128 * m128 * 16, hipMemcpyDeviceToHost));
-    (void)hipFree(T0); (void)hipFree(U);
+
     r->ctr += m128;
     return LGC_OK;
 }
 static int send_extend(lgc_ot_sender *s, uint64_t m, const uint8_t *u_in, uint4 **rows_out) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     const uint32_t m128 = (uint32_t)(round128(m) / 128);
     uint4 *Q = 0, *U = 0, *rows = 0;
-    OTCHK(hipMalloc(&Q, (size_t)128 * m128 * 16));
-    OTCHK(hipMalloc(&U, (size_t)128 * m128 * 16));
-    OTCHK(hipMalloc(&rows, (size_t)m128 * 128 * 16));
+    OTCHK(hipMalloc(&Q, (size_t)128 * m128 * 16)); dev_guard.add(Q);
+    OTCHK(hipMalloc(&U, (size_t)128 * m128 * 16)); dev_guard.add(U);
+    OTCHK(hipMalloc(&rows, (size_t)m128 * 128 * 16)); dev_guard.add(rows);
     OTCHK(hipMemcpy(U, u_in, (size_t)128 * m128 * 16, hipMemcpyHostToDevice));
     unsigned gx = (m128 + 1023) / 1024; if (gx > 64) gx = 64;
     hipLaunchKernelGGL((ot_cols_kernel<1>), dim3(gx, 128), dim3(1024), 0, 0, s->rk, (const uint32_t *)0, s->ctr, m128,
@@ -317,8 +320,9 @@ static int send_extend(lgc_ot_sender *s, uint64_t m, const uint8_t *u_in, uint4 
     const uint64_t mp = (uint64_t)m128 * 128;
     hipLaunchKernelGGL(ot_transpose_kernel, dim3((unsigned)((mp / 64 + 3) / 4)), dim3(256), 0, 0, (const uint64_t *)Q, m128,
                        rows, mp);
-    (void)hipFree(Q); (void)hipFree(U);
+
     s->ctr += m128;
+    dev_guard.release(rows);   // ownership passes to the caller
     *rows_out = rows;
     return LGC_OK;
 }
@@ -346,6 +350,7 @@ extern "C" int lgc_ot_gilboa_recv_start(lgc_ot_receiver *r, const uint64_t *a, s
 }
 extern "C" int lgc_ot_gilboa_send(lgc_ot_sender *s, const uint64_t *b, size_t npairs, size_t n, int width, const uint8_t *u_in,
                                   uint64_t *y_out, uint64_t *shares) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     if (!s || !b || !u_in || !y_out || !shares) return lgc_fail(LGC_EINVAL, "null argument");
     if (width != 32 && width != 64) return lgc_fail(LGC_EINVAL, "width must be 32 or 64");
     OTCHK(hipSetDevice(s->device));
@@ -353,8 +358,9 @@ extern "C" int lgc_ot_gilboa_send(lgc_ot_sender *s, const uint64_t *b, size_t np
     uint4 *rows = 0;
     int rc = send_extend(s, m, u_in, &rows);
     if (rc) return rc;
+    dev_guard.add(rows);
     uint64_t *db = 0, *dy = 0, *dsh = 0;
-    OTCHK(hipMalloc(&db, nw * 8)); OTCHK(hipMalloc(&dy, m * 8)); OTCHK(hipMalloc(&dsh, npairs * 8));
+    OTCHK(hipMalloc(&db, nw * 8)); dev_guard.add(db); OTCHK(hipMalloc(&dy, m * 8)); dev_guard.add(dy); OTCHK(hipMalloc(&dsh, npairs * 8)); dev_guard.add(dsh);
     OTCHK(hipMemcpy(db, b, nw * 8, hipMemcpyHostToDevice));
     OTCHK(hipMemset(dsh, 0, npairs * 8));
     unsigned gx = (unsigned)((mpp + 1023) / 1024); if (gx > 256) gx = 256;
@@ -363,16 +369,17 @@ extern "C" int lgc_ot_gilboa_send(lgc_ot_sender *s, const uint64_t *b, size_t np
     OTCHK(hipMemcpy(y_out, dy, m * 8, hipMemcpyDeviceToHost));
     OTCHK(hipMemcpy(shares, dsh, npairs * 8, hipMemcpyDeviceToHost));
     if (width == 32) for (size_t q = 0; q < npairs; q++) shares[q] &= 0xffffffffull;
-    (void)hipFree(rows); (void)hipFree(db); (void)hipFree(dy); (void)hipFree(dsh);
+
     s->tweak += m;
     return LGC_OK;
 }
 extern "C" int lgc_ot_gilboa_recv_finish(lgc_ot_receiver *r, const uint64_t *y_in, uint64_t *shares) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     if (!r || !y_in || !shares) return lgc_fail(LGC_EINVAL, "null argument");
     if (!r->rows || !r->avals) return lgc_fail(LGC_ESTATE, "no Gilboa receive in flight");
     OTCHK(hipSetDevice(r->device));
     uint64_t *dy = 0, *dsh = 0;
-    OTCHK(hipMalloc(&dy, r->m * 8)); OTCHK(hipMalloc(&dsh, r->npairs * 8));
+    OTCHK(hipMalloc(&dy, r->m * 8)); dev_guard.add(dy); OTCHK(hipMalloc(&dsh, r->npairs * 8)); dev_guard.add(dsh);
     OTCHK(hipMemcpy(dy, y_in, r->m * 8, hipMemcpyHostToDevice));
     OTCHK(hipMemset(dsh, 0, r->npairs * 8));
     const uint64_t mpp = r->n * (uint64_t)r->w;
@@ -381,7 +388,7 @@ extern "C" int lgc_ot_gilboa_recv_finish(lgc_ot_receiver *r, const uint64_t *y_i
                        r->tweak_cur, dy, dsh);
     OTCHK(hipMemcpy(shares, dsh, r->npairs * 8, hipMemcpyDeviceToHost));
     if (r->w == 32) for (size_t q = 0; q < r->npairs; q++) shares[q] &= 0xffffffffull;
-    (void)hipFree(dy); (void)hipFree(dsh);
+
     recv_drop_state(r);
     return LGC_OK;
 }
@@ -404,33 +411,36 @@ extern "C" int lgc_ot_labels_recv_start(lgc_ot_receiver *r, const uint8_t *choic
     return LGC_OK;
 }
 extern "C" int lgc_ot_labels_send(lgc_ot_sender *s, const uint8_t *msg0, const uint8_t *msg1, size_t m, const uint8_t *u_in, uint8_t *e_out) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     if (!s || !msg0 || !msg1 || !u_in || !e_out) return lgc_fail(LGC_EINVAL, "null argument");
     OTCHK(hipSetDevice(s->device));
     uint4 *rows = 0;
     int rc = send_extend(s, m, u_in, &rows);
     if (rc) return rc;
+    dev_guard.add(rows);
     uint4 *d0 = 0, *d1 = 0, *de = 0;
-    OTCHK(hipMalloc(&d0, m * 16)); OTCHK(hipMalloc(&d1, m * 16)); OTCHK(hipMalloc(&de, m * 32));
+    OTCHK(hipMalloc(&d0, m * 16)); dev_guard.add(d0); OTCHK(hipMalloc(&d1, m * 16)); dev_guard.add(d1); OTCHK(hipMalloc(&de, m * 32)); dev_guard.add(de);
     OTCHK(hipMemcpy(d0, msg0, m * 16, hipMemcpyHostToDevice));
     OTCHK(hipMemcpy(d1, msg1, m * 16, hipMemcpyHostToDevice));
     unsigned gx = (unsigned)((m + 1023) / 1024); if (gx > 512) gx = 512;
     hipLaunchKernelGGL(ot_labels_send_kernel, dim3(gx), dim3(1024), 0, 0, rows, s->delta, d0, d1, (uint64_t)m, s->tweak, de);
     OTCHK(hipMemcpy(e_out, de, m * 32, hipMemcpyDeviceToHost));
-    (void)hipFree(rows); (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(de);
+
     s->tweak += m;
     return LGC_OK;
 }
 extern "C" int lgc_ot_labels_recv_finish(lgc_ot_receiver *r, const uint8_t *e_in, uint8_t *out) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     if (!r || !e_in || !out) return lgc_fail(LGC_EINVAL, "null argument");
     if (!r->rows || r->avals) return lgc_fail(LGC_ESTATE, "no label receive in flight");
     OTCHK(hipSetDevice(r->device));
     uint4 *de = 0, *dout = 0;
-    OTCHK(hipMalloc(&de, r->m * 32)); OTCHK(hipMalloc(&dout, r->m * 16));
+    OTCHK(hipMalloc(&de, r->m * 32)); dev_guard.add(de); OTCHK(hipMalloc(&dout, r->m * 16)); dev_guard.add(dout);
     OTCHK(hipMemcpy(de, e_in, r->m * 32, hipMemcpyHostToDevice));
     unsigned gx = (unsigned)((r->m + 1023) / 1024); if (gx > 512) gx = 512;
     hipLaunchKernelGGL(ot_labels_recv_kernel, dim3(gx), dim3(1024), 0, 0, r->rows, r->cbits, de, r->m, r->tweak_cur, dout);
     OTCHK(hipMemcpy(out, dout, r->m * 16, hipMemcpyDeviceToHost));
-    (void)hipFree(de); (void)hipFree(dout);
+
     recv_drop_state(r);
     return LGC_OK;
 }

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/linreg_gc.h"
+#include "hip_scope.h"
 #include "gc_device.h"
 
 using namespace gc;
@@ -237,6 +238,7 @@ static uint64_t maskw(int w) { return w == 32 ? 0xffffffffull : ~0ull; }
 
 // shares of the block a data provider can compute alone (src/phase1.c:562-571; 359-384 in OT mode)
 extern "C" int lgc_p1_local(lgc_p1 *h, size_t c0, size_t c1, int with_y, uint64_t *out_A, uint64_t *out_b) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     if (!h || !out_A) return lgc_fail(LGC_EINVAL, "null argument");
     if (c0 >= c1 || c1 > h->d) return lgc_fail(LGC_EINVAL, "bad column range");
     if (with_y && (!h->have_y || !out_b)) return lgc_fail(LGC_EINVAL, "y requested but not set");
@@ -247,9 +249,9 @@ extern "C" int lgc_p1_local(lgc_p1 *h, size_t c0, size_t c1, int with_y, uint64_
     if (with_y) cols[own] = (uint32_t)h->d;
     uint32_t *dcols = 0;
     uint64_t *dC = 0, *ddiag = 0;
-    P1CHK(hipMalloc(&dcols, L * sizeof(uint32_t)));
-    P1CHK(hipMalloc(&dC, (size_t)L * L * sizeof(uint64_t)));
-    P1CHK(hipMalloc(&ddiag, own * sizeof(uint64_t)));
+    P1CHK(hipMalloc(&dcols, L * sizeof(uint32_t))); dev_guard.add(dcols);
+    P1CHK(hipMalloc(&dC, (size_t)L * L * sizeof(uint64_t))); dev_guard.add(dC);
+    P1CHK(hipMalloc(&ddiag, own * sizeof(uint64_t))); dev_guard.add(ddiag);
     P1CHK(hipMemcpy(dcols, cols.data(), L * sizeof(uint32_t), hipMemcpyHostToDevice));
     P1CHK(hipMemset(dC, 0, (size_t)L * L * sizeof(uint64_t)));
     const uint32_t tiles = (L + 63) / 64;
@@ -266,7 +268,7 @@ extern "C" int lgc_p1_local(lgc_p1 *h, size_t c0, size_t c1, int with_y, uint64_
     std::vector<uint64_t> C((size_t)L * L), diag(own);
     P1CHK(hipMemcpy(C.data(), dC, C.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
     P1CHK(hipMemcpy(diag.data(), ddiag, own * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    (void)hipFree(dcols); (void)hipFree(dC); (void)hipFree(ddiag);
+
     const uint64_t m = maskw(h->w);
     for (uint32_t i = 0; i < own; i++)
         for (uint32_t j = 0; j <= i; j++)
@@ -364,6 +366,7 @@ extern "C" int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const
 // by `seed`; xy_minus_r[q] = <x,y> - r.  Stream position of pair q is q * (2n + 1) words.
 extern "C" int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t first_pair, size_t npairs, size_t n, int width,
                                uint64_t *x, uint64_t *y, uint64_t *r, uint64_t *xy_minus_r) {
+    DevFree dev_guard;   // temporary device buffers are released on every return path
     if (!seed || !x || !y || !r || !xy_minus_r) return lgc_fail(LGC_EINVAL, "null argument");
     if (width != 32 && width != 64) return lgc_fail(LGC_EINVAL, "width must be 32 or 64");
     if (npairs == 0) return LGC_OK;
@@ -374,19 +377,19 @@ extern "C" int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t firs
     AesTables t;
     aes_build_tables(t, seed);
     uint32_t *drk = 0;
-    P1CHK(hipMalloc(&drk, sizeof(t.rk)));
+    P1CHK(hipMalloc(&drk, sizeof(t.rk))); dev_guard.add(drk);
     P1CHK(hipMemcpy(drk, t.rk, sizeof(t.rk), hipMemcpyHostToDevice));
     const size_t wb = width / 8;
     const uint64_t words_per_pair = 2 * n + 1;
     const uint64_t byte0 = first_pair * words_per_pair * wb, byte1 = (first_pair + npairs) * words_per_pair * wb;
     const uint64_t blk0 = byte0 / 16, blk1 = (byte1 + 15) / 16;
     uint4 *dks = 0;
-    P1CHK(hipMalloc(&dks, (blk1 - blk0) * 16));
+    P1CHK(hipMalloc(&dks, (blk1 - blk0) * 16)); dev_guard.add(dks);
     hipLaunchKernelGGL(ti_prg_kernel, dim3(512), dim3(1024), 0, 0, drk, blk0, blk1 - blk0, dks);
     const uint64_t m = maskw(width);
     uint64_t *dA = 0, *dB = 0, *dr = 0, *dout = 0;
     size_t bytes = npairs * n * 8;
-    P1CHK(hipMalloc(&dA, bytes)); P1CHK(hipMalloc(&dB, bytes)); P1CHK(hipMalloc(&dr, npairs * 8)); P1CHK(hipMalloc(&dout, npairs * 8));
+    P1CHK(hipMalloc(&dA, bytes)); dev_guard.add(dA); P1CHK(hipMalloc(&dB, bytes)); dev_guard.add(dB); P1CHK(hipMalloc(&dr, npairs * 8)); dev_guard.add(dr); P1CHK(hipMalloc(&dout, npairs * 8)); dev_guard.add(dout);
     hipLaunchKernelGGL(ti_unpack_kernel, dim3(1024), dim3(256), 0, 0, (const uint8_t *)dks, (size_t)(byte0 - blk0 * 16), npairs, n,
                        (int)wb, dA, dB, dr);
     P1CHK(hipMemset(dout, 0, npairs * 8));
@@ -397,8 +400,7 @@ extern "C" int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t firs
     P1CHK(hipMemcpy(y, dB, bytes, hipMemcpyDeviceToHost));
     P1CHK(hipMemcpy(r, dr, npairs * 8, hipMemcpyDeviceToHost));
     P1CHK(hipMemcpy(xy_minus_r, dout, npairs * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(dks); (void)hipFree(drk);
-    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dr); (void)hipFree(dout);
+
     for (size_t q = 0; q < npairs; q++) xy_minus_r[q] = (xy_minus_r[q] - r[q]) & m;
     return LGC_OK;
 }
