@@ -144,6 +144,11 @@ void lgc_program_destroy(lgc_program *p);
 int lgc_program_info_get(const lgc_program *p, lgc_program_info *info);
 const lgc_record *lgc_program_records(const lgc_program *p);
 const lgc_launch *lgc_program_launches(const lgc_program *p);
+/* The co-located solver's garbled-table ring for this program: launch i owns bytes
+ * [offsets[i], offsets[i] + 2048 * steps_i) (rounded up to 4 KiB) of a ring of *ring_bytes_out; the
+ * garbler may overwrite that range once launch wait_for[i] (-1: nobody) has been evaluated.
+ * ring_bytes = 0 asks for the solver's own choice (twice the largest launch).  Arrays: n_launches. */
+int lgc_program_ring_plan(const lgc_program *p, size_t ring_bytes, size_t *ring_bytes_out, size_t *offsets, int64_t *wait_for);
 
 /* One-shot convenience: create + set + run + get + destroy. */
 int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[16], const uint64_t *shares,

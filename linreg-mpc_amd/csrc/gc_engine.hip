@@ -207,6 +207,15 @@ extern "C" int lgc_program_build_sweep(lgc_program **out, const lgc_system *sys,
     *out = p;
     return LGC_OK;
 }
+extern "C" int lgc_program_ring_plan(const lgc_program *p, size_t ring_bytes, size_t *ring_bytes_out, size_t *offsets, int64_t *wait_for) {
+    if (!p || !offsets || !wait_for) return lgc_fail(LGC_EINVAL, "null argument");
+    std::vector<size_t> off;
+    std::vector<int64_t> wait;
+    size_t rb = plan_table_ring(p->P, ring_bytes, off, wait);
+    if (ring_bytes_out) *ring_bytes_out = rb;
+    for (size_t i = 0; i < off.size(); i++) { offsets[i] = off[i]; wait_for[i] = wait[i]; }
+    return LGC_OK;
+}
 extern "C" void lgc_program_destroy(lgc_program *p) { delete p; }
 extern "C" int lgc_program_info_get(const lgc_program *p, lgc_program_info *info) {
     if (!p || !info) return lgc_fail(LGC_EINVAL, "null argument");
@@ -338,7 +347,6 @@ static int solver_create(lgc_solver **out, int device, const lgc_system *sys, co
     s->R.x |= 1u;                               // point-and-permute: lsb(R) = 1
     const Program &P = s->P;
     size_t wbytes = (size_t)P.n_words * 64 * sizeof(Lbl);
-    size_t tbytes = (size_t)P.max_launch_steps * 128 * sizeof(Lbl);
     size_t nin = P.nshares * (P.T + P.d);
 #define TRY(x)                                                                                   \
     do {                                                                                         \
@@ -356,32 +364,7 @@ static int solver_create(lgc_solver **out, int device, const lgc_system *sys, co
     TRY(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
     // Table ring of twice the largest launch: the garbler of a large (MAC) launch overlaps the
     // evaluator of the previous one, and runs many small (divider, reveal) launches ahead of it.
-    {
-        const size_t align = 4096;
-        s->ring_bytes = 2 * ((tbytes + align - 1) / align * align) + align;
-        const size_t nl = P.launches.size();
-        s->tab_off.resize(nl);
-        s->tab_wait.assign(nl, -1);
-        std::vector<size_t> len(nl);
-        size_t head = 0;
-        for (size_t i = 0; i < nl; i++) {
-            len[i] = ((size_t)P.launches[i].steps * 128 * sizeof(Lbl) + align - 1) / align * align;
-            if (head + len[i] > s->ring_bytes) head = 0;
-            s->tab_off[i] = head;
-            head += len[i];
-        }
-        // newest earlier launch overlapping launch i; scanning back stops once a full ring has been passed
-        for (size_t i = 0; i < nl; i++) {
-            size_t seen = 0;
-            for (size_t j = i; j-- > 0 && seen <= s->ring_bytes;) {
-                seen += len[j];
-                if (len[i] && len[j] && s->tab_off[j] < s->tab_off[i] + len[i] && s->tab_off[i] < s->tab_off[j] + len[j]) {
-                    s->tab_wait[i] = (int64_t)j;
-                    break;
-                }
-            }
-        }
-    }
+    s->ring_bytes = plan_table_ring(P, 0, s->tab_off, s->tab_wait);
     TRY(hipMalloc(&s->wordsG, wbytes));
     TRY(hipMalloc(&s->wordsE, wbytes));
     TRY(hipMalloc(&s->tab, s->ring_bytes));

@@ -494,4 +494,42 @@ inline void replicate_program(Program &P, const Program &P0, size_t count, const
         }
     }
 }
+
+// Garbled-table ring (co-located solver): launch i owns the byte range [off[i], off[i] + len[i]) of a
+// ring of `ring_bytes`, allocated in launch order with wrap-around; before the garbler overwrites the
+// range it waits for the evaluation of wait[i], the newest earlier launch whose range overlaps (the
+// evaluator runs in launch order, so every older overlapping launch is done by then too; -1: none).
+// ring_bytes == 0 picks twice the largest launch.  Returns the ring size.
+inline size_t plan_table_ring(const Program &P, size_t ring_bytes, std::vector<size_t> &off, std::vector<int64_t> &wait) {
+    const size_t align = 4096, nl = P.launches.size();
+    const size_t tbytes = (size_t)P.max_launch_steps * 2048;
+    const size_t min_ring = (tbytes + align - 1) / align * align;
+    if (ring_bytes == 0) ring_bytes = 2 * min_ring + align;
+    if (ring_bytes < min_ring) ring_bytes = min_ring;
+    off.resize(nl);
+    wait.assign(nl, -1);
+    std::vector<size_t> len(nl);
+    size_t head = 0;
+    for (size_t i = 0; i < nl; i++) {
+        len[i] = ((size_t)P.launches[i].steps * 2048 + align - 1) / align * align;
+        if (head + len[i] > ring_bytes) head = 0;
+        off[i] = head;
+        head += len[i];
+    }
+    for (size_t i = 0; i < nl; i++) {
+        // scanning back may stop once more than a full ring of newer ranges has been passed: anything
+        // older was overwritten by launches that waited for evaluations newer than it
+        size_t seen = 0;
+        for (size_t j = i; j-- > 0 && seen <= ring_bytes;) {
+            seen += len[j];
+            if (len[i] && len[j] && off[j] < off[i] + len[i] && off[i] < off[j] + len[j]) {
+                wait[i] = (int64_t)j;
+                break;
+            }
+        }
+        // the garbler chain is in order: what an earlier launch waited for holds for this one too
+        if (i > 0 && wait[i - 1] > wait[i]) wait[i] = wait[i - 1];
+    }
+    return ring_bytes;
+}
 }  // namespace gc

@@ -81,6 +81,7 @@ def lib():
             ("lgc_program_build_sweep", [C.POINTER(vp), C.POINTER(System), sz, vp]),
             ("lgc_solver_create_sweep", [C.POINTER(vp), ci, C.POINTER(System), C.c_char_p, sz, vp]),
             ("lgc_program_info_get", [vp, C.POINTER(ProgramInfo)]),
+            ("lgc_program_ring_plan", [vp, sz, C.POINTER(sz), vp, vp]),
             ("lgc_aes_bench", [ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
             ("lgc_p1_create", [C.POINTER(vp), ci, sz, sz, ci, ci]), ("lgc_p1_set_data", [vp, vp, vp]),
             ("lgc_p1_local", [vp, sz, sz, ci, vp, vp]), ("lgc_p1_mask", [vp, vp, sz, vp, ci, vp]),
@@ -157,6 +158,14 @@ class Program:
         ptr = lib().lgc_program_launches(self._h)
         return [dict(first_rec=ptr[i].first_rec, nrec=ptr[i].nrec, step0=ptr[i].step0, steps=ptr[i].steps,
                      gates=ptr[i].gates, mac_only=ptr[i].mac_only) for i in range(self.info.n_launches)]
+
+    def ring_plan(self, ring_bytes=0):
+        """(ring size, offsets, wait_for) of the co-located solver's garbled-table ring"""
+        n = self.info.n_launches
+        off = np.zeros(n, dtype=np.uint64); wait = np.zeros(n, dtype=np.int64); rb = C.c_size_t()
+        _chk(lib().lgc_program_ring_plan(self._h, ring_bytes, C.byref(rb), off.ctypes.data_as(C.c_void_p),
+                                         wait.ctypes.data_as(C.c_void_p)))
+        return rb.value, off, wait
 
     def close(self):
         if self._h:

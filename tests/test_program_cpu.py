@@ -153,3 +153,30 @@ def test_library_exports_and_fails_loudly_without_gpu(lgc):
         lgc.Program(lgc.make_system(3, width=48))
     with pytest.raises(lgc.LgcError):
         lgc.Program(lgc.make_system(3, width=32, precision=32))
+
+
+@pytest.mark.parametrize("alg,d,iters", [("cgd", 30, 3), ("cholesky", 14, 0), ("ldlt", 9, 0)])
+def test_table_ring_plan_never_overwrites_live_tables(lgc, alg, d, iters):
+    """host logic of the co-located solver's garbled-table ring: with the garbler as far ahead of the
+    evaluator as its waits allow, no range is overwritten before its launch has been evaluated"""
+    prog = lgc.Program(lgc.make_system(d, 64, 56, alg, iters, 0.0, 2, 0, 0, 0))
+    L = prog.launches()
+    steps = np.array([l["steps"] for l in L], dtype=np.int64)
+    length = (steps * 2048 + 4095) // 4096 * 4096
+    biggest = int(length.max())
+    for ring in (0, biggest, biggest + 4096, 3 * biggest // 2, 64 * biggest):
+        rb, off, wait = prog.ring_plan(ring)
+        off = off.astype(np.int64)
+        assert rb >= biggest and (ring == 0 or rb == max(ring, biggest))
+        assert np.all(off + length <= rb) and np.all(wait < np.arange(len(L)))
+        for i in range(len(L)):
+            if length[i] == 0:
+                continue
+            lo = int(wait[i]) + 1                      # launches lo..i-1 may still be waiting for their evaluator
+            live = np.arange(lo, i)
+            live = live[length[live] > 0]
+            clash = (off[live] < off[i] + length[i]) & (off[i] < off[live] + length[live])
+            assert not clash.any(), (ring, i, live[clash][:4])
+        if ring == 0:                                   # the default ring lets the garbler run ahead
+            ahead = np.arange(len(L)) - wait - 1
+            assert ahead.max() >= 2
