@@ -32,6 +32,7 @@ static int io_all(int fd, void *buf, size_t len, int wr) {
 int net_send(node *n, int to, const void *buf, size_t len) {
     if (to < 1 || to > n->num_parties || n->fd[to - 1] < 0) return -1;
     n->sent[to - 1] += len;
+    n->nsend[to - 1]++;
     return io_all(n->fd[to - 1], (void *)buf, len, 1);
 }
 int net_recv(node *n, int from, void *buf, size_t len) {
@@ -74,6 +75,8 @@ int node_new(node **out, int party, int num_parties, char **endpoints) {
     n->party = party; n->num_parties = num_parties;
     n->fd = malloc(sizeof(int) * (size_t)num_parties);
     n->sent = calloc((size_t)num_parties, sizeof(uint64_t));
+    n->nsend = calloc((size_t)num_parties, sizeof(uint64_t));
+    n->wait_ns = calloc((size_t)num_parties, sizeof(uint64_t));
     for (int i = 0; i < num_parties; i++) n->fd[i] = -1;
     char host[256], port[32];
     for (int q = 1; q < party; q++) {                       /* lower-numbered peers listen */
@@ -120,7 +123,7 @@ void node_destroy(node **nn) {
     if (!nn || !*nn) return;
     node *n = *nn;
     if (n->fd) for (int i = 0; i < n->num_parties; i++) if (n->fd[i] >= 0) close(n->fd[i]);
-    free(n->fd); free(n->sent); free(n);
+    free(n->fd); free(n->sent); free(n->nsend); free(n->wait_ns); free(n);
     *nn = 0;
 }
 

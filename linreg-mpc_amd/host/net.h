@@ -11,6 +11,8 @@ typedef struct {
     int num_parties;
     int *fd;            /* fd[q-1] = socket to party q, -1 for self */
     uint64_t *sent;     /* bytes sent per peer (PROFILE_NETWORK-style accounting) */
+    uint64_t *wait_ns;  /* time spent waiting for a peer data provider's message, per peer (src/phase1.c:177-183) */
+    uint64_t *nsend;    /* send calls per peer (each one reaches the socket: the "flush count") */
 } node;
 
 int node_new(node **out, int party, int num_parties, char **endpoints);

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/linreg_gc.h"
 #include "baseot.h"
@@ -239,6 +240,15 @@ typedef struct {
     ti_queue *q;
     int failed;
 } ti_worker;
+/* recv_pmsg from a peer data provider, timed like the reference's wait_total (src/phase1.c:177-183, 211-217) */
+static int recv_pmsg_timed(node *self, int from, uint64_t **vec, size_t *n, uint64_t *value) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int rc = recv_pmsg(self, from, vec, n, value);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    self->wait_ns[from - 1] += (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
+    return rc;
+}
 static void *ti_worker_main(void *arg) {
     ti_worker *w = arg;
     const size_t n = w->n;
@@ -254,14 +264,14 @@ static void *ti_worker_main(void *arg) {
         uint32_t col = pr->col;
         sub = it.val;
         if (pr->is_a) {                                   /* party a (phase1.c:171-197) */
-            if (recv_pmsg(w->self, to, &in, &in_n, &inval) || in_n != n) { fprintf(stderr, "Could not receive message from party B (%d)\n", w->peer); w->failed = 1; }
+            if (recv_pmsg_timed(w->self, to, &in, &in_n, &inval) || in_n != n) { fprintf(stderr, "Could not receive message from party B (%d)\n", w->peer); w->failed = 1; }
             else if (lgc_p1_mask(w->p1, &col, 1, it.vec, -1, tmp)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* a - y */
             else if (send_pmsg(w->self, to, tmp, n, 0)) { fprintf(stderr, "Could not send message to party B (%d)\n", w->peer); w->failed = 1; }
             else if (lgc_p1_dot(w->p1, in, it.vec, 0, 1, &sub, &share)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* <b+x, y> - (xy - r) */
         } else {                                          /* party b (phase1.c:198-223) */
             if (lgc_p1_mask(w->p1, &col, 1, it.vec, +1, tmp)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }        /* b + x */
             else if (send_pmsg(w->self, to, tmp, n, 0)) { fprintf(stderr, "Could not send message to party A (%d)\n", w->peer); w->failed = 1; }
-            else if (recv_pmsg(w->self, to, &in, &in_n, &inval) || in_n != n) { fprintf(stderr, "Could not receive message from party A (%d)\n", w->peer); w->failed = 1; }
+            else if (recv_pmsg_timed(w->self, to, &in, &in_n, &inval) || in_n != n) { fprintf(stderr, "Could not receive message from party A (%d)\n", w->peer); w->failed = 1; }
             else if (lgc_p1_dot(w->p1, in, 0, &col, 1, &sub, &share)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* <a-y, b> - r */
         }
         free(in); free(it.vec);

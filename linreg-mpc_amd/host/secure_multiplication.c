@@ -46,12 +46,15 @@ int main(int argc, char **argv) {
     }
     clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &c1);
     clock_gettime(CLOCK_MONOTONIC, &r1);
-    double bill = 1e9;
+    double bill = 1e9, wait_s = 0.0;      /* summed over the per-peer worker threads */
+    for (int q = 0; q < self->num_parties; q++) wait_s += (double)self->wait_ns[q] / bill;
     printf("{\"party\":\"%d\", \"cputime\":\"%f\", \"wait_time\":%f, \"realtime\":\"%f\"}\n", party,
-           (c1.tv_sec - c0.tv_sec) + (c1.tv_nsec - c0.tv_nsec) / bill, 0.0,
+           (c1.tv_sec - c0.tv_sec) + (c1.tv_nsec - c0.tv_nsec) / bill, wait_s,
            (r1.tv_sec - r0.tv_sec) + (r1.tv_nsec - r0.tv_nsec) / bill);
     printf("{\"party\":\"%d\", \"bytes_sent\":[", party);
     for (int q = 0; q < self->num_parties; q++) printf("%s%llu", q ? ", " : "", (unsigned long long)self->sent[q]);
+    printf("], \"sends\":[");
+    for (int q = 0; q < self->num_parties; q++) printf("%s%llu", q ? ", " : "", (unsigned long long)self->nsend[q]);
     printf("]}\n");
     check(!net_barrier(self), "barrier failed");
     node_destroy(&self);

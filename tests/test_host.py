@@ -166,7 +166,9 @@ def test_secure_multiplication_binary(tmp_path, golden_dir, extra):
         t = json.loads(lines[0])
         assert t["party"] == str(k + 1) and float(t["realtime"]) >= 0 and (k == 1 or float(t["realtime"]) > 0 or extra)
         sent = json.loads(lines[1])["bytes_sent"]
-        assert len(sent) == P + 2
+        sends = json.loads(lines[1])["sends"]
+        assert len(sent) == P + 2 and len(sends) == P + 2
+        assert all((b > 0) == (c > 0) for b, c in zip(sent, sends))
         if k >= 2:
             assert sum(sent) > 0
 
