@@ -399,6 +399,9 @@ extern "C" int lgc_solver_set_shares(lgc_solver *s, const uint64_t *shares) {
 #define GC_TPB_MACE 768
 #endif
 static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
+#ifndef GC_MAC_EXCLUSIVE
+#define GC_MAC_EXCLUSIVE 1
+#endif
 // generic launches with at least this many records run one wave per record (throughput);
 // narrower ones run one 4-wave workgroup per record (latency)
 static constexpr uint32_t kWideLaunch = 2048;
@@ -413,6 +416,8 @@ static constexpr uint32_t kQuadOnePerCu = 256;
 // MAC launches with fewer records than this are latency-bound too (Cholesky / LDL^T stages at
 // small d): they run in the 4-wave mode instead of the throughput-oriented MAC kernel
 static constexpr uint32_t kNarrowMac = 1024;
+// MAC launches of at least two garbler rounds get the chip to themselves (GC_MAC_EXCLUSIVE)
+static constexpr uint32_t kExclusiveMac = 8192;
 template <bool G>
 static void launch_exec(lgc_solver *s, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, hipStream_t st) {
     if (L.mac_only && L.nrec >= kNarrowMac) {
@@ -489,6 +494,13 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
         Lbl *tab = reinterpret_cast<Lbl *>(reinterpret_cast<char *>(s->tab) + s->tab_off[i]);
         bool timed = profile || L.mac_only;
         if (!profile && s->tab_wait[i] >= 0) HIPCHK(hipStreamWaitEvent(sG, s->evE[(size_t)s->tab_wait[i]], 0));
+#if GC_MAC_EXCLUSIVE
+        // MAC launches are shaped to fill whole rounds of the chip (gc_program.h: kRoundRecs): a garbler
+        // MAC launch sharing the CUs with the previous launch's evaluator would break both into ragged rounds
+        if (!profile && L.mac_only && i > 0 && P.launches[i - 1].mac_only && L.nrec >= kExclusiveMac &&
+            P.launches[i - 1].nrec >= kExclusiveMac)
+            HIPCHK(hipStreamWaitEvent(sG, s->evE[i - 1], 0));
+#endif
         if (timed) HIPCHK(hipEventRecord(s->evs[3 * i], sG));
         launch_exec<true>(s, L, s->wordsG, s->decG, tab, sG);
         if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));

@@ -61,7 +61,7 @@ struct Program {
     Program() : w(64), p(56), d(0), T(0), nshares(0), n_words(1), n_reveal(0), in_base(0), rv_beta(0),
                 rv_trace(~0u), rv_ab(~0u), total_steps(0), total_gates(0), max_launch_steps(0),
                 replicas(1), word_stride(0), reveal_stride(0), lam_rec(~0u),
-                cap_steps(1ull << 22), step_cursor(0), open(false) {}
+                cap_steps(1ull << 23), step_cursor(0), open(false) {}
 
     uint32_t alloc(size_t n) { uint32_t r = n_words; n_words += (uint32_t)n; return r; }
     uint32_t alloc_reveal(size_t n) { uint32_t r = n_reveal; n_reveal += (uint32_t)n; return r; }
@@ -145,13 +145,12 @@ struct Program {
     // dot products in carry-save form, chunked so that a launch has enough waves.
     // result words: dst[i] = base[i] - sum_k A[i][k]*B[k]  (subtract) or  = sum (no base)
     struct DotJob { uint32_t dst, base, a, b; uint32_t len; bool has_base; };
-    void dots(const std::vector<DotJob> &jobs, uint32_t scratch, size_t target_waves) {
-        size_t total = 0;
-        for (size_t i = 0; i < jobs.size(); i++) total += jobs[i].len;
-        if (total == 0) return;
-        size_t chunk = dots_chunk(total, target_waves);
-        new_launch();
-        std::vector<std::pair<uint32_t, uint32_t>> parts(jobs.size());  // (first partial word, count of words)
+    // MAC records of a batch of dot products for `chunk` products per record (two chunks per record
+    // when w == 32); fills the partial-word bookkeeping of every job
+    void dots_records(const std::vector<DotJob> &jobs, uint32_t scratch, size_t chunk, std::vector<Rec> &out,
+                      std::vector<std::pair<uint32_t, uint32_t>> &parts) const {
+        out.clear();
+        parts.assign(jobs.size(), std::make_pair(0u, 0u));   // (first partial word, count of words)
         uint32_t cur = scratch;
         for (size_t i = 0; i < jobs.size(); i++) {
             const DotJob &J = jobs[i];
@@ -162,19 +161,70 @@ struct Program {
                 if (w == 32 && left >= 2) {
                     // two chunks of `len` products side by side in one wave (lanes 0..31 / 32..63)
                     uint32_t len = left / 2 < chunk ? left / 2 : (uint32_t)chunk;
-                    emit(mk(OP_MAC2, cur, J.a + k0, J.b + k0, 0, len));
+                    out.push_back(mk(OP_MAC2, cur, J.a + k0, J.b + k0, 0, len));
                     cur += 4;
                     nparts += 4;
                     k0 += 2 * len;
                 } else {
                     uint32_t len = left < chunk ? left : (uint32_t)chunk;
-                    emit(mk(OP_MAC, cur, J.a + k0, J.b + k0, 0, len));
+                    out.push_back(mk(OP_MAC, cur, J.a + k0, J.b + k0, 0, len));
                     cur += 2;
                     nparts += 2;
                     k0 += len;
                 }
             }
             parts[i].second = nparts;
+        }
+    }
+    // Launch shaping.  The MAC kernels run one workgroup per CU with 16 (garbler) or 12 (evaluator)
+    // records each, and every record of a batch takes the same time, so a launch proceeds in rounds
+    // of 4096 / 3072 records: a launch of 10 400 records costs three garbler rounds but fills 2.55.
+    // Among the chunk sizes down to half the default and the launch counts that respect the table
+    // cap, pick the pair with the least rounds x steps, and split the records evenly.
+    static const size_t kRoundRecs = 12288;          // lcm(256 x 16, 256 x 12)
+    static double round_cost(size_t per, size_t quantum) {   // a workgroup is the unit: a partial round costs a round
+        return (double)((per + quantum - 1) / quantum);
+    }
+    void dots(const std::vector<DotJob> &jobs, uint32_t scratch, size_t target_waves) {
+        size_t total = 0;
+        for (size_t i = 0; i < jobs.size(); i++) total += jobs[i].len;
+        if (total == 0) return;
+        const size_t c0 = dots_chunk(total, target_waves), clo = dots_chunk_low(total, target_waves);
+        std::vector<Rec> recs_best, recs_try;
+        std::vector<std::pair<uint32_t, uint32_t>> parts, parts_try;
+        double best = -1.0;
+        size_t best_launches = 1;
+        for (size_t c = c0; c >= clo; c--) {
+            dots_records(jobs, scratch, c, recs_try, parts_try);
+            uint64_t steps = 0, smax = 0;
+            for (size_t i = 0; i < recs_try.size(); i++) {
+                uint64_t s1, g1;
+                cost(recs_try[i], s1, g1);
+                steps += s1;
+                if (s1 > smax) smax = s1;
+            }
+            const size_t R = recs_try.size();
+            const size_t lmin = (size_t)((steps + cap_steps - 1) / cap_steps);
+            for (size_t L = lmin ? lmin : 1; L <= lmin + 3; L++) {
+                size_t per = (R + L - 1) / L;
+                if ((uint64_t)per * smax > cap_steps) continue;
+                // relative time of one launch: garbler rounds of 4096 records (16 waves/CU, 4 AES per gate)
+                // and evaluator rounds of 3072 (12 waves/CU, 2 AES)
+                double c_est = (double)L * ((double)smax * (64.0 * round_cost(per, 4096) + 24.0 * round_cost(per, 3072)) + 3e2);
+                if (best < 0 || c_est < best) { best = c_est; best_launches = L; recs_best = recs_try; parts = parts_try; }
+            }
+            if (c == 1) break;
+        }
+        if (best < 0) {   // cannot happen (L = lmin + 3 always fits); keep the default shape
+            dots_records(jobs, scratch, c0, recs_best, parts);
+            best_launches = 0;
+        }
+        new_launch();
+        const size_t R = recs_best.size();
+        const size_t per = best_launches ? (R + best_launches - 1) / best_launches : R;
+        for (size_t i = 0; i < R; i++) {
+            if (i && per && i % per == 0) new_launch();
+            emit(recs_best[i]);
         }
         new_launch();
         for (size_t i = 0; i < jobs.size(); i++) {
@@ -197,8 +247,13 @@ struct Program {
         if (chunk < 1) chunk = 1;
         return chunk;
     }
+    // smallest chunk the launch shaping in dots() may pick (sizes the scratch for the partial sums)
+    size_t dots_chunk_low(size_t total, size_t target_waves) {
+        size_t c = dots_chunk(total, target_waves) / 2;
+        return c < 1 ? 1 : c;
+    }
     size_t dots_scratch(size_t total_products, size_t njobs, size_t target_waves) {
-        size_t chunk = dots_chunk(total_products, target_waves);
+        size_t chunk = dots_chunk_low(total_products, target_waves);
         return 2 * (total_products / chunk + njobs + 2) + 4 * njobs + 16;   // + tails of dual 32-bit records
     }
 
