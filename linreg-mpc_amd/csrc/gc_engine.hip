@@ -404,7 +404,13 @@ static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
 #endif
 // generic launches with at least this many records run one wave per record (throughput);
 // narrower ones run one 4-wave workgroup per record (latency)
-static constexpr uint32_t kWideLaunch = 2048;
+#ifndef GC_WIDE_LAUNCH
+#define GC_WIDE_LAUNCH 2048
+#endif
+static constexpr uint32_t kWideLaunch = GC_WIDE_LAUNCH;
+// ... and only for short records (sums, merges): long dependent records (dividers, square roots) run
+// faster in the 4-wave mode even when there are thousands of them (measured on the merged lambda sweep)
+static constexpr uint64_t kWideMaxSteps = 256;
 // wide launches: 12 records (waves) per workgroup share one 128 KiB four-table image
 #ifndef GC_TPB_WIDE
 #define GC_TPB_WIDE 768
@@ -426,7 +432,7 @@ static void launch_exec(lgc_solver *s, const Launch &L, Lbl *words, uint64_t *de
         dim3 grid((L.nrec + per - 1) / per), block(TPB);
         hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
                            tab, L.step0, s->R, s->P.w, s->P.p);
-    } else if (L.nrec >= kWideLaunch) {
+    } else if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) {
         constexpr unsigned per = kTpbWide / 64;
         dim3 grid((L.nrec + per - 1) / per), block(kTpbWide);
         hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,

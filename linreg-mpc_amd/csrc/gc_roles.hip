@@ -195,7 +195,7 @@ static void party_launch(lgc_party *p, const Launch &L, Lbl *tab = 0) {
         const unsigned per = TPB / 64;
         hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(TPB), 0, 0, p->recs + L.first_rec, L.nrec,
                            p->words, tab, L.step0, p->R, p->P.w, p->P.p);
-    } else if (L.nrec >= kWideLaunch) {
+    } else if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) {
         constexpr unsigned per = kTpbWide / 64;
         hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(kTpbWide), 0, 0,
                            p->recs + L.first_rec, L.nrec, p->words, tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
