@@ -218,6 +218,12 @@ int lgc_p1_local(lgc_p1 *h, size_t c0, size_t c1, int with_y, uint64_t *out_A, u
 int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const uint64_t *V, int sign, uint64_t *out);
 int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const uint32_t *colsB, size_t npairs,
                const uint64_t *sub, uint64_t *out);
+/* party a of ONE inner_product_ti (src/phase1.c:171-197) in a single pass over the column:
+ * out_mask[n] = a - y (the message for party b) and *share = <in, y> - sub, where `in` is party b's
+ * message b + x and (y, sub) came from the trusted initializer.  Same results as lgc_p1_mask(sign
+ * -1) followed by lgc_p1_dot, with half the device operations. */
+int lgc_p1_ti_a(lgc_p1 *h, uint32_t col, const uint64_t *y, const uint64_t *in, uint64_t sub,
+                uint64_t *out_mask, uint64_t *share);
 /* Trusted initializer (src/phase1.c:241-287): pairs [first_pair, first_pair + npairs) of the
  * cross-party (i, j) enumeration; x, y: npairs x n words, r, xy_minus_r: npairs words, drawn in the
  * order x, y, r from one AES-128-CTR stream keyed by seed (newBCipherRandomGen / randomizeBuffer). */

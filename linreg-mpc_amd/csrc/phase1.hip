@@ -149,6 +149,49 @@ __global__ void p1_mask_kernel(const int64_t *X, size_t n, size_t ld, const uint
     }
 }
 
+// ---- single-pair forms used by the per-pair TI protocol: no column-index upload, the sum lands
+// next to the vector it belongs to (one copy back); up to 64 workgroups keep the strided column
+// reads in flight (a single workgroup was latency-bound: config 4 went from 90 s to 105 s)
+__device__ __forceinline__ uint64_t p1_block_sum(uint64_t acc) {
+    __shared__ uint64_t part[16];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    uint64_t t = 0;
+    if (threadIdx.x == 0) for (unsigned i = 0; i < (blockDim.x + 63) / 64; i++) t += part[i];
+    return t;   // valid in thread 0
+}
+// out[k] = X[k][col] + sign * V[k]
+__global__ void __launch_bounds__(1024)
+p1_mask1_kernel(const int64_t *X, size_t n, size_t ld, uint32_t col, const uint64_t *V, int sign, uint64_t *out) {
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        uint64_t x = (uint64_t)X[k * ld + col], v = V[k];
+        out[k] = sign > 0 ? x + v : x - v;
+    }
+}
+// out[0] = sum_k A[k] * (Bv ? Bv[k] : X[k][col])
+__global__ void __launch_bounds__(1024)
+p1_dot1_kernel(const uint64_t *A, const uint64_t *Bv, const int64_t *X, size_t ld, uint32_t col, size_t n, uint64_t *out) {
+    uint64_t acc = 0;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+        acc += A[k] * (Bv ? Bv[k] : (uint64_t)X[k * ld + col]);
+    uint64_t t = p1_block_sum(acc);
+    if (threadIdx.x == 0) atomicAdd((unsigned long long *)&out[0], (unsigned long long)t);   // out[0] zeroed by the host
+}
+// party a of inner_product_ti in one pass (phase1.c:186-196): out[k] = a[k] - y[k] for k < n, and
+// out[n] = sum_k in[k] * y[k]   (in = b + x from party b, y from the TI)
+__global__ void __launch_bounds__(1024)
+p1_ti_a_kernel(const int64_t *X, size_t n, size_t ld, uint32_t col, const uint64_t *y, const uint64_t *in, uint64_t *out) {
+    uint64_t acc = 0;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+        uint64_t yk = y[k];
+        out[k] = (uint64_t)X[k * ld + col] - yk;
+        acc += in[k] * yk;
+    }
+    uint64_t t = p1_block_sum(acc);
+    if (threadIdx.x == 0) atomicAdd((unsigned long long *)&out[n], (unsigned long long)t);   // out[n] zeroed by the host
+}
+
 // ---- batched wrap-around dot products: out[q] = sum_k A[q][k] * B[q][k]; B is either a vector
 // batch (colsB == NULL) or columns of X
 __global__ void __launch_bounds__(256)
@@ -306,6 +349,14 @@ struct P1Scratch {
 };
 static thread_local P1Scratch t_scratch;
 
+// The per-pair calls of one process share ONE stream, taken in turn: a data provider runs a worker
+// thread per peer, and with a stream (= a hardware queue) per thread five providers on one GPU
+// oversubscribe the queues, which the scheduler then time-slices at millisecond granularity.
+#include <mutex>
+static std::mutex g_p1_mutex;
+struct P1Serial { std::lock_guard<std::mutex> g; P1Serial() : g(g_p1_mutex) {} };
+static hipStream_t p1_stream() { return 0; }
+
 // out[q][k] = column cols[q] (d means y) +/- V[q][k]: the vectors a DP sends in inner_product_ti
 // (b + x at phase1.c:201-207, a - y at 186-191).  Safe to call from several threads on one handle.
 extern "C" int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const uint64_t *V, int sign, uint64_t *out) {
@@ -313,9 +364,20 @@ extern "C" int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const
     if (npairs == 0) return LGC_OK;
     for (size_t q = 0; q < npairs; q++) if (cols[q] > h->d) return lgc_fail(LGC_EINVAL, "column out of range");
     P1CHK(hipSetDevice(h->device));
-    hipStream_t st = hipStreamPerThread;
+    P1Serial serial_; hipStream_t st = p1_stream();
     uint32_t *dcols = 0; uint64_t *dV = 0, *dout = 0;
     size_t bytes = npairs * h->n * sizeof(uint64_t);
+    if (npairs == 1) {   // per-pair protocol step: three operations
+        P1CHK(t_scratch.get(h->device, 1, bytes, (void **)&dV));
+        P1CHK(t_scratch.get(h->device, 2, bytes, (void **)&dout));
+        P1CHK(hipMemcpyAsync(dV, V, bytes, hipMemcpyHostToDevice, st));
+        unsigned g1 = (unsigned)((h->n + 1023) / 1024); if (g1 > 64) g1 = 64;
+        hipLaunchKernelGGL(p1_mask1_kernel, dim3(g1), dim3(1024), 0, st, h->X, h->n, h->d + 1, cols[0], dV, sign, dout);
+        P1CHK(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
+        P1CHK(hipStreamSynchronize(st));
+        if (h->w == 32) for (size_t i = 0; i < h->n; i++) out[i] &= 0xffffffffull;
+        return LGC_OK;
+    }
     P1CHK(t_scratch.get(h->device, 0, npairs * sizeof(uint32_t), (void **)&dcols));
     P1CHK(t_scratch.get(h->device, 1, bytes, (void **)&dV));
     P1CHK(t_scratch.get(h->device, 2, bytes, (void **)&dout));
@@ -338,11 +400,25 @@ extern "C" int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const
     if (npairs == 0) return LGC_OK;
     if (colsB) for (size_t q = 0; q < npairs; q++) if (colsB[q] > h->d) return lgc_fail(LGC_EINVAL, "column out of range");
     P1CHK(hipSetDevice(h->device));
-    hipStream_t st = hipStreamPerThread;
+    P1Serial serial_; hipStream_t st = p1_stream();
     size_t bytes = npairs * h->n * sizeof(uint64_t);
     uint64_t *dA = 0, *dB = 0, *dout = 0; uint32_t *dcols = 0;
     P1CHK(t_scratch.get(h->device, 1, bytes, (void **)&dA));
     P1CHK(hipMemcpyAsync(dA, A, bytes, hipMemcpyHostToDevice, st));
+    if (npairs == 1) {   // per-pair protocol step: one workgroup writes the sum, no memset
+        if (!colsB) {
+            P1CHK(t_scratch.get(h->device, 2, bytes, (void **)&dB));
+            P1CHK(hipMemcpyAsync(dB, B, bytes, hipMemcpyHostToDevice, st));
+        }
+        P1CHK(t_scratch.get(h->device, 3, sizeof(uint64_t), (void **)&dout));
+        P1CHK(hipMemsetAsync(dout, 0, sizeof(uint64_t), st));
+        unsigned g1 = (unsigned)((h->n + 1023) / 1024); if (g1 > 64) g1 = 64;
+        hipLaunchKernelGGL(p1_dot1_kernel, dim3(g1), dim3(1024), 0, st, dA, dB, h->X, h->d + 1, colsB ? colsB[0] : 0u, h->n, dout);
+        P1CHK(hipMemcpyAsync(out, dout, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        P1CHK(hipStreamSynchronize(st));
+        out[0] = (out[0] - (sub ? sub[0] : 0)) & maskw(h->w);
+        return LGC_OK;
+    }
     if (colsB) {
         P1CHK(t_scratch.get(h->device, 0, npairs * sizeof(uint32_t), (void **)&dcols));
         P1CHK(hipMemcpyAsync(dcols, colsB, npairs * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -358,6 +434,34 @@ extern "C" int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const
     P1CHK(hipStreamSynchronize(st));
     const uint64_t m = maskw(h->w);
     for (size_t q = 0; q < npairs; q++) out[q] = (out[q] - (sub ? sub[q] : 0)) & m;
+    return LGC_OK;
+}
+
+// Party a of one inner_product_ti (phase1.c:171-197) in a single pass: out_mask = a - y (sent to
+// party b) and *share = <in, y> - sub, where `in` = b + x is party b's message, (y, sub) the TI's.
+extern "C" int lgc_p1_ti_a(lgc_p1 *h, uint32_t col, const uint64_t *y, const uint64_t *in, uint64_t sub,
+                           uint64_t *out_mask, uint64_t *share) {
+    if (!h || !y || !in || !out_mask || !share) return lgc_fail(LGC_EINVAL, "null argument");
+    if (col > h->d) return lgc_fail(LGC_EINVAL, "column out of range");
+    P1CHK(hipSetDevice(h->device));
+    P1Serial serial_; hipStream_t st = p1_stream();
+    const size_t n = h->n, bytes = n * sizeof(uint64_t);
+    uint64_t *dy = 0, *din = 0, *dout = 0;
+    P1CHK(t_scratch.get(h->device, 1, bytes, (void **)&dy));
+    P1CHK(t_scratch.get(h->device, 2, bytes, (void **)&din));
+    P1CHK(t_scratch.get(h->device, 3, bytes + sizeof(uint64_t), (void **)&dout));
+    P1CHK(hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, st));
+    P1CHK(hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, st));
+    P1CHK(hipMemsetAsync(dout + n, 0, sizeof(uint64_t), st));
+    unsigned g1 = (unsigned)((n + 1023) / 1024); if (g1 > 64) g1 = 64;
+    hipLaunchKernelGGL(p1_ti_a_kernel, dim3(g1), dim3(1024), 0, st, h->X, n, h->d + 1, col, dy, din, dout);
+    P1CHK(hipMemcpyAsync(out_mask, dout, bytes, hipMemcpyDeviceToHost, st));
+    uint64_t acc = 0;
+    P1CHK(hipMemcpyAsync(&acc, dout + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    P1CHK(hipStreamSynchronize(st));
+    const uint64_t m = maskw(h->w);
+    if (h->w == 32) for (size_t i = 0; i < n; i++) out_mask[i] &= m;
+    *share = (acc - sub) & m;
     return LGC_OK;
 }
 

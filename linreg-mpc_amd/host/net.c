@@ -48,6 +48,20 @@ static int split_endpoint(const char *ep, char *host, size_t hl, char *port, siz
     return 0;
 }
 
+/* large socket buffers: a TI message is ~0.5 MB at n = 5*10^4; with the default ~200 KB buffers a
+ * sender sleeps several times per message (the kernel caps the request at net.core.[rw]mem_max) */
+static void tune_socket(int s) {
+    int one = 1, big = 8 << 20;
+    setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    setsockopt(s, SOL_SOCKET, SO_SNDBUF, &big, sizeof big);
+    setsockopt(s, SOL_SOCKET, SO_RCVBUF, &big, sizeof big);
+    if (getenv("LINREG_TIMING")) {
+        int sb = 0, rb = 0; socklen_t l = sizeof sb;
+        getsockopt(s, SOL_SOCKET, SO_SNDBUF, &sb, &l); l = sizeof rb;
+        getsockopt(s, SOL_SOCKET, SO_RCVBUF, &rb, &l);
+        fprintf(stderr, "socket buffers: snd %d rcv %d\n", sb, rb);
+    }
+}
 static int connect_retry(const char *host, const char *port) {
     for (;;) {   /* retry every 200 ms like util_loop_connect (src/util.c:26-38) */
         struct addrinfo hints, *res = 0;
@@ -56,8 +70,7 @@ static int connect_retry(const char *host, const char *port) {
         if (getaddrinfo(host, port, &hints, &res) == 0) {
             int s = socket(res->ai_family, res->ai_socktype, res->ai_protocol);
             if (s >= 0 && connect(s, res->ai_addr, res->ai_addrlen) == 0) {
-                int one = 1;
-                setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+                tune_socket(s);
                 freeaddrinfo(res);
                 return s;
             }
@@ -101,7 +114,7 @@ int node_new(node **out, int party, int num_parties, char **endpoints) {
         for (int k = party; k < num_parties; k++) {
             int s = accept(ls, 0, 0);
             if (s < 0) { close(ls); goto fail; }
-            setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+            tune_socket(s);
             int32_t other = 0;
             if (io_all(s, &other, sizeof other, 0) || other <= party || other > num_parties || n->fd[other - 1] >= 0) {
                 fprintf(stderr, "Party %d received invalid party number %d from remote\n", party, other);

@@ -3,6 +3,7 @@
  * step runs on the MI355X through liblinreg_gc; this file moves bytes between parties. */
 #define _GNU_SOURCE
 #include <errno.h>
+#include <malloc.h>
 #include <math.h>
 #include <openssl/rand.h>
 #include <pthread.h>
@@ -49,6 +50,16 @@ int send_pmsg(node *self, int to, const uint64_t *vec, size_t n, uint64_t value)
     int rc = net_send(self, to, buf, sz + sizeof sz);
     free(buf);
     return rc;
+}
+/* the framed bytes of send_pmsg (8-byte length + protobuf), malloc'd */
+static uint8_t *frame_pmsg(const uint64_t *vec, size_t n, uint64_t value, size_t *len) {
+    size_t sz = pmsg_packed_size(vec, n, value);
+    uint8_t *buf = malloc(sz + sizeof(size_t));
+    if (!buf) return NULL;
+    memcpy(buf, &sz, sizeof sz);
+    pmsg_pack(vec, n, value, buf + sizeof sz);
+    *len = sz + sizeof sz;
+    return buf;
 }
 int recv_pmsg(node *self, int from, uint64_t **vec, size_t *n, uint64_t *value) {
     size_t sz = 0;
@@ -129,23 +140,82 @@ int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
 }
 
 /* ---------------------------------------------------------------- phase 1: trusted initializer */
+/* Per batch the TI first encodes every message on a pool of threads (varint packing is the CPU cost),
+ * then one sender thread per data provider writes that provider's messages in loop order. */
+typedef struct { uint8_t *buf; size_t len; } ti_frame;
 typedef struct {
-    node *self;
-    int owner;                 /* 0-based party index of the destination data provider */
-    size_t n, nb;
-    const int *pa, *pb;        /* owners of the two rows of each pair of the batch */
+    size_t n, nb, first, stride;      /* this thread encodes messages first, first + stride, ... of 2 * nb */
     const uint64_t *x, *y, *r, *xyr;
+    ti_frame *frames;                 /* [2q] = (y, <x,y> - r) for party a, [2q + 1] = (x, r) for party b */
     int failed;
-} ti_sender;
-static void *ti_sender_main(void *arg) {
-    ti_sender *t = arg;
-    for (size_t q = 0; q < t->nb && !t->failed; q++) {
-        if (t->pa[q] == t->owner) t->failed |= send_pmsg(t->self, t->owner + 1, t->y + q * t->n, t->n, t->xyr[q]);   /* (y, <x,y> - r) */
-        if (t->pb[q] == t->owner) t->failed |= send_pmsg(t->self, t->owner + 1, t->x + q * t->n, t->n, t->r[q]);     /* (x, r) */
+} ti_encoder;
+static void *ti_encoder_main(void *arg) {
+    ti_encoder *t = arg;
+    for (size_t m = t->first; m < 2 * t->nb; m += t->stride) {
+        size_t q = m >> 1;
+        ti_frame *f = &t->frames[m];
+        f->buf = (m & 1) ? frame_pmsg(t->x + q * t->n, t->n, t->r[q], &f->len)
+                         : frame_pmsg(t->y + q * t->n, t->n, t->xyr[q], &f->len);
+        if (!f->buf) t->failed = 1;
     }
     return NULL;
 }
+/* A ring of encoded batches decouples the destinations: the main thread generates and encodes batch
+ * after batch; every data provider has a persistent sender thread that walks the batches at the pace
+ * of ITS socket (a provider whose queues are full must not stall the messages of the others); a slot
+ * is reused once all senders are through with it. */
+enum { kTiRing = 8 };
+typedef struct {
+    ti_frame *frames;          /* 2 * batch frames */
+    size_t q0, nb;             /* pairs [q0, q0 + nb) */
+    int done;                  /* senders finished with this slot */
+} ti_slot;
+typedef struct {
+    node *self;
+    int P;
+    const int *pa_of, *pb_of;
+    ti_slot slot[kTiRing];
+    size_t ready;              /* batches published so far */
+    size_t total;              /* number of batches, known from the start */
+    int failed;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} ti_ring;
+typedef struct { ti_ring *ring; int owner; } ti_sender;
+static void *ti_sender_main(void *arg) {
+    ti_sender *t = arg;
+    ti_ring *R = t->ring;
+    for (size_t b = 0; b < R->total; b++) {
+        pthread_mutex_lock(&R->mu);
+        while (R->ready <= b && !R->failed) pthread_cond_wait(&R->cv, &R->mu);
+        int failed = R->failed;
+        pthread_mutex_unlock(&R->mu);
+        if (failed) break;
+        ti_slot *S = &R->slot[b % kTiRing];
+        const int *pa = R->pa_of + S->q0, *pb = R->pb_of + S->q0;
+        int bad = 0;
+        for (size_t q = 0; q < S->nb && !bad; q++) {
+            if (pa[q] == t->owner) bad |= net_send(R->self, t->owner + 1, S->frames[2 * q].buf, S->frames[2 * q].len);
+            if (pb[q] == t->owner) bad |= net_send(R->self, t->owner + 1, S->frames[2 * q + 1].buf, S->frames[2 * q + 1].len);
+        }
+        pthread_mutex_lock(&R->mu);
+        if (bad) R->failed = 1;
+        S->done++;
+        pthread_cond_broadcast(&R->cv);
+        pthread_mutex_unlock(&R->mu);
+        if (bad) break;
+    }
+    return NULL;
+}
+/* Messages of ~0.5 MB are allocated and freed hundreds of thousands of times, by different threads:
+ * keep them on the heap instead of one mmap/munmap (page faults, TLB shootdowns) per message. */
+static void tune_malloc(void) {
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
+}
 int run_trusted_initializer(node *self, config *c, int w1, int device) {
+    tune_malloc();
     uint8_t seed[16];
     RAND_bytes(seed, sizeof seed);                       /* newBCipherRandomGen (src/phase1.c:243) */
     const char *fixed = getenv("LINREG_TI_SEED");        /* tests only: 32 hex digits pin the TI stream */
@@ -158,6 +228,9 @@ int run_trusted_initializer(node *self, config *c, int w1, int device) {
     int *pa_of = NULL, *pb_of = NULL;
     ti_sender *snd = NULL;
     pthread_t *tid = NULL;
+    ti_ring *R = NULL;
+    uint64_t *x = NULL, *y = NULL, *r = NULL, *xyr = NULL;
+    int rc = 1, started = 0;
     for (size_t i = 0; i <= c->d; i++)
         for (size_t j = 0; j <= i && j < c->d; j++) {
             int pa = config_owner(c, i), pb = config_owner(c, j);
@@ -168,35 +241,83 @@ int run_trusted_initializer(node *self, config *c, int w1, int device) {
     size_t batch = ((size_t)64 << 20) / (n * 8);          /* about 64 MiB of x (and of y) per batch */
     if (batch < 1) batch = 1;
     if (batch > 1024) batch = 1024;
-    uint64_t *x = malloc(batch * n * 8), *y = malloc(batch * n * 8), *r = malloc(batch * 8), *xyr = malloc(batch * 8);
-    int rc = 1;
-    /* Each data provider reads its TI socket in its own pair order, so the per-destination message
-     * sequences are independent: one sender thread per data provider encodes and sends that
-     * provider's messages of the batch, in order. */
+    x = malloc(batch * n * 8); y = malloc(batch * n * 8); r = malloc(batch * 8); xyr = malloc(batch * 8);
     const int P = c->num_parties - 2;
     snd = calloc((size_t)P, sizeof *snd);
     tid = calloc((size_t)P, sizeof *tid);
-    for (size_t q0 = 0; q0 < np; q0 += batch) {
-        size_t nb = np - q0 < batch ? np - q0 : batch;
-        LGC(lgc_ti_generate(device, seed, q0, nb, n, w1, x, y, r, xyr));
-        for (int k = 0; k < P; k++) {
-            ti_sender t = {self, k + 2, n, nb, pa_of + q0, pb_of + q0, x, y, r, xyr, 0};
-            snd[k] = t;
-            check(!pthread_create(&tid[k], NULL, ti_sender_main, &snd[k]), "pthread_create failed");
-        }
-        int failed = 0;
-        for (int k = 0; k < P; k++) { pthread_join(tid[k], NULL); failed |= snd[k].failed; }
-        check(!failed, "Could not send message to a data provider");
+    R = calloc(1, sizeof *R);
+    check(x && y && r && xyr && snd && tid && R, "out of memory");
+    R->self = self; R->P = P; R->pa_of = pa_of; R->pb_of = pb_of;
+    R->total = (np + batch - 1) / batch;
+    pthread_mutex_init(&R->mu, NULL); pthread_cond_init(&R->cv, NULL);
+    for (int k = 0; k < kTiRing; k++) {
+        R->slot[k].frames = calloc(2 * batch, sizeof(ti_frame));
+        check(R->slot[k].frames, "out of memory");
+        R->slot[k].done = P;                              /* free */
     }
+    for (int k = 0; k < P; k++) {
+        snd[k].ring = R; snd[k].owner = k + 2;
+        check(!pthread_create(&tid[k], NULL, ti_sender_main, &snd[k]), "pthread_create failed");
+        started = k + 1;
+    }
+    enum { kEnc = 16 };
+    ti_encoder enc[kEnc];
+    pthread_t etid[kEnc];
+    const int timing = getenv("LINREG_TIMING") != NULL;
+    double t_gen = 0, t_enc = 0, t_wait = 0, t_all = wall_clock();
+    for (size_t b = 0; b < R->total; b++) {
+        const size_t q0 = b * batch, nb = np - q0 < batch ? np - q0 : batch;
+        ti_slot *S = &R->slot[b % kTiRing];
+        double t0 = wall_clock();
+        pthread_mutex_lock(&R->mu);                       /* wait until every sender is through with the slot */
+        while (S->done < P && !R->failed) pthread_cond_wait(&R->cv, &R->mu);
+        int failed = R->failed;
+        pthread_mutex_unlock(&R->mu);
+        check(!failed, "Could not send message to a data provider");
+        for (size_t m = 0; m < 2 * batch; m++) { free(S->frames[m].buf); S->frames[m].buf = NULL; }
+        double t1 = wall_clock();
+        LGC(lgc_ti_generate(device, seed, q0, nb, n, w1, x, y, r, xyr));
+        double t2 = wall_clock();
+        for (int e = 0; e < kEnc; e++) {
+            ti_encoder t = {n, nb, (size_t)e, (size_t)kEnc, x, y, r, xyr, S->frames, 0};
+            enc[e] = t;
+            check(!pthread_create(&etid[e], NULL, ti_encoder_main, &enc[e]), "pthread_create failed");
+        }
+        for (int e = 0; e < kEnc; e++) { pthread_join(etid[e], NULL); failed |= enc[e].failed; }
+        check(!failed, "out of memory while encoding TI messages");
+        double t3 = wall_clock();
+        t_wait += t1 - t0; t_gen += t2 - t1; t_enc += t3 - t2;
+        pthread_mutex_lock(&R->mu);
+        S->q0 = q0; S->nb = nb; S->done = 0;
+        R->ready = b + 1;
+        pthread_cond_broadcast(&R->cv);
+        pthread_mutex_unlock(&R->mu);
+    }
+    for (int k = 0; k < P; k++) pthread_join(tid[k], NULL);
+    started = 0;
+    check(!R->failed, "Could not send message to a data provider");
+    if (timing) fprintf(stderr, "TI: %zu pairs, batches of %zu, ring of %d: generate %.2fs, encode %.2fs, waiting for a free slot %.2fs, total %.2fs\n",
+                        np, batch, (int)kTiRing, t_gen, t_enc, t_wait, wall_clock() - t_all);
     rc = 0;
 error:
+    if (R) {
+        if (started) {                                    /* unblock and collect the senders */
+            pthread_mutex_lock(&R->mu); R->failed = 1; pthread_cond_broadcast(&R->cv); pthread_mutex_unlock(&R->mu);
+            for (int k = 0; k < started; k++) pthread_join(tid[k], NULL);
+        }
+        for (int k = 0; k < kTiRing; k++) {
+            if (R->slot[k].frames) for (size_t m = 0; m < 2 * batch; m++) free(R->slot[k].frames[m].buf);
+            free(R->slot[k].frames);
+        }
+        free(R);
+    }
     free(x); free(y); free(r); free(xyr); free(pa_of); free(pb_of); free(snd); free(tid);
     return rc;
 }
 
 /* ---------------------------------------------------------------- phase 1: data provider */
 /* TI-mode plumbing: a bounded queue of decoded TI messages per peer, and the per-peer worker */
-typedef struct { uint64_t *vec; uint64_t val; } ti_item;
+typedef struct { uint8_t *raw; size_t len; uint64_t *vec; uint64_t val; } ti_item;   /* raw: undecoded message (decoded by the worker) */
 typedef struct {
     ti_item *items;
     size_t cap, head, count;
@@ -209,7 +330,7 @@ static void ti_queue_init(ti_queue *q, size_t cap) {
     pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL);
 }
 static void ti_queue_destroy(ti_queue *q) {
-    for (size_t i = 0; i < q->count; i++) free(q->items[(q->head + i) % q->cap].vec);
+    for (size_t i = 0; i < q->count; i++) { free(q->items[(q->head + i) % q->cap].vec); free(q->items[(q->head + i) % q->cap].raw); }
     free(q->items); pthread_mutex_destroy(&q->mu); pthread_cond_destroy(&q->cv);
 }
 static void ti_queue_close(ti_queue *q) {
@@ -249,25 +370,119 @@ static int recv_pmsg_timed(node *self, int from, uint64_t **vec, size_t *n, uint
     self->wait_ns[from - 1] += (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
     return rc;
 }
-static void *ti_worker_main(void *arg) {
-    ti_worker *w = arg;
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+/* Party b of a run of pairs with one peer, pipelined.  b's first message (b + x) depends only on
+ * the TI's message, so this thread sends the masks of successive pairs back to back, while a second
+ * thread receives party a's replies and finishes the shares (<a - y, b> - r): party b then never
+ * idles for a round trip, and party a always finds its next input waiting.  Both directions of the
+ * socket carry the same bytes in the same order as the one-pair-at-a-time exchange. */
+typedef struct {
+    ti_worker *w;
+    const ti_pair **pr;        /* this worker's pairs, in order */
+    uint64_t *r;               /* the TI's r of each pair (filled by the sender side) */
+    size_t total;
+    size_t sent;               /* pairs whose mask has been sent (published under mu) */
+    int stop;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} ti_b_pipe;
+static void *ti_b_finisher(void *arg) {
+    ti_b_pipe *bp = arg;
+    ti_worker *w = bp->w;
     const size_t n = w->n;
     const int to = w->peer + 1;
+    for (size_t k = 0; k < bp->total; k++) {
+        pthread_mutex_lock(&bp->mu);
+        while (bp->sent <= k && !bp->stop) pthread_cond_wait(&bp->cv, &bp->mu);
+        int stop = bp->sent <= k;
+        pthread_mutex_unlock(&bp->mu);
+        if (stop) break;
+        uint64_t *in = 0, inval = 0, share = 0, sub = bp->r[k];
+        size_t in_n = 0;
+        uint32_t col = bp->pr[k]->col;
+        if (recv_pmsg_timed(w->self, to, &in, &in_n, &inval) || in_n != n) { fprintf(stderr, "Could not receive message from party A (%d)\n", w->peer); w->failed = 1; }
+        else if (lgc_p1_dot(w->p1, in, 0, &col, 1, &sub, &share)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* <a-y, b> - r */
+        free(in);
+        if (w->failed) break;
+        *bp->pr[k]->dst = share;
+    }
+    return NULL;
+}
+static int ti_worker_b_pipelined(ti_worker *w, const ti_pair **mine, size_t total) {
+    const size_t n = w->n;
+    const int to = w->peer + 1;
+    ti_b_pipe bp;
+    memset(&bp, 0, sizeof bp);
+    bp.w = w; bp.pr = mine; bp.total = total;
+    bp.r = malloc((total + 1) * sizeof *bp.r);
+    uint64_t *tmp = malloc(n * 8);
+    pthread_mutex_init(&bp.mu, NULL); pthread_cond_init(&bp.cv, NULL);
+    pthread_t fin;
+    int have_fin = bp.r && tmp && !pthread_create(&fin, NULL, ti_b_finisher, &bp);
+    if (!have_fin) w->failed = 1;
+    for (size_t k = 0; k < total && !w->failed; k++) {
+        ti_item it = {0, 0, 0, 0};
+        size_t ti_n = 0;
+        uint32_t col = mine[k]->col;
+        if (ti_queue_pop(w->q, &it)) { w->failed = 1; break; }
+        if (pmsg_unpack(it.raw, it.len, &it.vec, &ti_n, &it.val) || ti_n != n) { fprintf(stderr, "Could not decode message from TI\n"); w->failed = 1; }
+        else if (lgc_p1_mask(w->p1, &col, 1, it.vec, +1, tmp)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }        /* b + x */
+        else if (send_pmsg(w->self, to, tmp, n, 0)) { fprintf(stderr, "Could not send message to party A (%d)\n", w->peer); w->failed = 1; }
+        free(it.raw); free(it.vec);
+        if (w->failed) break;
+        bp.r[k] = it.val;
+        pthread_mutex_lock(&bp.mu); bp.sent = k + 1; pthread_cond_broadcast(&bp.cv); pthread_mutex_unlock(&bp.mu);
+    }
+    pthread_mutex_lock(&bp.mu); bp.stop = 1; pthread_cond_broadcast(&bp.cv); pthread_mutex_unlock(&bp.mu);
+    if (have_fin) pthread_join(fin, NULL);
+    pthread_mutex_destroy(&bp.mu); pthread_cond_destroy(&bp.cv);
+    free(bp.r); free(tmp);
+    return w->failed;
+}
+
+static void *ti_worker_main(void *arg) {
+    ti_worker *w = arg;
+    const int timing = getenv("LINREG_TIMING") != NULL;
+    double t_pop = 0, t_recv = 0, t_gpu = 0, t_send = 0, t0 = 0;
+    size_t done = 0;
+    const size_t n = w->n;
+    const int to = w->peer + 1;
+    {   /* the role towards one peer is fixed by the column ownership (the later party owns the rows):
+         * when this party is b throughout, run the pipelined form */
+        size_t cnt = 0, as_b = 0;
+        for (size_t k = 0; k < w->npairs; k++) if (w->pairs[k].peer == w->peer) { cnt++; as_b += !w->pairs[k].is_a; }
+        if (cnt && as_b == cnt && !getenv("LINREG_TI_LOCKSTEP")) {
+            const ti_pair **mine = malloc(cnt * sizeof *mine);
+            size_t m = 0;
+            for (size_t k = 0; k < w->npairs; k++) if (w->pairs[k].peer == w->peer) mine[m++] = &w->pairs[k];
+            ti_worker_b_pipelined(w, mine, cnt);
+            free(mine);
+            if (w->failed) ti_queue_close(w->q);
+            return NULL;
+        }
+    }
     uint64_t *tmp = malloc(n * 8);
     for (size_t k = 0; k < w->npairs && !w->failed; k++) {
         const ti_pair *pr = &w->pairs[k];
         if (pr->peer != w->peer) continue;
-        ti_item it = {0, 0};
+        ti_item it = {0, 0, 0, 0};
         uint64_t *in = 0, inval = 0, share = 0, sub;
-        size_t in_n = 0;
+        size_t in_n = 0, ti_n = 0;
+        if (timing) t0 = now_s();
         if (ti_queue_pop(w->q, &it)) { w->failed = 1; break; }
+        if (timing) t_pop += now_s() - t0;
+        if (pmsg_unpack(it.raw, it.len, &it.vec, &ti_n, &it.val) || ti_n != n) {
+            fprintf(stderr, "Could not decode message from TI\n"); w->failed = 1; free(it.raw); free(it.vec); break;
+        }
+        free(it.raw); it.raw = 0;
         uint32_t col = pr->col;
         sub = it.val;
         if (pr->is_a) {                                   /* party a (phase1.c:171-197) */
+            double ta = timing ? now_s() : 0, tb, tc;
             if (recv_pmsg_timed(w->self, to, &in, &in_n, &inval) || in_n != n) { fprintf(stderr, "Could not receive message from party B (%d)\n", w->peer); w->failed = 1; }
-            else if (lgc_p1_mask(w->p1, &col, 1, it.vec, -1, tmp)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* a - y */
-            else if (send_pmsg(w->self, to, tmp, n, 0)) { fprintf(stderr, "Could not send message to party B (%d)\n", w->peer); w->failed = 1; }
-            else if (lgc_p1_dot(w->p1, in, it.vec, 0, 1, &sub, &share)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* <b+x, y> - (xy - r) */
+            else if ((tb = timing ? now_s() : 0, lgc_p1_ti_a(w->p1, col, it.vec, in, sub, tmp, &share))) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* a - y and <b+x, y> - (xy - r) */
+            else if ((tc = timing ? now_s() : 0, send_pmsg(w->self, to, tmp, n, 0))) { fprintf(stderr, "Could not send message to party B (%d)\n", w->peer); w->failed = 1; }
+            else if (timing) { double td = now_s(); t_recv += tb - ta; t_gpu += tc - tb; t_send += td - tc; }
         } else {                                          /* party b (phase1.c:198-223) */
             if (lgc_p1_mask(w->p1, &col, 1, it.vec, +1, tmp)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }        /* b + x */
             else if (send_pmsg(w->self, to, tmp, n, 0)) { fprintf(stderr, "Could not send message to party A (%d)\n", w->peer); w->failed = 1; }
@@ -276,7 +491,10 @@ static void *ti_worker_main(void *arg) {
         }
         free(in); free(it.vec);
         if (!w->failed) *pr->dst = share;
+        done++;
     }
+    if (timing) fprintf(stderr, "worker peer %d: %zu pairs; as party a: recv %.2fs gpu %.2fs send %.2fs; TI queue wait %.2fs (all roles)\n",
+                        w->peer, done, t_recv, t_gpu, t_send, t_pop);
     free(tmp);
     if (w->failed) ti_queue_close(w->q);                  /* unblock the reader */
     return NULL;
@@ -288,6 +506,7 @@ static void column_of(const int64_t *Xq, const int64_t *yq, size_t n, size_t d, 
 
 int run_party(node *self, config *c, int precision, int precision_p2, int w1, int w2, int use_ot, int device,
                      uint64_t **res_A, uint64_t **res_b) {
+    tune_malloc();
     const size_t n = c->n, d = c->d, T = d * (d + 1) / 2;
     const int me = c->party - 1, last = c->num_parties - 1;
     int64_t *Xq = malloc(n * d * 8), *yq = malloc(n * 8);
@@ -334,6 +553,12 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
                               i < d ? share_A + idx(i, j) : share_b + j};
                 pairs[npairs++] = pr;
             }
+        /* The TI socket delivers this party's messages in loop order, i.e. in runs of consecutive pairs with
+         * the SAME peer (a whole row against one peer's columns).  The queues must hold more than such a
+         * run, or the reader blocks on one worker's full queue while the other workers starve. */
+        size_t qcap = ((size_t)256 << 20) / (n * 8 + 64);
+        if (qcap < 64) qcap = 64;
+        if (qcap > 4096) qcap = 4096;
         ti_queue *queues = calloc((size_t)np_all, sizeof *queues);
         ti_worker *workers = calloc((size_t)np_all, sizeof *workers);
         pthread_t *tids = calloc((size_t)np_all, sizeof *tids);
@@ -344,19 +569,36 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
             size_t cnt = 0;
             for (size_t q = 0; q < npairs; q++) cnt += pairs[q].peer == k;
             if (!cnt) continue;
-            ti_queue_init(&queues[k], 8);
+            ti_queue_init(&queues[k], qcap);
             ti_worker w = {self, p1, n, k, pairs, npairs, &queues[k], 0};
             workers[k] = w;
             if (pthread_create(&tids[k], NULL, ti_worker_main, &workers[k])) { failed = 1; break; }
             started[k] = 1;
         }
         /* reader: this thread */
+        double rd_hdr = 0, rd_body = 0, rd_push = 0;
+        const int timing_r = getenv("LINREG_TIMING") != NULL;
         for (size_t q = 0; q < npairs && !failed; q++) {
-            ti_item it = {0, 0};
-            size_t tn = 0;
-            if (recv_pmsg(self, 1, &it.vec, &tn, &it.val) || tn != n) { fprintf(stderr, "Could not receive message from TI\n"); failed = 1; free(it.vec); break; }
-            if (ti_queue_push(&queues[pairs[q].peer], it)) { failed = 1; free(it.vec); break; }   /* the worker gave up */
+            ti_item it = {0, 0, 0, 0};
+            size_t sz = 0;
+            double r0 = timing_r ? now_s() : 0, r1, r2;
+            if (timing_r) {
+                if (net_recv(self, 1, &sz, sizeof sz)) { failed = 1; break; }
+                r1 = now_s();
+                if (!(it.raw = malloc(sz ? sz : 1)) || net_recv(self, 1, it.raw, sz)) { failed = 1; free(it.raw); break; }
+                r2 = now_s();
+                it.len = sz;
+                if (ti_queue_push(&queues[pairs[q].peer], it)) { failed = 1; free(it.raw); break; }
+                rd_hdr += r1 - r0; rd_body += r2 - r1; rd_push += now_s() - r2;
+                continue;
+            }
+            if (net_recv(self, 1, &sz, sizeof sz) || !(it.raw = malloc(sz ? sz : 1)) || net_recv(self, 1, it.raw, sz)) {
+                fprintf(stderr, "Could not receive message from TI\n"); failed = 1; free(it.raw); break;
+            }
+            it.len = sz;
+            if (ti_queue_push(&queues[pairs[q].peer], it)) { failed = 1; free(it.raw); break; }   /* the worker gave up */
         }
+        if (timing_r) fprintf(stderr, "reader: %zu TI messages: waiting for header %.2fs, body %.2fs, queue push %.2fs\n", npairs, rd_hdr, rd_body, rd_push);
         for (int k = 2; k < np_all; k++) if (started[k]) ti_queue_close(&queues[k]);
         for (int k = 2; k < np_all; k++)
             if (started[k]) { pthread_join(tids[k], NULL); failed |= workers[k].failed; ti_queue_destroy(&queues[k]); }

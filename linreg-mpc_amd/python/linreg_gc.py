@@ -86,6 +86,7 @@ def lib():
             ("lgc_p1_create", [C.POINTER(vp), ci, sz, sz, ci, ci]), ("lgc_p1_set_data", [vp, vp, vp]),
             ("lgc_p1_local", [vp, sz, sz, ci, vp, vp]), ("lgc_p1_mask", [vp, vp, sz, vp, ci, vp]),
             ("lgc_p1_dot", [vp, vp, vp, vp, sz, vp, vp]),
+            ("lgc_p1_ti_a", [vp, C.c_uint32, vp, vp, C.c_uint64, vp, C.POINTER(C.c_uint64)]),
             ("lgc_ti_generate", [ci, C.c_char_p, C.c_uint64, sz, sz, ci, vp, vp, vp, vp]),
             ("lgc_party_create", [C.POINTER(vp), ci, C.POINTER(System), ci, C.c_char_p, sz]),
             ("lgc_party_input_pairs", [vp, sz, vp, vp]), ("lgc_party_encode_inputs", [vp, sz, vp, vp]),
@@ -281,6 +282,14 @@ class Phase1:
         out = np.empty_like(V)
         _chk(lib().lgc_p1_mask(self._h, _vp(cols), len(cols), _vp(V), sign, _vp(out)))
         return out
+
+    def ti_a(self, col, y, inn, sub):
+        """party a of one inner_product_ti in a single pass: (a - y, <inn, y> - sub)"""
+        y = np.ascontiguousarray(y, dtype=np.uint64).reshape(self.n)
+        inn = np.ascontiguousarray(inn, dtype=np.uint64).reshape(self.n)
+        out = np.empty(self.n, dtype=np.uint64); share = C.c_uint64()
+        _chk(lib().lgc_p1_ti_a(self._h, int(col), _vp(y), _vp(inn), C.c_uint64(int(sub)), _vp(out), C.byref(share)))
+        return out, np.uint64(share.value)
 
     def dot(self, A, B=None, cols=None, sub=None):
         A = np.ascontiguousarray(A, dtype=np.uint64).reshape(-1, self.n)

@@ -69,6 +69,8 @@ def test_ti_mode_shares_match_oracle(lgc, oracle, gccpu):
         bx = dps[b].mask([j], x[q:q + 1], +1)                       # b + x -> a
         ay = dps[a].mask([i], y[q:q + 1], -1)                       # a - y -> b
         share_a = dps[a].dot(bx, B=y[q:q + 1], sub=xyr[q:q + 1])[0]  # <b+x, y> - (xy - r)
+        ay2, share_a2 = dps[a].ti_a(i, y[q], bx[0], xyr[q])          # the same two results in one pass
+        assert np.array_equal(ay2, ay[0]) and int(share_a2) == int(share_a)
         share_b = dps[b].dot(ay, cols=[j], sub=r[q:q + 1])[0]        # <a-y, b> - r
         if i < d:
             gA[a, oracle.lib.orc_idx(i, j)] = share_a; gA[b, oracle.lib.orc_idx(i, j)] = share_b

@@ -82,3 +82,4 @@ if "c4s" in which: run("c4-small-n-ring", 1000, 500, [0, 100, 200, 300, 400], "c
                        ["--width_phase2=32", "--prec_phase2=30", "--table_ring"], w2=32)
 if "c4r" in which: run("c4-ring", 50000, 500, [0, 100, 200, 300, 400], "cgd", 20, 0.001,
                        ["--width_phase2=32", "--prec_phase2=30", "--table_ring"], w2=32)
+if "c4m" in which: run("c4-mid", 50000, 200, [0, 40, 80, 120, 160], "cgd", 2, 0.001, ["--width_phase2=32", "--prec_phase2=30", "--table_ring"], w2=32)
