@@ -440,6 +440,86 @@ static int ti_worker_b_pipelined(ti_worker *w, const ti_pair **mine, size_t tota
     return w->failed;
 }
 
+/* Party a of a run of pairs with one peer, as two stages: a prefetch thread takes the TI's message
+ * and party b's message off the queues / socket and decodes both, while this thread runs the fused
+ * device step and sends the reply.  Same bytes, same order on the socket. */
+enum { kTiAhead = 4 };
+typedef struct { uint64_t *y, *in, sub; } ti_a_input;
+typedef struct {
+    ti_worker *w;
+    size_t total;
+    ti_a_input slot[kTiAhead];
+    size_t produced, consumed;
+    int stop;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} ti_a_pipe;
+static void *ti_a_prefetch(void *arg) {
+    ti_a_pipe *ap = arg;
+    ti_worker *w = ap->w;
+    const size_t n = w->n;
+    const int to = w->peer + 1;
+    for (size_t k = 0; k < ap->total; k++) {
+        ti_item it = {0, 0, 0, 0};
+        ti_a_input x = {0, 0, 0};
+        size_t ti_n = 0, in_n = 0;
+        uint64_t inval = 0;
+        int bad = 0;
+        if (ti_queue_pop(w->q, &it)) bad = 1;
+        else if (pmsg_unpack(it.raw, it.len, &it.vec, &ti_n, &it.val) || ti_n != n) { fprintf(stderr, "Could not decode message from TI\n"); bad = 1; }
+        else if (recv_pmsg_timed(w->self, to, &x.in, &in_n, &inval) || in_n != n) { fprintf(stderr, "Could not receive message from party B (%d)\n", w->peer); bad = 1; }
+        free(it.raw);
+        x.y = it.vec; x.sub = it.val;
+        pthread_mutex_lock(&ap->mu);
+        while (!bad && ap->produced - ap->consumed == kTiAhead && !ap->stop) pthread_cond_wait(&ap->cv, &ap->mu);
+        if (bad || ap->stop) {
+            ap->stop = 1;
+            if (bad) w->failed = 1;
+            pthread_cond_broadcast(&ap->cv);
+            pthread_mutex_unlock(&ap->mu);
+            free(x.y); free(x.in);
+            return NULL;
+        }
+        ap->slot[ap->produced % kTiAhead] = x;
+        ap->produced++;
+        pthread_cond_broadcast(&ap->cv);
+        pthread_mutex_unlock(&ap->mu);
+    }
+    return NULL;
+}
+static int ti_worker_a_pipelined(ti_worker *w, const ti_pair **mine, size_t total) {
+    const size_t n = w->n;
+    const int to = w->peer + 1;
+    ti_a_pipe ap;
+    memset(&ap, 0, sizeof ap);
+    ap.w = w; ap.total = total;
+    pthread_mutex_init(&ap.mu, NULL); pthread_cond_init(&ap.cv, NULL);
+    uint64_t *tmp = malloc(n * 8);
+    pthread_t pre;
+    int have = tmp && !pthread_create(&pre, NULL, ti_a_prefetch, &ap);
+    if (!have) w->failed = 1;
+    for (size_t k = 0; k < total && !w->failed; k++) {
+        pthread_mutex_lock(&ap.mu);
+        while (ap.produced == ap.consumed && !ap.stop) pthread_cond_wait(&ap.cv, &ap.mu);
+        int empty = ap.produced == ap.consumed;
+        ti_a_input x = ap.slot[ap.consumed % kTiAhead];
+        pthread_mutex_unlock(&ap.mu);
+        if (empty) { w->failed = 1; break; }
+        uint64_t share = 0;
+        if (lgc_p1_ti_a(w->p1, mine[k]->col, x.y, x.in, x.sub, tmp, &share)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* a - y and <b+x, y> - (xy - r) */
+        else if (send_pmsg(w->self, to, tmp, n, 0)) { fprintf(stderr, "Could not send message to party B (%d)\n", w->peer); w->failed = 1; }
+        free(x.y); free(x.in);
+        pthread_mutex_lock(&ap.mu); ap.consumed++; pthread_cond_broadcast(&ap.cv); pthread_mutex_unlock(&ap.mu);
+        if (!w->failed) *mine[k]->dst = share;
+    }
+    pthread_mutex_lock(&ap.mu); ap.stop = 1; pthread_cond_broadcast(&ap.cv); pthread_mutex_unlock(&ap.mu);
+    if (have) pthread_join(pre, NULL);
+    for (; ap.consumed < ap.produced; ap.consumed++) { free(ap.slot[ap.consumed % kTiAhead].y); free(ap.slot[ap.consumed % kTiAhead].in); }
+    pthread_mutex_destroy(&ap.mu); pthread_cond_destroy(&ap.cv);
+    free(tmp);
+    return w->failed;
+}
+
 static void *ti_worker_main(void *arg) {
     ti_worker *w = arg;
     const int timing = getenv("LINREG_TIMING") != NULL;
@@ -448,14 +528,14 @@ static void *ti_worker_main(void *arg) {
     const size_t n = w->n;
     const int to = w->peer + 1;
     {   /* the role towards one peer is fixed by the column ownership (the later party owns the rows):
-         * when this party is b throughout, run the pipelined form */
+         * run the pipelined form of that role */
         size_t cnt = 0, as_b = 0;
         for (size_t k = 0; k < w->npairs; k++) if (w->pairs[k].peer == w->peer) { cnt++; as_b += !w->pairs[k].is_a; }
-        if (cnt && as_b == cnt && !getenv("LINREG_TI_LOCKSTEP")) {
+        if (cnt && (as_b == cnt || as_b == 0) && !getenv("LINREG_TI_LOCKSTEP")) {
             const ti_pair **mine = malloc(cnt * sizeof *mine);
             size_t m = 0;
             for (size_t k = 0; k < w->npairs; k++) if (w->pairs[k].peer == w->peer) mine[m++] = &w->pairs[k];
-            ti_worker_b_pipelined(w, mine, cnt);
+            if (as_b) ti_worker_b_pipelined(w, mine, cnt); else ti_worker_a_pipelined(w, mine, cnt);
             free(mine);
             if (w->failed) ti_queue_close(w->q);
             return NULL;
@@ -507,6 +587,7 @@ static void column_of(const int64_t *Xq, const int64_t *yq, size_t n, size_t d, 
 int run_party(node *self, config *c, int precision, int precision_p2, int w1, int w2, int use_ot, int device,
                      uint64_t **res_A, uint64_t **res_b) {
     tune_malloc();
+    const double t_start = wall_clock();
     const size_t n = c->n, d = c->d, T = d * (d + 1) / 2;
     const int me = c->party - 1, last = c->num_parties - 1;
     int64_t *Xq = malloc(n * d * 8), *yq = malloc(n * 8);
@@ -519,6 +600,7 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
     check(!read_values(c->input, n * d, precision, normalizer, w2, Xq), "Could not read data");
     check(fscanf(c->input, "%zu", &n2) == 1 && n2 == n, "Input dimensions invalid");
     check(!read_values(c->input, n, precision, normalizer, w2, yq), "Could not read target");
+    if (getenv("LINREG_TIMING")) fprintf(stderr, "party %d: input parsed after %.2fs\n", c->party, wall_clock() - t_start);
     LGC(lgc_p1_create(&p1, device, n, d, w1, precision));
     LGC(lgc_p1_set_data(p1, Xq, yq));
     const size_t c0 = (size_t)c->index_owned[me], c1 = me < last ? (size_t)c->index_owned[me + 1] : d;
@@ -604,6 +686,7 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
             if (started[k]) { pthread_join(tids[k], NULL); failed |= workers[k].failed; ti_queue_destroy(&queues[k]); }
         free(pairs); free(queues); free(workers); free(tids);
         check(!failed, "TI-mode aggregation failed");
+        if (getenv("LINREG_TIMING")) fprintf(stderr, "party %d: TI-mode aggregation done after %.2fs\n", c->party, wall_clock() - t_start);
     } else {
         /* OT mode (src/phase1.c:353-450): one Gilboa batch per peer, peers in a global order */
         for (int lo = 2; lo < c->num_parties; lo++)
