@@ -247,7 +247,10 @@ size_t lgc_ot_u_bytes(uint64_t m);
 /* Gilboa inner products (inner_product_ot_recver / _sender, src/phase1.c:53-96), batched over
  * npairs: OT index (q*n + k)*width + bit; receiver choice = bit of a[q][k] (LSB first), sender
  * correlation 2^bit * b[q][k] + s.  y: npairs*n*width words.  shares: npairs words each side;
- * share_sender + share_receiver = <a[q], b[q]> mod 2^width. */
+ * share_sender + share_receiver = <a[q], b[q]> mod 2^width.
+ * Up to four receives may be in flight on one receiver: every *_recv_finish completes the OLDEST
+ * started batch (the sender answers in order), and one thread may call *_recv_start while another
+ * calls *_recv_finish -- the network round trip of batch k then overlaps the extension of batch k+1. */
 int lgc_ot_gilboa_recv_start(lgc_ot_receiver *r, const uint64_t *a, size_t npairs, size_t n, int width, uint8_t *u_out);
 int lgc_ot_gilboa_send(lgc_ot_sender *s, const uint64_t *b, size_t npairs, size_t n, int width, const uint8_t *u_in,
                        uint64_t *y_out, uint64_t *shares);

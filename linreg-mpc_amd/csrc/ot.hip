@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <deque>
+#include <mutex>
 #include <vector>
 
 #include "../../include/linreg_gc.h"
@@ -221,7 +223,27 @@ struct lgc_ot_receiver {
     uint64_t m, npairs, n;
     int w;
     uint64_t tweak_cur;
+    // receives started but not finished yet, oldest first: *_recv_start parks its state here and
+    // *_recv_finish takes the oldest, so a caller may keep a few batches in flight (one thread
+    // starting and sending u, another receiving the replies and finishing)
+    struct Pending { uint4 *rows; uint64_t *cbits, *avals; uint64_t m, npairs, n; int w; uint64_t tweak_cur; };
+    std::deque<Pending> fifo;
+    std::mutex mu;
 };
+static const size_t kMaxRecvInFlight = 4;
+static void recv_park(lgc_ot_receiver *r) {
+    lgc_ot_receiver::Pending p = {r->rows, r->cbits, r->avals, r->m, r->npairs, r->n, r->w, r->tweak_cur};
+    r->fifo.push_back(p);
+    r->rows = 0; r->cbits = 0; r->avals = 0; r->m = 0;
+}
+static bool recv_unpark(lgc_ot_receiver *r) {
+    if (r->fifo.empty()) return false;
+    lgc_ot_receiver::Pending p = r->fifo.front();
+    r->fifo.pop_front();
+    r->rows = p.rows; r->cbits = p.cbits; r->avals = p.avals; r->m = p.m; r->npairs = p.npairs; r->n = p.n; r->w = p.w;
+    r->tweak_cur = p.tweak_cur;
+    return true;
+}
 
 static int upload_keys(const uint8_t seeds[][16], uint32_t **out) {
     std::vector<uint32_t> rk(128 * 44);
@@ -261,8 +283,7 @@ extern "C" int lgc_ot_receiver_create(lgc_ot_receiver **out, int device, const u
     if (rc) return rc;
     rc = lgc_upload_constants();
     if (rc) return rc;
-    lgc_ot_receiver *r = new lgc_ot_receiver();
-    memset(r, 0, sizeof(*r));
+    lgc_ot_receiver *r = new lgc_ot_receiver();   // value-initialised: scalars and pointers are zero
     r->device = device;
     rc = upload_keys(seeds0, &r->rk0);
     if (!rc) rc = upload_keys(seeds1, &r->rk1);
@@ -280,6 +301,7 @@ extern "C" void lgc_ot_receiver_destroy(lgc_ot_receiver *r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     recv_drop_state(r);
+    while (recv_unpark(r)) recv_drop_state(r);
     if (r->rk0) (void)hipFree(r->rk0);
     if (r->rk1) (void)hipFree(r->rk1);
     delete r;
@@ -333,7 +355,8 @@ extern "C" size_t lgc_ot_u_bytes(uint64_t m) { return (size_t)(round128(m) / 128
 extern "C" int lgc_ot_gilboa_recv_start(lgc_ot_receiver *r, const uint64_t *a, size_t npairs, size_t n, int width, uint8_t *u_out) {
     if (!r || !a || !u_out) return lgc_fail(LGC_EINVAL, "null argument");
     if (width != 32 && width != 64) return lgc_fail(LGC_EINVAL, "width must be 32 or 64");
-    if (r->rows) return lgc_fail(LGC_ESTATE, "a receive is already in flight");
+    std::lock_guard<std::mutex> lock(r->mu);
+    if (r->fifo.size() >= kMaxRecvInFlight) return lgc_fail(LGC_ESTATE, "too many receives in flight (%zu)", r->fifo.size());
     OTCHK(hipSetDevice(r->device));
     const uint64_t nw = (uint64_t)npairs * n, m = nw * (uint64_t)width;
     const uint64_t m128 = round128(m) / 128;
@@ -346,6 +369,7 @@ extern "C" int lgc_ot_gilboa_recv_start(lgc_ot_receiver *r, const uint64_t *a, s
     int rc = recv_extend(r, m, u_out);
     if (rc) { recv_drop_state(r); return rc; }
     r->tweak += m;
+    recv_park(r);
     return LGC_OK;
 }
 extern "C" int lgc_ot_gilboa_send(lgc_ot_sender *s, const uint64_t *b, size_t npairs, size_t n, int width, const uint8_t *u_in,
@@ -376,7 +400,9 @@ extern "C" int lgc_ot_gilboa_send(lgc_ot_sender *s, const uint64_t *b, size_t np
 extern "C" int lgc_ot_gilboa_recv_finish(lgc_ot_receiver *r, const uint64_t *y_in, uint64_t *shares) {
     DevFree dev_guard;   // temporary device buffers are released on every return path
     if (!r || !y_in || !shares) return lgc_fail(LGC_EINVAL, "null argument");
-    if (!r->rows || !r->avals) return lgc_fail(LGC_ESTATE, "no Gilboa receive in flight");
+    std::lock_guard<std::mutex> lock(r->mu);
+    if (r->fifo.empty() || !r->fifo.front().avals) return lgc_fail(LGC_ESTATE, "no Gilboa receive in flight");
+    recv_unpark(r);
     OTCHK(hipSetDevice(r->device));
     uint64_t *dy = 0, *dsh = 0;
     OTCHK(hipMalloc(&dy, r->m * 8)); dev_guard.add(dy); OTCHK(hipMalloc(&dsh, r->npairs * 8)); dev_guard.add(dsh);
@@ -397,7 +423,8 @@ extern "C" int lgc_ot_gilboa_recv_finish(lgc_ot_receiver *r, const uint64_t *y_i
 // choice: m bytes, one per OT (the reference's bool* sel, src/input.c:40-44)
 extern "C" int lgc_ot_labels_recv_start(lgc_ot_receiver *r, const uint8_t *choice, size_t m, uint8_t *u_out) {
     if (!r || !choice || !u_out) return lgc_fail(LGC_EINVAL, "null argument");
-    if (r->rows) return lgc_fail(LGC_ESTATE, "a receive is already in flight");
+    std::lock_guard<std::mutex> lock(r->mu);
+    if (r->fifo.size() >= kMaxRecvInFlight) return lgc_fail(LGC_ESTATE, "too many receives in flight (%zu)", r->fifo.size());
     OTCHK(hipSetDevice(r->device));
     const uint64_t m128 = round128(m) / 128;
     std::vector<uint64_t> packed(m128 * 2, 0);
@@ -408,6 +435,7 @@ extern "C" int lgc_ot_labels_recv_start(lgc_ot_receiver *r, const uint8_t *choic
     int rc = recv_extend(r, m, u_out);
     if (rc) { recv_drop_state(r); return rc; }
     r->tweak += m;
+    recv_park(r);
     return LGC_OK;
 }
 extern "C" int lgc_ot_labels_send(lgc_ot_sender *s, const uint8_t *msg0, const uint8_t *msg1, size_t m, const uint8_t *u_in, uint8_t *e_out) {
@@ -432,7 +460,9 @@ extern "C" int lgc_ot_labels_send(lgc_ot_sender *s, const uint8_t *msg0, const u
 extern "C" int lgc_ot_labels_recv_finish(lgc_ot_receiver *r, const uint8_t *e_in, uint8_t *out) {
     DevFree dev_guard;   // temporary device buffers are released on every return path
     if (!r || !e_in || !out) return lgc_fail(LGC_EINVAL, "null argument");
-    if (!r->rows || r->avals) return lgc_fail(LGC_ESTATE, "no label receive in flight");
+    std::lock_guard<std::mutex> lock(r->mu);
+    if (r->fifo.empty() || r->fifo.front().avals) return lgc_fail(LGC_ESTATE, "no label receive in flight");
+    recv_unpark(r);
     OTCHK(hipSetDevice(r->device));
     uint4 *de = 0, *dout = 0;
     OTCHK(hipMalloc(&de, r->m * 32)); dev_guard.add(de); OTCHK(hipMalloc(&dout, r->m * 16)); dev_guard.add(dout);

@@ -584,6 +584,94 @@ static void column_of(const int64_t *Xq, const int64_t *yq, size_t n, size_t d, 
     for (size_t k = 0; k < n; k++) out[k] = (uint64_t)(row < d ? Xq[k * d + row] : yq[k]);
 }
 
+/* OT mode, sender side: u arrives on one helper thread and y leaves on another while the main
+ * thread runs the extension + Gilboa kernels, two buffers each (the socket copies of 24 bytes per OT
+ * are the cost of this phase; this overlaps the two directions and the GPU) */
+typedef struct {
+    node *self; int peer;
+    size_t n; int w1; size_t npairs, per;
+    uint8_t *u[2]; uint64_t *y[2];
+    size_t recvd, gpu_done, sent;
+    int failed;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} ot_send_ctx;
+static void *ot_send_recv_u(void *arg) {
+    ot_send_ctx *c = arg;
+    for (size_t q0 = 0, k = 0; q0 < c->npairs; q0 += c->per, k++) {
+        size_t nb = c->npairs - q0 < c->per ? c->npairs - q0 : c->per;
+        const uint64_t m = (uint64_t)nb * c->n * (uint64_t)c->w1;
+        pthread_mutex_lock(&c->mu);
+        while (k >= c->gpu_done + 2 && !c->failed) pthread_cond_wait(&c->cv, &c->mu);
+        int bad = c->failed;
+        pthread_mutex_unlock(&c->mu);
+        if (bad) break;
+        bad = recv_blob(c->self, c->peer, c->u[k & 1], lgc_ot_u_bytes(m));
+        if (bad) fprintf(stderr, "OT: could not receive u\n");
+        pthread_mutex_lock(&c->mu); if (bad) c->failed = 1; else c->recvd = k + 1; pthread_cond_broadcast(&c->cv); pthread_mutex_unlock(&c->mu);
+        if (bad) break;
+    }
+    return NULL;
+}
+static void *ot_send_send_y(void *arg) {
+    ot_send_ctx *c = arg;
+    for (size_t q0 = 0, k = 0; q0 < c->npairs; q0 += c->per, k++) {
+        size_t nb = c->npairs - q0 < c->per ? c->npairs - q0 : c->per;
+        const uint64_t m = (uint64_t)nb * c->n * (uint64_t)c->w1;
+        pthread_mutex_lock(&c->mu);
+        while (c->gpu_done <= k && !c->failed) pthread_cond_wait(&c->cv, &c->mu);
+        int bad = c->failed;
+        pthread_mutex_unlock(&c->mu);
+        if (bad) break;
+        bad = send_blob(c->self, c->peer, c->y[k & 1], m * 8);
+        if (bad) fprintf(stderr, "OT: could not send y\n");
+        pthread_mutex_lock(&c->mu); if (bad) c->failed = 1; else c->sent = k + 1; pthread_cond_broadcast(&c->cv); pthread_mutex_unlock(&c->mu);
+        if (bad) break;
+    }
+    return NULL;
+}
+
+/* OT mode, receiver side: the helper thread that starts batches (OT extension on the GPU) and sends
+ * their u; at most two batches ahead of the finishing thread */
+typedef struct {
+    node *self; int to; lgc_ot_receiver *R;
+    const int64_t *Xq, *yq; size_t n, d; int w1;
+    const size_t *rows; size_t npairs, per;
+    size_t started, finished;
+    int failed;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+} ot_recv_ctx;
+static void *ot_recv_starter(void *arg) {
+    ot_recv_ctx *c = arg;
+    const size_t n = c->n;
+    const uint64_t mmax = (uint64_t)c->per * n * (uint64_t)c->w1;
+    uint64_t *vals = lgc_host_alloc(c->per * n * 8);
+    uint8_t *u = lgc_host_alloc(lgc_ot_u_bytes(mmax));
+    int bad = !vals || !u;
+    double tt[3] = {0, 0, 0};
+    for (size_t q0 = 0, k = 0; q0 < c->npairs && !bad; q0 += c->per, k++) {
+        size_t nb = c->npairs - q0 < c->per ? c->npairs - q0 : c->per;
+        const uint64_t m = (uint64_t)nb * n * (uint64_t)c->w1;
+        pthread_mutex_lock(&c->mu);
+        while (k >= c->finished + 2 && !c->failed) pthread_cond_wait(&c->cv, &c->mu);
+        bad = c->failed;
+        pthread_mutex_unlock(&c->mu);
+        if (bad) break;
+        double t0 = wall_clock();
+        for (size_t q = 0; q < nb; q++) column_of(c->Xq, c->yq, n, c->d, c->rows[q0 + q], vals + q * n);
+        double t1 = wall_clock(), t2 = t1;
+        if (lgc_ot_gilboa_recv_start(c->R, vals, nb, n, c->w1, u)) { fprintf(stderr, "%s\n", lgc_last_error()); bad = 1; }
+        else if ((t2 = wall_clock(), send_blob(c->self, c->to, u, lgc_ot_u_bytes(m)))) { fprintf(stderr, "OT: could not send u\n"); bad = 1; }
+        tt[0] += t1 - t0; tt[1] += t2 - t1; tt[2] += wall_clock() - t2;
+        pthread_mutex_lock(&c->mu); if (bad) c->failed = 1; else c->started = k + 1; pthread_cond_broadcast(&c->cv); pthread_mutex_unlock(&c->mu);
+    }
+    if (bad) { pthread_mutex_lock(&c->mu); c->failed = 1; pthread_cond_broadcast(&c->cv); pthread_mutex_unlock(&c->mu); }
+    if (getenv("LINREG_TIMING")) fprintf(stderr, "OT receiver (start thread): columns %.2fs, gpu %.2fs, send u %.2fs\n", tt[0], tt[1], tt[2]);
+    lgc_host_free(vals); lgc_host_free(u);
+    return NULL;
+}
+
 int run_party(node *self, config *c, int precision, int precision_p2, int w1, int w2, int use_ot, int device,
                      uint64_t **res_A, uint64_t **res_b) {
     tune_malloc();
@@ -705,8 +793,8 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
                     if (pj == last) { ri[q] = i; rj[q++] = d; }
                 }
                 if (pi == last) for (size_t j = j0; j < j1; j++) { ri[q] = d; rj[q++] = j; }
-                /* batches of pairs: at most 2^26 OTs (1 GiB of u) in flight */
-                size_t per = ((size_t)1 << 26) / (n * (size_t)w1);
+                /* batches of pairs: at most 2^25 OTs (512 MiB of u) each, two in flight on the receiver side */
+                size_t per = ((size_t)1 << 25) / (n * (size_t)w1);
                 if (per < 1) per = 1;
                 if (per > npairs) per = npairs;
                 uint64_t *vals = lgc_host_alloc(per * n * 8), *shares = malloc(npairs * 8);
@@ -725,22 +813,66 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
                     check(!baseot_ext_receiver(self, peer + 1, s0, s1), "base OT failed");
                     LGC(lgc_ot_receiver_create(&R, device, s0, s1));
                 }
-                for (size_t q0 = 0; q0 < npairs; q0 += per) {
-                    size_t nb = npairs - q0 < per ? npairs - q0 : per;
-                    const uint64_t m = (uint64_t)nb * n * (uint64_t)w1;
-                    size_t ub = lgc_ot_u_bytes(m);
-                    if (i_am_sender) {
+                double ot_t[4] = {0, 0, 0, 0};
+                if (i_am_sender) {
+                    ot_send_ctx sx;
+                    memset(&sx, 0, sizeof sx);
+                    sx.self = self; sx.peer = peer + 1; sx.n = n; sx.w1 = w1; sx.npairs = npairs; sx.per = per;
+                    sx.u[0] = u; sx.y[0] = yv;
+                    sx.u[1] = lgc_host_alloc(lgc_ot_u_bytes(mmax)); sx.y[1] = lgc_host_alloc(mmax * 8);
+                    check(sx.u[1] && sx.y[1], "%s", lgc_last_error());
+                    pthread_mutex_init(&sx.mu, NULL); pthread_cond_init(&sx.cv, NULL);
+                    pthread_t tin, tout;
+                    check(!pthread_create(&tin, NULL, ot_send_recv_u, &sx), "pthread_create failed");
+                    check(!pthread_create(&tout, NULL, ot_send_send_y, &sx), "pthread_create failed");
+                    int bad = 0;
+                    for (size_t q0 = 0, k = 0; q0 < npairs && !bad; q0 += per, k++) {
+                        size_t nb = npairs - q0 < per ? npairs - q0 : per;
+                        double t0 = wall_clock();
                         for (q = 0; q < nb; q++) column_of(Xq, yq, n, d, ri[q0 + q], vals + q * n);
-                        check(!recv_blob(self, peer + 1, u, ub), "OT: could not receive u");
-                        LGC(lgc_ot_gilboa_send(S, vals, nb, n, w1, u, yv, shares + q0));
-                        check(!send_blob(self, peer + 1, yv, m * 8), "OT: could not send y");
-                    } else {
-                        for (q = 0; q < nb; q++) column_of(Xq, yq, n, d, rj[q0 + q], vals + q * n);
-                        LGC(lgc_ot_gilboa_recv_start(R, vals, nb, n, w1, u));
-                        check(!send_blob(self, peer + 1, u, ub), "OT: could not send u");
-                        check(!recv_blob(self, peer + 1, yv, m * 8), "OT: could not receive y");
-                        LGC(lgc_ot_gilboa_recv_finish(R, yv, shares + q0));
+                        double t1 = wall_clock();
+                        pthread_mutex_lock(&sx.mu);                 /* u of batch k is here, and the y buffer it will fill is free */
+                        while ((sx.recvd <= k || k >= sx.sent + 2) && !sx.failed) pthread_cond_wait(&sx.cv, &sx.mu);
+                        bad = sx.failed;
+                        pthread_mutex_unlock(&sx.mu);
+                        if (bad) break;
+                        double t2 = wall_clock();
+                        if (lgc_ot_gilboa_send(S, vals, nb, n, w1, sx.u[k & 1], sx.y[k & 1], shares + q0)) { fprintf(stderr, "%s\n", lgc_last_error()); bad = 1; }
+                        pthread_mutex_lock(&sx.mu); if (bad) sx.failed = 1; else sx.gpu_done = k + 1; pthread_cond_broadcast(&sx.cv); pthread_mutex_unlock(&sx.mu);
+                        ot_t[0] += t1 - t0; ot_t[1] += t2 - t1; ot_t[2] += wall_clock() - t2;
                     }
+                    pthread_mutex_lock(&sx.mu); if (bad) sx.failed = 1; pthread_cond_broadcast(&sx.cv); pthread_mutex_unlock(&sx.mu);
+                    pthread_join(tin, NULL); pthread_join(tout, NULL);
+                    bad |= sx.failed;
+                    pthread_mutex_destroy(&sx.mu); pthread_cond_destroy(&sx.cv);
+                    lgc_host_free(sx.u[1]); lgc_host_free(sx.y[1]);
+                    if (getenv("LINREG_TIMING")) fprintf(stderr, "OT sender: columns %.2fs, waiting for u / a free y buffer %.2fs, gpu %.2fs\n", ot_t[0], ot_t[1], ot_t[2]);
+                    check(!bad, "OT-mode aggregation failed");
+                } else {
+                    /* the receiver keeps two batches in flight: a helper thread extends batch k + 1 and sends
+                     * its u while this thread waits for the sender's answer to batch k and finishes it */
+                    ot_recv_ctx rx = {self, peer + 1, R, Xq, yq, n, d, w1, rj, npairs, per, 0, 0, 0};
+                    pthread_mutex_init(&rx.mu, NULL); pthread_cond_init(&rx.cv, NULL);
+                    pthread_t th;
+                    check(!pthread_create(&th, NULL, ot_recv_starter, &rx), "pthread_create failed");
+                    int bad = 0;
+                    for (size_t q0 = 0, k = 0; q0 < npairs && !bad; q0 += per, k++) {
+                        size_t nb = npairs - q0 < per ? npairs - q0 : per;
+                        const uint64_t m = (uint64_t)nb * n * (uint64_t)w1;
+                        pthread_mutex_lock(&rx.mu);
+                        while (rx.started <= k && !rx.failed) pthread_cond_wait(&rx.cv, &rx.mu);
+                        bad = rx.failed;
+                        pthread_mutex_unlock(&rx.mu);
+                        if (bad) break;
+                        if (recv_blob(self, peer + 1, yv, m * 8)) { fprintf(stderr, "OT: could not receive y\n"); bad = 1; }
+                        else if (lgc_ot_gilboa_recv_finish(R, yv, shares + q0)) { fprintf(stderr, "%s\n", lgc_last_error()); bad = 1; }
+                        pthread_mutex_lock(&rx.mu); rx.finished = k + 1; if (bad) rx.failed = 1; pthread_cond_broadcast(&rx.cv); pthread_mutex_unlock(&rx.mu);
+                    }
+                    pthread_mutex_lock(&rx.mu); if (bad) rx.failed = 1; pthread_cond_broadcast(&rx.cv); pthread_mutex_unlock(&rx.mu);
+                    pthread_join(th, NULL);
+                    bad |= rx.failed;
+                    pthread_mutex_destroy(&rx.mu); pthread_cond_destroy(&rx.cv);
+                    check(!bad, "OT-mode aggregation failed");
                 }
                 if (S) lgc_ot_sender_destroy(S);
                 if (R) lgc_ot_receiver_destroy(R);
