@@ -437,13 +437,18 @@ class OtReceiver:
 
     def gilboa_start(self, a, width):
         a = np.ascontiguousarray(a, dtype=np.uint64); npairs, n = a.shape
-        self._np = npairs
         u = np.zeros(lib().lgc_ot_u_bytes(npairs * n * width), dtype=np.uint8)
         _chk(lib().lgc_ot_gilboa_recv_start(self._h, _vp(a), npairs, n, width, _vp(u)))
+        if not hasattr(self, "_nps"):
+            self._nps = []
+        self._nps.append(npairs)               # several receives may be in flight; finishes complete the oldest
         return u
 
     def gilboa_finish(self, y):
-        sh = np.zeros(self._np, dtype=np.uint64)
+        if not getattr(self, "_nps", None):
+            sh = np.zeros(1, dtype=np.uint64)
+            _chk(lib().lgc_ot_gilboa_recv_finish(self._h, _vp(np.ascontiguousarray(y, dtype=np.uint64)), _vp(sh)))
+        sh = np.zeros(self._nps.pop(0), dtype=np.uint64)
         _chk(lib().lgc_ot_gilboa_recv_finish(self._h, _vp(np.ascontiguousarray(y, dtype=np.uint64)), _vp(sh)))
         return sh
 

@@ -67,6 +67,31 @@ def test_gpu_gilboa_matches_mirror(lgc, gccpu, w, npairs, n):
 
 
 @pytest.mark.gpu
+def test_gpu_gilboa_receives_in_flight(lgc):
+    """several receives started before the first is finished (the pipelined OT mode of the host):
+    finishes complete the oldest batch; the sender answers in order"""
+    rng = np.random.default_rng(9)
+    seeds0, seeds1, delta, seeds_s = _setup(rng)
+    S = lgc.OtSender(delta.tobytes(), seeds_s); R = lgc.OtReceiver(seeds0, seeds1)
+    w = 64
+    shapes = [(2, 40), (1, 300), (3, 7)]
+    A = [rng.integers(0, 2 ** 63, size=sh, dtype=np.uint64) for sh in shapes]
+    B = [rng.integers(0, 2 ** 63, size=sh, dtype=np.uint64) for sh in shapes]
+    us = [R.gilboa_start(a, w) for a in A]                     # three in flight
+    for a, b, u in zip(A, B, us):
+        y, ss = S.gilboa(b, w, u)
+        sr = R.gilboa_finish(y)
+        assert [(int(x) + int(z)) & (2 ** 64 - 1) for x, z in zip(ss, sr)] == _ip(a, b, w)
+    with pytest.raises(lgc.LgcError):                           # nothing in flight any more
+        R.gilboa_finish(np.zeros(64, dtype=np.uint64))
+    for a in A + [A[0]]:
+        R.gilboa_start(a, w)                                    # four in flight is the limit
+    with pytest.raises(lgc.LgcError):
+        R.gilboa_start(A[0], w)
+    S.close(); R.close()
+
+
+@pytest.mark.gpu
 def test_gpu_label_ot_matches_mirror(lgc, gccpu):
     rng = np.random.default_rng(5)
     seeds0, seeds1, delta, seeds_s = _setup(rng)
