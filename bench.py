@@ -68,7 +68,18 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+                dist.barrier()                       # creates the RCCL communicator now, not inside the timed region
+            except Exception as e:                   # the data path has no collective: a CPU barrier is enough
+                sys.stderr.write("bench.py: RCCL init failed (%s); using gloo for the barrier\n" % e)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                backend = "gloo"
+                import datetime
+                dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
         else:
             dist.init_process_group(backend=backend)
 
@@ -197,6 +208,7 @@ def main():
             "metric": "AND-gates/sec (garble+eval) d=500 CGD-15; phase1+2 wall-clock",
             "value": value, "unit": "AND-gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "barrier_backend": (backend if world > 1 else None),
             "vs_baseline": value / REF_RATE if (d == 500 and iters == 15 and w == 64) else None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "phase-2 CGD solve, d=%d, %d iterations, %d-bit fixed point, precision %d, "
