@@ -2,7 +2,8 @@
 # Round profile set (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats, HBM
 # counters (FETCH_SIZE / WRITE_SIZE in separate passes, no tracing alongside), SQ counters of the
 # MAC kernels, per-op launch profiles.  Outputs under gpurun_out/; scripts/summarize_profiles.py
-# copies the summaries into profiles/.
+# copies the summaries into profiles/.  gpurun MERGES into the local gpurun_out/: delete the local
+# gpurun_out/prof first, or the summariser may pick up counter files of an older run.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
