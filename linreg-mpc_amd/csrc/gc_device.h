@@ -24,6 +24,9 @@ __constant__ uint32_t c_rk24[44];
 __device__ unsigned long long *g_stamp = 0;   // diagnostic build only: [hash, barrier, glue, last, count, tail]
 #endif   // rotl24 of the round keys (two-table AES rounds)
 
+#ifndef GC_SOLO_INLINE
+#define GC_SOLO_INLINE 0   /* wide generic kernel: 1 = gate bodies inlined at every AND site (experiment) */
+#endif
 #ifndef GC_AES_TAB4
 #define GC_AES_TAB4 1   /* MAC kernels and the AES micro-benchmark: four rotated tables, 32 replicas each */
 #endif
@@ -251,7 +254,7 @@ struct GpuBackend {
         const uint64_t gid = step * 64 + (uint64_t)lane;
         Lbl *slot = tab + (step - launch_step0) * 128 + lane;
         step++;
-        if (MODE == MODE_SOLO) return and_outlined(lt, R, a, b, gid, slot, on);
+        if (MODE == MODE_SOLO) return GC_SOLO_INLINE ? and_impl(lt, R, a, b, gid, slot, on) : and_outlined(lt, R, a, b, gid, slot, on);
         if (MODE == MODE_MAC) return and_impl(lt, R, a, b, gid, slot, on);
         xsel ^= 1;
         return and_quad(lt, R, a, b, gid, slot, on, wave, xch + xsel * 512, lane);

@@ -410,7 +410,10 @@ static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
 static constexpr uint32_t kWideLaunch = GC_WIDE_LAUNCH;
 // ... and only for short records (sums, merges): long dependent records (dividers, square roots) run
 // faster in the 4-wave mode even when there are thousands of them (measured on the merged lambda sweep)
-static constexpr uint64_t kWideMaxSteps = 256;
+#ifndef GC_WIDE_MAX_STEPS
+#define GC_WIDE_MAX_STEPS 256
+#endif
+static constexpr uint64_t kWideMaxSteps = GC_WIDE_MAX_STEPS;
 // wide launches: 12 records (waves) per workgroup share one 128 KiB four-table image
 #ifndef GC_TPB_WIDE
 #define GC_TPB_WIDE 768
