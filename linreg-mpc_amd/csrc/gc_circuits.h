@@ -118,6 +118,36 @@ struct Circ {
         S = be.zero();
         L = be.zero();
         C = (p >= 1) ? be.konst(1ull << (w - 1)) : be.zero();
+        if (B::kPairSteps) {
+            // latency-bound backends: the partial product of row r + 1 does not depend on row r, so it
+            // issues together with the carry-save AND of row r (one dual step): w levels instead of 2w - 1
+            W pp = be.AND(a, be.bcast(b, 0), lanes(w < M ? w : M));
+            for (int r = 0; r < w; r++) {
+                const int na = (M - r) < w ? (M - r) : w;
+                const uint64_t act = lanes(na);
+                uint64_t inv = (r == w - 1) ? lanes(w - 1) : (1ull << (w - 1));
+                pp = be.NOTm(pp, inv & act);
+                W ppn = be.zero();
+                const int nan = (M - r - 1) < w ? (M - r - 1) : w;
+                if (r == 0) {
+                    S = pp;
+                    if (w > 1) ppn = be.AND(a, be.bcast(b, 1), lanes(nan));
+                } else {
+                    W t;
+                    if (r + 1 < w) be.AND2(be.XOR(S, pp), be.XOR(C, pp), act, a, be.bcast(b, r + 1), lanes(nan), t, ppn);
+                    else t = be.AND(be.XOR(S, pp), be.XOR(C, pp), act);
+                    W Sn = be.XOR(be.XOR(S, C), pp);
+                    C = be.XOR(t, pp);
+                    S = Sn;
+                }
+                L = be.sel(1ull << r, be.bcast(S, 0), L);
+                S = be.shr(S, 1);
+                pp = ppn;
+            }
+            S = be.sel(lanes(p), S, be.zero());
+            C = be.sel(lanes(p), C, be.zero());
+            return;
+        }
         for (int r = 0; r < w; r++) {
             const int na = (M - r) < w ? (M - r) : w;
             const uint64_t act = lanes(na);
@@ -239,30 +269,66 @@ struct Circ {
         return be.XOR(be.sel(act, be.shr(lo, p), be.zero()), be.sel(act, be.shl(hi, w - p), be.zero()));
     }
 
-    // ---- restoring divider: wrap_w(tdiv(a << p, b)), truncation toward zero.
-    // b == 0 gives an all-ones magnitude (-1 for a >= 0, +1 for a < 0).
-    static GC_HD W div(B &be, W a, W b, int w, int p) {
+    // ---- non-restoring divider: wrap_w(tdiv(a << p, b)), truncation toward zero.
+    // The partial remainder R in [-|b|, |b|) is a (w+1)-bit two's complement number: its low w bits
+    // live in the lanes, its sign s is a separate broadcast wire (no spare lane at w = 64).  Step k:
+    //     X = 2R + n_k;   R' = s ? X + |b| : X - |b|      (one Kogge-Stone add, the +-|b| select is an XOR)
+    //     s' = R[w-1] ^ ~s ^ carry-out                    (bit w of the sum: free)
+    //     q_k = ~s'
+    // (the digits +-1 of the non-restoring recurrence, converted: Q = 2E + ~s_0 - 2^M with E = sum e_k 2^k,
+    // e_k = ~s_{k+1}, e_{M-1} = 1, is bit for bit q_k = ~s_k).  7 dependent levels per quotient bit; the
+    // restoring form needs an eighth for the remainder mux.  b == 0 is unspecified upstream
+    // (fixed.oc:174-180); oracle and circuit define an all-ones magnitude (-1 for a >= 0, +1 for a < 0),
+    // forced here by a zero detector on |b| (zcheck; not needed for a public non-zero divisor).
+    static GC_HD W div_mag(B &be, W ua, W ub, int w, int p, bool zcheck) {
         const int M = w + p;
         const uint64_t act = lanes(w);
+        W R = be.zero(), Q = be.zero(), s = be.zero();
+        for (int k = M - 1; k >= 0; k--) {
+            W rtop = be.bcast(R, w - 1);
+            W X = be.sel(act, be.shl(R, 1), be.zero());
+            if (k >= p) X = be.XOR(X, be.sel(1ull, be.bcast(ua, k - p), be.zero()));
+            W ns = be.NOTm(s, ~0ull);
+            W Y = be.XOR(ub, be.sel(act, ns, be.zero()));
+            W co;
+            R = add(be, X, Y, w, be.sel(1ull, ns, be.zero()), &co);
+            s = be.XOR(be.XOR(rtop, ns), co);
+            if (k < w) Q = be.sel(1ull << k, be.NOTm(s, ~0ull), Q);
+        }
+        if (zcheck) {
+            W nz = ub;                                   // OR of all lanes of |b| -> lane 0
+            for (int dist = 32; dist >= 1; dist >>= 1) {
+                if (dist >= w) continue;
+                W sh = be.shr(nz, dist);
+                W t = be.AND(nz, sh, lanes(dist));
+                nz = be.XOR(be.XOR(nz, sh), t);
+            }
+            // Q | ~nz
+            Q = be.NOTm(be.AND(be.NOTm(Q, act), be.bcast(nz, 0), act), act);
+        }
+        return Q;
+    }
+    static GC_HD W div(B &be, W a, W b, int w, int p) {
         W sa = be.bcast(a, w - 1), sb = be.bcast(b, w - 1);
         W ua = condneg(be, a, sa, w), ub = condneg(be, b, sb, w);
-        W nub = be.NOTm(ub, act);
-        W one = be.konst(1);
-        W R = be.zero(), Q = be.zero();
-        for (int k = M - 1; k >= 0; k--) {
-            R = be.sel(act, be.shl(R, 1), be.zero());
-            if (k >= p) R = be.XOR(R, be.sel(1ull, be.bcast(ua, k - p), be.zero()));
-            W co;
-            W T = add(be, R, nub, w, one, &co);      // R - |b|, co = (R >= |b|)
-            R = mux(be, co, T, R, w);
-            if (k < w) Q = be.sel(1ull << k, co, Q);
-        }
+        W Q = div_mag(be, ua, ub, w, p, true);
         return condneg(be, Q, be.XOR(sa, sb), w);
     }
+    // tdiv(a, c) for a public constant c > 0 (the normalizer of linear.oc:52-65)
+    static GC_HD W divc(B &be, W a, uint64_t c, int w) {
+        W sa = be.bcast(a, w - 1);
+        W ua = condneg(be, a, sa, w);
+        W Q = div_mag(be, ua, be.sel(lanes(w), be.konst(c), be.zero()), w, 0, false);
+        return condneg(be, Q, sa, w);
+    }
 
-    // ---- square root.  w = 64: floor(sqrt(a_u * 2^p)), digit-by-digit with a
-    // shifting remainder (needs w + p <= 124).  w = 32: the explicit loop of
+    // ---- square root.  w = 64: floor(sqrt(a_u * 2^p)); w = 32: the explicit loop of
     // src/fixed.oc:228-240 on the low (32+p) bits, mirrored literally.
+    // w = 64, w + p <= 124: non-restoring digit recurrence on an (n+2)-bit signed remainder (n root bits):
+    //     R >= 0: R = 4R + v_i - (4Q + 1)     R < 0: R = 4R + v_i + (4Q + 3)     q_i = (R >= 0), Q = 2Q + q_i
+    // one Kogge-Stone add per root bit (7 levels; the restoring form adds a mux level).
+    // w + p > 124 (precision 61..63, allowed by src/cmd/linreg.c:85-88): the remainder no longer fits the
+    // 64 lanes; a restoring recurrence on a two-word remainder (low 64 lanes + 1 or 2 high lanes).
     static GC_HD W vsqrt(B &be, W a, int w, int p) {
         const int M = w + p;
         if (w == 32) {
@@ -279,27 +345,54 @@ struct Circ {
             return be.sel(lanes(32), r, be.zero());
         }
         const int n = (M + 1) / 2;                       // root bits
-        const int rb = n + 2;                            // remainder / trial width
-        W R = be.zero(), Q = be.zero();
-        for (int i = n - 1; i >= 0; i--) {
-            // R = (R << 2) | V[2i+1 : 2i], V = a << p
-            R = be.sel(lanes(rb), be.shl(R, 2), be.zero());
-            int hi = 2 * i + 1 - p, lo = 2 * i - p;
-            if (hi >= 0 && hi < w) R = be.XOR(R, be.sel(2ull, be.bcast(a, hi), be.zero()));
-            if (lo >= 0 && lo < w) R = be.XOR(R, be.sel(1ull, be.bcast(a, lo), be.zero()));
-            W Tt = be.NOTm(be.sel(lanes(rb), be.shl(Q, 2), be.zero()), 1ull);  // 4Q + 1
-            W co;
-            W Rs = sub(be, R, Tt, rb, &co);
-            R = mux(be, co, Rs, R, rb);
-            Q = be.XOR(be.sel(lanes(rb), be.shl(Q, 1), be.zero()), be.sel(1ull, co, be.zero()));
+        const int rb = n + 2;                            // remainder width
+        W Q = be.zero();
+        if (rb <= 64) {
+            const uint64_t act = lanes(rb);
+            W R = be.zero();
+            for (int i = n - 1; i >= 0; i--) {
+                W s = be.bcast(R, rb - 1);               // sign of the remainder before the step
+                W ns = be.NOTm(s, ~0ull);
+                W X = be.sel(act, be.shl(R, 2), be.zero());
+                int hi = 2 * i + 1 - p, lo = 2 * i - p;
+                if (hi >= 0 && hi < w) X = be.XOR(X, be.sel(2ull, be.bcast(a, hi), be.zero()));
+                if (lo >= 0 && lo < w) X = be.XOR(X, be.sel(1ull, be.bcast(a, lo), be.zero()));
+                // s = 0: - (4Q + 1) = ~(4Q + 1) + 1;   s = 1: + (4Q + 3)
+                W Y = be.XOR(be.NOTm(be.sel(act, be.shl(Q, 2), be.zero()), 1ull), be.sel(2ull, s, be.zero()));
+                Y = be.XOR(Y, be.sel(act, ns, be.zero()));
+                R = add(be, X, Y, rb, be.sel(1ull, ns, be.zero()), (W *)0);
+                W q = be.NOTm(be.bcast(R, rb - 1), ~0ull);
+                Q = be.XOR(be.sel(act, be.shl(Q, 1), be.zero()), be.sel(1ull, q, be.zero()));
+            }
+            return be.sel(lanes(w), Q, be.zero());
         }
-        return be.sel(lanes(w), Q, be.zero());
+        const int nh = rb - 64;                          // 1 or 2 high lanes
+        W Rl = be.zero(), Rh = be.zero();
+        for (int i = n - 1; i >= 0; i--) {
+            Rh = be.sel(lanes(nh), be.XOR(be.shl(Rh, 2), be.shr(Rl, 62)), be.zero());
+            Rl = be.shl(Rl, 2);
+            int hi = 2 * i + 1 - p, lo = 2 * i - p;
+            if (hi >= 0 && hi < w) Rl = be.XOR(Rl, be.sel(2ull, be.bcast(a, hi), be.zero()));
+            if (lo >= 0 && lo < w) Rl = be.XOR(Rl, be.sel(1ull, be.bcast(a, lo), be.zero()));
+            W Tl = be.NOTm(be.shl(Q, 2), 1ull);          // 4Q + 1, low 64 bits
+            W Th = be.sel(lanes(nh), be.shr(Q, 62), be.zero());
+            W c1, c2;
+            W Dl = sub(be, Rl, Tl, 64, &c1);
+            W Dh = add(be, Rh, be.NOTm(Th, lanes(nh)), nh, be.sel(1ull, c1, be.zero()), &c2);
+            W ml, mh;
+            be.AND2(c2, be.XOR(Dl, Rl), ~0ull, c2, be.XOR(Dh, Rh), lanes(nh), ml, mh);
+            Rl = be.XOR(Rl, ml);
+            Rh = be.XOR(Rh, mh);
+            Q = be.XOR(be.shl(Q, 1), be.sel(1ull, c2, be.zero()));
+        }
+        return Q;
     }
 };
 
 // ---- host-side plaintext backend: circuit logic checks + step/gate counting
 struct PlainBackend {
     typedef uint64_t W;
+    static const bool kPairSteps = false;   // order of independent gate steps in mul_core (see there)
     uint64_t steps, gates;
     PlainBackend() : steps(0), gates(0) {}
     GC_HD W zero() const { return 0; }

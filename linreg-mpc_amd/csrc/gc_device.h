@@ -20,9 +20,7 @@ namespace gc {
 __constant__ uint32_t c_rk[44];
 __constant__ uint32_t c_te0[256];
 __constant__ uint32_t c_rk24[44];
-#ifdef GC_STAMP
-__device__ unsigned long long *g_stamp = 0;   // diagnostic build only: [hash, barrier, glue, last, count, tail]
-#endif   // rotl24 of the round keys (two-table AES rounds)
+// c_rk24: rotl24 of the round keys (two-table AES rounds)
 
 #ifndef GC_SOLO_INLINE
 #define GC_SOLO_INLINE 0   /* wide generic kernel: 1 = gate bodies inlined at every AND site (experiment) */
@@ -197,9 +195,21 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");   // no LDS access of the next phase may be scheduled above the barrier
 }
 
-template <bool GARBLER, int MODE, class TAB = LdsTab>
+// CRIT (garbler, MODE_QUAD only): "critical-path" garbling for launches of so few records that the
+// chain of dependent gate steps of ONE record sets the run time.  The garbler's output label needs only
+// two of its four hashes -- with pa, pb the colours of the zero-labels a0, b0 (half-gates, ZRE15):
+//     c0 = H(a0 ^ pa R, 2g) ^ H(b0 ^ pb R, 2g+1) ^ (pa & pb) R
+// (WG = pa ? h1 ^ pb R : h0 and WE = pb ? h3 : h2 in the notation of garble_and) -- the other two only
+// enter the ciphertexts.  The record kernel therefore computes c0 alone (two hash-waves per gate step,
+// what the evaluator needs too) and leaves (a0, b0) in the step's two table rows; gc_tabfill_kernel
+// then turns every row pair into (TG, TE) in place, all steps of all records in parallel on the whole
+// chip.  Inactive lanes leave zeros; an active gate with a0 = b0 = 0 (two public constants) never
+// reads its ciphertexts (both colours are 0), so "both rows zero" is the in-band "no table" mark.
+template <bool GARBLER, int MODE, class TAB = LdsTab, bool CRIT = false>
 struct GpuBackend {
     typedef Lbl W;
+    // latency-bound kernels issue independent gate steps of the multiplier as dual steps (gc_circuits.h)
+    static const bool kPairSteps = (MODE == MODE_QUAD);
     int wave;            // MODE_QUAD: wave index inside the workgroup (wave-uniform)
     Lbl *xch;            // MODE_QUAD: LDS exchange area, 2 buffers x 512 labels (16 KiB)
     int xsel;            // MODE_QUAD: buffer used by the next step (adjacent steps alternate)
@@ -213,10 +223,23 @@ struct GpuBackend {
     TAB lt;
 
     __device__ __forceinline__ W zero() const { return lzero(); }
-    __device__ __forceinline__ uint32_t bit(uint64_t m) const { return (uint32_t)(m >> lane) & 1u; }
-    __device__ __forceinline__ W konst(uint64_t bits) const { return GARBLER ? lmask(R, bit(bits)) : lzero(); }
+    // public lane masks are wave-uniform 64-bit scalars: used directly as the v_cndmask condition
+#ifndef GC_INVBALLOT
+#define GC_INVBALLOT 1
+#endif
+#if GC_INVBALLOT
+    __device__ __forceinline__ bool bit(uint64_t m) const { return __builtin_amdgcn_inverse_ballot_w64(m); }
+#else
+    __device__ __forceinline__ bool bit(uint64_t m) const { return (m >> lane) & 1u; }
+#endif
+    __device__ __forceinline__ W rmask(uint64_t m) const {
+        bool t = bit(m);
+        W r = {t ? R.x : 0u, t ? R.y : 0u, t ? R.z : 0u, t ? R.w : 0u};
+        return r;
+    }
+    __device__ __forceinline__ W konst(uint64_t bits) const { return GARBLER ? rmask(bits) : lzero(); }
     __device__ __forceinline__ W XOR(W a, W b) const { return lxor(a, b); }
-    __device__ __forceinline__ W NOTm(W a, uint64_t m) const { return GARBLER ? lxor(a, lmask(R, bit(m))) : a; }
+    __device__ __forceinline__ W NOTm(W a, uint64_t m) const { return GARBLER ? lxor(a, rmask(m)) : a; }
     __device__ __forceinline__ W sel(uint64_t m, W a, W b) const {
         bool t = bit(m);
         W r = {t ? a.x : b.x, t ? a.y : b.y, t ? a.z : b.z, t ? a.w : b.w};
@@ -290,25 +313,35 @@ struct GpuBackend {
     static __device__ __noinline__ W and_outlined(TAB lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on) {
         return and_impl(lt, R, a, b, gid, slot, on);
     }
-    // cooperative gate step (one out-of-line copy: code size, compile time).  Every wave of
-    // the workgroup calls this with identical operands; exactly one barrier per step, the
-    // exchange area is double-buffered by step parity.
-#ifndef GC_QUAD_INLINE
-#define GC_QUAD_INLINE 1   /* inlined: no call ABI spills around every gate step (DIV 3.5 -> 2.4 ms) */
-#endif
-#if GC_QUAD_INLINE
-#define GC_QUAD_ATTR __forceinline__
-#else
-#define GC_QUAD_ATTR __noinline__
-#endif
-    static __device__ GC_QUAD_ATTR W and_quad(TAB lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on,
-                                              int wave, Lbl *xbuf, int lane) {
-#ifdef GC_STAMP
-        unsigned long long st0 = __builtin_amdgcn_s_memtime();
-#endif
+    // cooperative gate step.  Every wave of the workgroup calls this with identical operands; exactly
+    // one barrier per step, the exchange area is double-buffered by step parity.  Inlined: the call
+    // ABI spilled around every gate step (DIV 3.5 -> 2.4 ms).
+    // Evaluator: the two ciphertext rows are fetched by ALL lanes before the hash (rows are 64 labels
+    // wide whatever the activity mask), so no EXEC-masked load forces a vmcnt(0) ahead of the hash.
+    static __device__ __forceinline__ W and_quad(TAB lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on,
+                                                 int wave, Lbl *xbuf, int lane) {
+        if (GARBLER && CRIT) {
+            const uint32_t pa = a.x & 1u, pb = b.x & 1u;
+            if (wave < 2) {
+                Lbl h = lzero();
+                if (on) {
+                    Lbl x = (wave == 0) ? lxor(a, lmask(R, pa)) : lxor(b, lmask(R, pb));
+                    uint64_t tw = 2 * gid + (uint64_t)wave;
+                    hash_n<1, TAB>(lt, c_rk, &x, &tw, &h, c_rk24);
+                }
+                xbuf[wave * 64 + lane] = h;
+            } else {
+                Lbl v = (wave == 2) ? a : b;     // the zero-labels, for gc_tabfill_kernel
+                st_lbl(slot + (wave - 2) * 64, on ? v : lzero());
+            }
+            lds_barrier();
+            W c = lzero();
+            if (on) c = lxor(lxor(xbuf[lane], xbuf[64 + lane]), lmask(R, pa & pb));
+            return c;
+        }
         const int nh = GARBLER ? 4 : 2;
         Lbl TGe = lzero(), TEe = lzero();
-        if (!GARBLER && on) { TGe = ld_lbl(slot); TEe = ld_lbl(slot + 64); }   // in flight during the hash
+        if (!GARBLER) { TGe = ld_lbl(slot); TEe = ld_lbl(slot + 64); }   // in flight during the hash
         if (wave < nh) {
             Lbl h = lzero();
             if (on) {
@@ -319,20 +352,10 @@ struct GpuBackend {
             }
             xbuf[wave * 64 + lane] = h;
         }
-#ifdef GC_STAMP
-        unsigned long long st1 = __builtin_amdgcn_s_memtime();
-#endif
         lds_barrier();
-#ifdef GC_STAMP
-        unsigned long long st2 = __builtin_amdgcn_s_memtime();
-        if (wave == 0 && lane == 0 && g_stamp) {     // store-only trace: [entry, after hash, after barrier, exit]
-            unsigned long long *t = g_stamp + (((gid >> 6) & 0xffffull) << 2);
-            t[0] = st0; t[1] = st1; t[2] = st2;
-        }
-#endif
         W c = lzero();
-        if (on) {
-            if (GARBLER) {
+        if (GARBLER) {
+            if (on) {
                 Lbl h0 = xbuf[lane], h1 = xbuf[64 + lane], h2 = xbuf[128 + lane], h3 = xbuf[192 + lane];
                 uint32_t pa = a.x & 1u, pb = b.x & 1u;
                 Lbl TG = lxor(lxor(h0, h1), lmask(R, pb));
@@ -344,31 +367,45 @@ struct GpuBackend {
                     st_lbl(slot + 64, TE);
                 }
                 c = lxor(WG, WE);
-            } else {
-                Lbl h0 = xbuf[lane], h1 = xbuf[64 + lane];
-                uint32_t sa = a.x & 1u, sb = b.x & 1u;
-                Lbl WG = lxor(h0, lmask(TGe, sa));
-                Lbl WE = lxor(h1, lmask(lxor(TEe, a), sb));
-                c = lxor(WG, WE);
             }
+        } else {
+            Lbl h0 = xbuf[lane], h1 = xbuf[64 + lane];
+            uint32_t sa = a.x & 1u, sb = b.x & 1u;
+            Lbl WG = lxor(h0, lmask(TGe, sa));
+            Lbl WE = lxor(h1, lmask(lxor(TEe, a), sb));
+            c = lmask(lxor(WG, WE), on ? 1u : 0u);
         }
-#ifdef GC_STAMP
-        if (wave == 0 && lane == 0 && g_stamp) g_stamp[((((gid >> 6) & 0xffffull) << 2)) + 3] = __builtin_amdgcn_s_memtime();
-#endif
         return c;
     }
-    // two gate steps (gid, gid + 64) at once: 8 (garbler) / 4 (evaluator) hashes over 4 waves
-    static __device__ GC_QUAD_ATTR void and2_quad(TAB lt, Lbl R, W a1, W b1, W a2, W b2, uint64_t gid, Lbl *slot,
-                                                  bool on1, bool on2, int wave, Lbl *xbuf, int lane, W &c1, W &c2) {
-#ifdef GC_STAMP
-        unsigned long long st0 = __builtin_amdgcn_s_memtime();
-#endif
+    // two gate steps (gid, gid + 64) at once: 8 (garbler) / 4 (evaluator, critical-path garbler) hashes over 4 waves
+    static __device__ __forceinline__ void and2_quad(TAB lt, Lbl R, W a1, W b1, W a2, W b2, uint64_t gid, Lbl *slot,
+                                                     bool on1, bool on2, int wave, Lbl *xbuf, int lane, W &c1, W &c2) {
         const uint64_t gid2 = gid + 64;
         Lbl *slot2 = slot + 128;
+        if (GARBLER && CRIT) {
+            // wave q: colour-0 label of input (q & 1) of gate (q >> 1); it also stashes that zero-label (row q)
+            const bool g2 = wave >= 2;
+            Lbl src = (wave & 1) ? (g2 ? b2 : b1) : (g2 ? a2 : a1);
+            const bool on = g2 ? on2 : on1;
+            Lbl h = lzero();
+            if (on) {
+                Lbl x = lxor(src, lmask(R, src.x & 1u));
+                uint64_t tw = 2 * (g2 ? gid2 : gid) + (uint64_t)(wave & 1);
+                hash_n<1, TAB>(lt, c_rk, &x, &tw, &h, c_rk24);
+            }
+            xbuf[wave * 64 + lane] = h;
+            st_lbl(slot + wave * 64, on ? src : lzero());
+            lds_barrier();
+            c1 = lzero();
+            c2 = lzero();
+            if (on1) c1 = lxor(lxor(xbuf[lane], xbuf[64 + lane]), lmask(R, a1.x & b1.x & 1u));
+            if (on2) c2 = lxor(lxor(xbuf[128 + lane], xbuf[192 + lane]), lmask(R, a2.x & b2.x & 1u));
+            return;
+        }
         Lbl TG1 = lzero(), TE1 = lzero(), TG2 = lzero(), TE2 = lzero();
         if (!GARBLER) {
-            if (on1) { TG1 = ld_lbl(slot); TE1 = ld_lbl(slot + 64); }
-            if (on2) { TG2 = ld_lbl(slot2); TE2 = ld_lbl(slot2 + 64); }
+            TG1 = ld_lbl(slot); TE1 = ld_lbl(slot + 64);
+            TG2 = ld_lbl(slot2); TE2 = ld_lbl(slot2 + 64);
         }
         if (GARBLER) {
             // wave q: hash q of gate 1 and hash q of gate 2 (q = 0: a0, 1: a0^R, 2: b0, 3: b0^R)
@@ -387,17 +424,7 @@ struct GpuBackend {
             if ((wave < 2) ? on1 : on2) hash_n<1, TAB>(lt, c_rk, &x, &tw, &h, c_rk24);
             xbuf[(wave >> 1) * 256 + (wave & 1) * 64 + lane] = h;
         }
-#ifdef GC_STAMP
-        unsigned long long st1 = __builtin_amdgcn_s_memtime();
-#endif
         lds_barrier();
-#ifdef GC_STAMP
-        unsigned long long st2 = __builtin_amdgcn_s_memtime();
-        if (wave == 0 && lane == 0 && g_stamp) {
-            unsigned long long *t = g_stamp + (((gid >> 6) & 0xffffull) << 2);
-            t[0] = st0; t[1] = st1; t[2] = st2;
-        }
-#endif
         c1 = lzero();
         c2 = lzero();
         if (GARBLER) {
@@ -422,20 +449,17 @@ struct GpuBackend {
                 c2 = lxor(WG, WE);
             }
         } else {
-            if (on1) {
+            {
                 Lbl h0 = xbuf[lane], h1 = xbuf[64 + lane];
                 uint32_t sa = a1.x & 1u, sb = b1.x & 1u;
-                c1 = lxor(lxor(h0, lmask(TG1, sa)), lxor(h1, lmask(lxor(TE1, a1), sb)));
+                c1 = lmask(lxor(lxor(h0, lmask(TG1, sa)), lxor(h1, lmask(lxor(TE1, a1), sb))), on1 ? 1u : 0u);
             }
-            if (on2) {
+            {
                 Lbl h0 = xbuf[256 + lane], h1 = xbuf[320 + lane];
                 uint32_t sa = a2.x & 1u, sb = b2.x & 1u;
-                c2 = lxor(lxor(h0, lmask(TG2, sa)), lxor(h1, lmask(lxor(TE2, a2), sb)));
+                c2 = lmask(lxor(lxor(h0, lmask(TG2, sa)), lxor(h1, lmask(lxor(TE2, a2), sb))), on2 ? 1u : 0u);
             }
         }
-#ifdef GC_STAMP
-        if (wave == 0 && lane == 0 && g_stamp) g_stamp[((((gid >> 6) & 0xffffull) << 2)) + 3] = __builtin_amdgcn_s_memtime();
-#endif
     }
     __device__ __forceinline__ W load(uint32_t id) const { return ld_lbl(words + (size_t)id * 64 + lane); }
     __device__ __forceinline__ W load2(uint32_t lo, uint32_t hi) const {
@@ -516,7 +540,7 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
 // launches; TPB = 256); QUAD = false: one wave per record, TPB / 64 records per workgroup (wide
 // launches).  TABV picks the AES tables: 4 = four rotated tables in 128 KiB (fewest instructions
 // per round; one workgroup per CU), 2 = two tables in 64 KiB (two 4-wave workgroups per CU).
-template <bool GARBLER, bool QUAD, int TABV, int TPB>
+template <bool GARBLER, bool QUAD, int TABV, int TPB, bool CRIT = false>
 __global__ void __launch_bounds__(TPB)
 gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *decode,
                uint64_t launch_step0, Lbl R, int w, int p) {
@@ -526,7 +550,7 @@ gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *d
     TS::fill(lds_te0);
     const uint32_t wid = QUAD ? blockIdx.x : blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (wid >= nrec) return;
-    typedef GpuBackend<GARBLER, QUAD ? MODE_QUAD : MODE_SOLO, typename TS::T> B;
+    typedef GpuBackend<GARBLER, QUAD ? MODE_QUAD : MODE_SOLO, typename TS::T, CRIT && GARBLER && QUAD> B;
     B be;
     be.R = R;
     be.words = words;
@@ -551,6 +575,30 @@ gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *d
     uint32_t s_hi = __builtin_amdgcn_readfirstlane((uint32_t)(r.step0 >> 32));
     be.step = ((uint64_t)s_hi << 32) | s_lo;
     exec_record(be, r, w, p);
+}
+
+// second pass of critical-path garbling: every gate step of the launch holds (a0, b0) in its two table
+// rows; one wavefront per step turns them into the half-gates ciphertexts (TG, TE) in place.  All four
+// hashes are recomputed here, in throughput mode (16 waves per CU, four-table AES).
+template <int TPB>
+__global__ void __launch_bounds__(TPB)
+gc_tabfill_kernel(Lbl *tab, uint32_t nsteps, uint64_t launch_step0, Lbl R) {
+    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    lds_tab4_fill(lds_te0);
+    const LdsTab4 lt = lds_tab4_make(lds_te0);
+    const int lane = threadIdx.x & 63;
+    const uint32_t per = TPB / 64;
+    for (uint32_t row = blockIdx.x * per + (threadIdx.x >> 6); row < nsteps; row += gridDim.x * per) {
+        Lbl *slot = tab + (size_t)row * 128 + lane;
+        const Lbl a0 = ld_lbl(slot), b0 = ld_lbl(slot + 64);
+        Lbl TG = lzero(), TE = lzero();
+        if ((a0.x | a0.y | a0.z | a0.w | b0.x | b0.y | b0.z | b0.w) != 0u) {
+            const uint64_t gid = (launch_step0 + row) * 64 + (uint64_t)lane;
+            (void)garble_and(lt, c_rk, R, a0, b0, gid, TG, TE, c_rk24);
+        }
+        st_lbl(slot, TG);
+        st_lbl(slot + 64, TE);
+    }
 }
 
 }  // namespace gc

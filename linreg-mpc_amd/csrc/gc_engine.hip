@@ -14,6 +14,7 @@
 #include "hip_scope.h"
 #include "gc_device.h"
 #include "gc_program.h"
+#include "gc_launch.h"
 
 using namespace gc;
 
@@ -261,7 +262,7 @@ struct lgc_solver {
     Lbl *wordsG, *wordsE, *tab;
     uint64_t *decG, *decE, *vals;
     Rec *recs;
-    hipStream_t stream, streamE;
+    hipStream_t stream, streamE, streamT;   // garbler chain, evaluator chain, table passes of critical-path launches
     hipEvent_t ev0, ev1, ev_in;
     // garbled-table ring: launch i writes / reads [tab_off[i], tab_off[i] + its table bytes); before
     // overwriting, the garbler waits for the evaluation of launch tab_wait[i] (the newest earlier
@@ -270,6 +271,7 @@ struct lgc_solver {
     std::vector<size_t> tab_off;
     std::vector<int64_t> tab_wait;
     std::vector<hipEvent_t> evG, evE;     // per launch: tables written / tables consumed
+    std::vector<hipEvent_t> evC;          // per launch: critical-path garbling done (table pass may start)
     std::vector<hipEvent_t> evs;
     std::vector<uint64_t> hG, hE;
     std::vector<double> tG, tE;
@@ -277,7 +279,7 @@ struct lgc_solver {
     std::vector<double> t_iter;
     bool have_shares, ran;
     lgc_stats st;
-    lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), streamE(0), ev0(0), ev1(0), ev_in(0), ring_bytes(0),
+    lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), streamE(0), streamT(0), ev0(0), ev1(0), ev_in(0), ring_bytes(0),
                    have_shares(false), ran(false) { memset(&st, 0, sizeof(st)); }
 };
 
@@ -297,9 +299,11 @@ extern "C" void lgc_solver_destroy(lgc_solver *s) {
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (size_t i = 0; i < s->evG.size(); i++) (void)hipEventDestroy(s->evG[i]);
     for (size_t i = 0; i < s->evE.size(); i++) (void)hipEventDestroy(s->evE[i]);
+    for (size_t i = 0; i < s->evC.size(); i++) (void)hipEventDestroy(s->evC[i]);
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->streamE) (void)hipStreamDestroy(s->streamE);
+    if (s->streamT) (void)hipStreamDestroy(s->streamT);
     delete s;
 }
 
@@ -359,6 +363,7 @@ static int solver_create(lgc_solver **out, int device, const lgc_system *sys, co
     } while (0)
     TRY(hipStreamCreate(&s->stream));
     TRY(hipStreamCreate(&s->streamE));
+    TRY(hipStreamCreate(&s->streamT));
     TRY(hipEventCreate(&s->ev0));
     TRY(hipEventCreate(&s->ev1));
     TRY(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
@@ -389,68 +394,6 @@ extern "C" int lgc_solver_set_shares(lgc_solver *s, const uint64_t *shares) {
     return LGC_OK;
 }
 
-// workgroup sizes of the MAC kernels (one workgroup per CU: 128 KiB of tables).  Measured on
-// d=500 (scripts/exp/mac_ab.sh): garbler 1024 threads (4 waves/SIMD, 128 VGPRs) and evaluator
-// 768 threads are the fastest; 256-thread workgroups are 25 % slower
-#ifndef GC_TPB_MACG
-#define GC_TPB_MACG 1024
-#endif
-#ifndef GC_TPB_MACE
-#define GC_TPB_MACE 768
-#endif
-static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
-#ifndef GC_MAC_EXCLUSIVE
-#define GC_MAC_EXCLUSIVE 1
-#endif
-// generic launches with at least this many records run one wave per record (throughput);
-// narrower ones run one 4-wave workgroup per record (latency)
-#ifndef GC_WIDE_LAUNCH
-#define GC_WIDE_LAUNCH 2048
-#endif
-static constexpr uint32_t kWideLaunch = GC_WIDE_LAUNCH;
-// ... and only for short records (sums, merges): long dependent records (dividers, square roots) run
-// faster in the 4-wave mode even when there are thousands of them (measured on the merged lambda sweep)
-#ifndef GC_WIDE_MAX_STEPS
-#define GC_WIDE_MAX_STEPS 256
-#endif
-static constexpr uint64_t kWideMaxSteps = GC_WIDE_MAX_STEPS;
-// wide launches: 12 records (waves) per workgroup share one 128 KiB four-table image
-#ifndef GC_TPB_WIDE
-#define GC_TPB_WIDE 768
-#endif
-static constexpr int kTpbWide = GC_TPB_WIDE;
-// 4-wave launches with at most one workgroup per CU use the four-table image (144 KiB per
-// workgroup); larger ones the two-table 64 KiB image, so that two workgroups share a CU
-static constexpr uint32_t kQuadOnePerCu = 256;
-// MAC launches with fewer records than this are latency-bound too (Cholesky / LDL^T stages at
-// small d): they run in the 4-wave mode instead of the throughput-oriented MAC kernel
-static constexpr uint32_t kNarrowMac = 1024;
-// MAC launches of at least two garbler rounds get the chip to themselves (GC_MAC_EXCLUSIVE)
-static constexpr uint32_t kExclusiveMac = 8192;
-template <bool G>
-static void launch_exec(lgc_solver *s, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, hipStream_t st) {
-    if (L.mac_only && L.nrec >= kNarrowMac) {
-        constexpr int TPB = G ? kTpbMacG : kTpbMacE;
-        const unsigned per = TPB / 64;
-        dim3 grid((L.nrec + per - 1) / per), block(TPB);
-        hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
-                           tab, L.step0, s->R, s->P.w, s->P.p);
-    } else if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) {
-        constexpr unsigned per = kTpbWide / 64;
-        dim3 grid((L.nrec + per - 1) / per), block(kTpbWide);
-        hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
-                           tab, dec, L.step0, s->R, s->P.w, s->P.p);
-    } else if (L.nrec <= kQuadOnePerCu) {
-        dim3 grid(L.nrec), block(256);
-        hipLaunchKernelGGL((gc_exec_kernel<G, true, 4, 256>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
-                           tab, dec, L.step0, s->R, s->P.w, s->P.p);
-    } else {
-        dim3 grid(L.nrec), block(256);
-        hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256>), grid, block, 0, st, s->recs + L.first_rec, L.nrec, words,
-                           tab, dec, L.step0, s->R, s->P.w, s->P.p);
-    }
-}
-
 extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
     if (!s) return lgc_fail(LGC_EINVAL, "null solver");
     if (!s->have_shares) return lgc_fail(LGC_ESTATE, "lgc_solver_set_shares has not been called");
@@ -473,6 +416,8 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
         s->evG.push_back(a);
         HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
         s->evE.push_back(b);
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        s->evC.push_back(b);
     }
     // Garbler chain on `stream`, evaluator chain on `streamE`.  Evaluate(k) waits for garble(k);
     // garble(k) waits for the evaluation of the launch whose ring region it overwrites.  With
@@ -511,18 +456,26 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
             HIPCHK(hipStreamWaitEvent(sG, s->evE[i - 1], 0));
 #endif
         if (timed) HIPCHK(hipEventRecord(s->evs[3 * i], sG));
-        launch_exec<true>(s, L, s->wordsG, s->decG, tab, sG);
-        if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
-        if (!profile) {
-            HIPCHK(hipEventRecord(s->evG[i], sG));
-            HIPCHK(hipStreamWaitEvent(sE, s->evG[i], 0));
+        if (profile || !gc_launch_is_crit(L)) {
+            HIPCHK(gc_launch<true>(s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
+            if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
+            if (!profile) HIPCHK(hipEventRecord(s->evG[i], sG));
+        } else {
+            // critical path on the garbler chain, table pass on the side stream: only the evaluation waits for it
+            HIPCHK(gc_launch_records<true>(s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
+            if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
+            HIPCHK(hipEventRecord(s->evC[i], sG));
+            HIPCHK(hipStreamWaitEvent(s->streamT, s->evC[i], 0));
+            HIPCHK(gc_launch_tabfill(L, tab, s->R, s->streamT));
+            HIPCHK(hipEventRecord(s->evG[i], s->streamT));
         }
+        if (!profile) HIPCHK(hipStreamWaitEvent(sE, s->evG[i], 0));
         if (profile) {
-            launch_exec<false>(s, L, s->wordsE, s->decE, tab, sE);
+            HIPCHK(gc_launch<false>(s->recs, L, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
             HIPCHK(hipEventRecord(s->evs[3 * i + 2], sE));
         } else {
             if (L.mac_only) HIPCHK(hipEventRecord(s->evs[3 * i + 2], sE));   // start of the evaluate kernel
-            launch_exec<false>(s, L, s->wordsE, s->decE, tab, sE);
+            HIPCHK(gc_launch<false>(s->recs, L, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
             HIPCHK(hipEventRecord(s->evE[i], sE));
         }
         while (next_iter < P.iter_launch.size() && P.iter_launch[next_iter] == i)
@@ -536,6 +489,7 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
     HIPCHK(hipEventRecord(s->ev1, sG));
     HIPCHK(hipStreamSynchronize(sG));
     HIPCHK(hipStreamSynchronize(s->streamE));
+    HIPCHK(hipStreamSynchronize(s->streamT));
     HIPCHK(hipGetLastError());
     lgc_stats &st = s->st;
     memset(&st, 0, sizeof(st));
@@ -641,28 +595,6 @@ extern "C" int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[1
     if (!rc && stats) rc = lgc_solver_get_stats(s, stats);
     lgc_solver_destroy(s);
     return rc;
-}
-
-// diagnostic: keep `blocks` workgroups busy with VALU work for about `ms` milliseconds on a
-// separate stream (used to study how the clock the chip holds depends on load)
-__global__ void gc_spin_kernel(uint32_t *out, unsigned long long ticks_100mhz) {
-    unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    uint32_t a = threadIdx.x, b = blockIdx.x * 2654435761u;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz) {
-#pragma unroll 64
-        for (int i = 0; i < 256; i++) { a = a * 1664525u + b; b ^= a >> 7; }
-    }
-    if (a == 0x12345678u) out[0] = b;
-}
-static hipStream_t g_spin_stream = 0;
-extern "C" int lgc_debug_spin(int device, int blocks, double ms) {
-    int rc = lgc_need_device(device);
-    if (rc) return rc;
-    static uint32_t *dummy = 0;
-    if (!dummy) HIPCHK(hipMalloc(&dummy, 64));
-    if (!g_spin_stream) HIPCHK(hipStreamCreateWithFlags(&g_spin_stream, hipStreamNonBlocking));
-    hipLaunchKernelGGL(gc_spin_kernel, dim3(blocks), dim3(256), 0, g_spin_stream, dummy, (unsigned long long)(ms * 1e5));
-    return LGC_OK;
 }
 
 extern "C" void *lgc_host_alloc(size_t bytes) {

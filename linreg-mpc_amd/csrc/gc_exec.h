@@ -134,7 +134,7 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
         be.store(r.dst, C::vsqrt(be, be.load(r.a), w, p));
         break;
     case OP_IDIVC:
-        be.store(r.dst, C::div(be, be.load(r.a), be.konst((uint64_t)r.c), w, 0));
+        be.store(r.dst, C::divc(be, be.load(r.a), (uint64_t)r.c, w));
         break;
     case OP_CONST:
         be.store(r.dst, be.sel(lanes(w), be.konst((uint64_t)r.a | ((uint64_t)r.b << 32)), be.zero()));

@@ -1,0 +1,140 @@
+// gc_launch.h -- which kernel runs a launch of the garbled word machine, and with what geometry.
+// One dispatch for the co-located solver (gc_engine.hip) and for the separate CSP / Evaluator
+// objects (gc_roles.hip): garbler and evaluator of a launch must agree on the execution mode,
+// because the mode fixes the order in which independent gate steps are numbered (B::kPairSteps).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gc_device.h"
+#include "gc_program.h"
+
+namespace gc {
+
+// workgroup sizes of the MAC kernels (one workgroup per CU: 128 KiB of tables).  Measured on
+// d=500: garbler 1024 threads (4 waves/SIMD, 128 VGPRs) and evaluator 768 threads are the fastest;
+// 256-thread workgroups are 25 % slower
+#ifndef GC_TPB_MACG
+#define GC_TPB_MACG 1024
+#endif
+#ifndef GC_TPB_MACE
+#define GC_TPB_MACE 768
+#endif
+static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
+#ifndef GC_MAC_EXCLUSIVE
+#define GC_MAC_EXCLUSIVE 1
+#endif
+// generic launches with at least this many records run one wave per record (throughput);
+// narrower ones run one 4-wave workgroup per record (latency)
+#ifndef GC_WIDE_LAUNCH
+#define GC_WIDE_LAUNCH 2048
+#endif
+static constexpr uint32_t kWideLaunch = GC_WIDE_LAUNCH;
+// ... and only for short records (sums, merges): long dependent records (dividers, square roots) run
+// faster in the 4-wave mode even when there are thousands of them (measured on the merged lambda sweep)
+#ifndef GC_WIDE_MAX_STEPS
+#define GC_WIDE_MAX_STEPS 256
+#endif
+static constexpr uint64_t kWideMaxSteps = GC_WIDE_MAX_STEPS;
+// wide launches: 12 records (waves) per workgroup share one 128 KiB four-table image
+#ifndef GC_TPB_WIDE
+#define GC_TPB_WIDE 768
+#endif
+static constexpr int kTpbWide = GC_TPB_WIDE;
+// 4-wave launches with at most one workgroup per CU use the four-table image (144 KiB per
+// workgroup); larger ones the two-table 64 KiB image, so that two workgroups share a CU.
+// The former are bound by the dependent chain of ONE record: their garbler runs the critical
+// path only (2 hashes per gate) and a table pass completes the ciphertexts (gc_device.h: CRIT)
+#ifndef GC_QUAD_ONE_PER_CU
+#define GC_QUAD_ONE_PER_CU 256
+#endif
+static constexpr uint32_t kQuadOnePerCu = GC_QUAD_ONE_PER_CU;
+#ifndef GC_CRIT
+#define GC_CRIT 1
+#endif
+// MAC launches with fewer records than this are latency-bound too (Cholesky / LDL^T stages at
+// small d): they run in the 4-wave mode instead of the throughput-oriented MAC kernel
+static constexpr uint32_t kNarrowMac = 1024;
+// MAC launches of at least two garbler rounds get the chip to themselves (GC_MAC_EXCLUSIVE)
+static constexpr uint32_t kExclusiveMac = 8192;
+static constexpr int kTpbTabfill = 1024;
+
+// MAC launches: one workgroup per CU and every record of a launch takes the same time, so a launch runs
+// in rounds of (CUs x waves per workgroup) records and a partly filled last round costs a whole one.
+// Pick the workgroup size (waves) in [lo, hi] that wastes the least: cost = rounds x waves.
+#ifndef GC_MAC_ADAPT
+#define GC_MAC_ADAPT 0   /* measured: -5 % on a serialised d=100 matvec, +10 % when it overlaps the evaluator chain */
+#endif
+static inline unsigned gc_num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        else
+            cus = 256;
+    }
+    return (unsigned)cus;
+}
+static inline unsigned gc_mac_waves(uint32_t nrec, unsigned lo, unsigned hi) {
+    if (!GC_MAC_ADAPT) return hi;
+    const uint64_t cus = gc_num_cus();
+    unsigned best = hi;
+    uint64_t best_cost = ~0ull;
+    for (unsigned wv = hi; wv >= lo; wv--) {
+        uint64_t wgs = (nrec + wv - 1) / wv, rounds = (wgs + cus - 1) / cus, cost = rounds * wv;
+        if (cost < best_cost) { best_cost = cost; best = wv; }
+    }
+    return best;
+}
+
+// true when the garbler of this launch runs the critical path only and needs gc_launch_tabfill afterwards
+static inline bool gc_launch_is_crit(const Launch &L) {
+    const bool mac = L.mac_only && L.nrec >= kNarrowMac;
+    const bool wide = L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps;
+    return GC_CRIT && !mac && !wide && L.nrec > 0 && L.nrec <= kQuadOnePerCu && L.steps > 0;
+}
+// the table pass of a critical-path launch; it only has to finish before the launch is EVALUATED, so the
+// co-located solver runs it on a side stream while the garbler chain moves on to the next launch
+static hipError_t gc_launch_tabfill(const Launch &L, Lbl *tab, Lbl R, hipStream_t st) {
+    const uint64_t per = kTpbTabfill / 64;
+    uint64_t blocks = (L.steps + per - 1) / per;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((gc_tabfill_kernel<kTpbTabfill>), dim3((unsigned)blocks), dim3(kTpbTabfill), 0, st, tab,
+                       (uint32_t)L.steps, L.step0, R);
+    return hipGetLastError();
+}
+
+// the record kernel of a launch (garbler: without the table pass)
+template <bool G>
+static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R, int w, int p,
+                                    hipStream_t st) {
+    if (L.nrec == 0) return hipSuccess;
+    if (L.mac_only && L.nrec >= kNarrowMac) {
+        constexpr int TPB = G ? kTpbMacG : kTpbMacE;       // upper bound (register budget of the kernel)
+        const unsigned per = gc_mac_waves(L.nrec, G ? 10 : 8, TPB / 64);
+        hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(per * 64), 0, st, recs + L.first_rec,
+                           L.nrec, words, tab, L.step0, R, w, p);
+    } else if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) {
+        constexpr unsigned per = kTpbWide / 64;
+        hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(kTpbWide), 0, st,
+                           recs + L.first_rec, L.nrec, words, tab, dec, L.step0, R, w, p);
+    } else if (L.nrec <= kQuadOnePerCu) {
+        hipLaunchKernelGGL((gc_exec_kernel<G, true, 4, 256, G && GC_CRIT>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec,
+                           L.nrec, words, tab, dec, L.step0, R, w, p);
+    } else {
+        hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec, L.nrec, words,
+                           tab, dec, L.step0, R, w, p);
+    }
+    return hipGetLastError();
+}
+
+template <bool G>
+static hipError_t gc_launch(const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R, int w, int p,
+                            hipStream_t st) {
+    hipError_t e = gc_launch_records<G>(recs, L, words, dec, tab, R, w, p, st);
+    if (e == hipSuccess && G && gc_launch_is_crit(L)) e = gc_launch_tabfill(L, tab, R, st);
+    return e;
+}
+
+}  // namespace gc

@@ -17,6 +17,7 @@
 #include "hip_scope.h"
 #include "gc_device.h"
 #include "gc_program.h"
+#include "gc_launch.h"
 
 using namespace gc;
 
@@ -188,24 +189,8 @@ extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint
 }
 
 template <bool G>
-static void party_launch(lgc_party *p, const Launch &L, Lbl *tab = 0) {
-    if (!tab) tab = p->tab;
-    if (L.mac_only && L.nrec >= kNarrowMac) {
-        constexpr int TPB = G ? kTpbMacG : kTpbMacE;
-        const unsigned per = TPB / 64;
-        hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(TPB), 0, 0, p->recs + L.first_rec, L.nrec,
-                           p->words, tab, L.step0, p->R, p->P.w, p->P.p);
-    } else if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) {
-        constexpr unsigned per = kTpbWide / 64;
-        hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(kTpbWide), 0, 0,
-                           p->recs + L.first_rec, L.nrec, p->words, tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
-    } else if (L.nrec <= kQuadOnePerCu) {
-        hipLaunchKernelGGL((gc_exec_kernel<G, true, 4, 256>), dim3(L.nrec), dim3(256), 0, 0, p->recs + L.first_rec, L.nrec, p->words,
-                           tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
-    } else {
-        hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256>), dim3(L.nrec), dim3(256), 0, 0, p->recs + L.first_rec, L.nrec, p->words,
-                           tab, p->dec, L.step0, p->R, p->P.w, p->P.p);
-    }
+static hipError_t party_launch(lgc_party *p, const Launch &L, Lbl *tab = 0) {
+    return gc_launch<G>(p->recs, L, p->words, p->dec, tab ? tab : p->tab, p->R, p->P.w, p->P.p, 0);
 }
 
 extern "C" int lgc_party_garble(lgc_party *p, size_t launch, uint8_t *tables_out) {
@@ -215,7 +200,7 @@ extern "C" int lgc_party_garble(lgc_party *p, size_t launch, uint8_t *tables_out
     RCHK(hipSetDevice(p->device));
     const Launch &L = p->P.launches[launch];
     if (L.steps) RCHK(hipMemset(p->tab, 0, (size_t)L.steps * 2048));   // inactive lanes: defined bytes on the wire
-    party_launch<true>(p, L);
+    RCHK(party_launch<true>(p, L));
     if (L.steps) RCHK(hipMemcpy(tables_out, p->tab, (size_t)L.steps * 2048, hipMemcpyDeviceToHost));
     else RCHK(hipDeviceSynchronize());
     return LGC_OK;
@@ -228,7 +213,7 @@ extern "C" int lgc_party_evaluate(lgc_party *p, size_t launch, const uint8_t *ta
     RCHK(hipSetDevice(p->device));
     const Launch &L = p->P.launches[launch];
     if (L.steps) RCHK(hipMemcpy(p->tab, tables_in, (size_t)L.steps * 2048, hipMemcpyHostToDevice));
-    party_launch<false>(p, L);
+    RCHK(party_launch<false>(p, L));
     RCHK(hipDeviceSynchronize());
     return LGC_OK;
 }
@@ -245,6 +230,10 @@ extern "C" int lgc_party_ring_create(lgc_party *p, int nslots, uint8_t handle_ou
     if (!sb) sb = 4096;
     hipError_t e = hipMalloc(&p->ring, sb * (size_t)nslots);
     if (e != hipSuccess) return lgc_fail(LGC_ENOMEM, "hipMalloc(table ring, %zu bytes): %s", sb * (size_t)nslots, hipGetErrorString(e));
+    // the evaluator process maps the whole ring: it must never see what this allocation held before
+    // (inactive lanes and padding are not written by the kernels)
+    e = hipMemset(p->ring, 0, sb * (size_t)nslots);
+    if (e != hipSuccess) { (void)hipFree(p->ring); p->ring = 0; return lgc_fail(LGC_EHIP, "hipMemset(table ring): %s", hipGetErrorString(e)); }
     hipIpcMemHandle_t h;
     e = hipIpcGetMemHandle(&h, p->ring);
     if (e != hipSuccess) {
@@ -280,7 +269,7 @@ extern "C" int lgc_party_garble_ring(lgc_party *p, size_t launch) {
     if (!p->ring) return lgc_fail(LGC_ESTATE, "lgc_party_ring_create has not been called");
     if (launch >= p->P.launches.size()) return lgc_fail(LGC_EINVAL, "launch out of range");
     RCHK(hipSetDevice(p->device));
-    party_launch<true>(p, p->P.launches[launch], ring_slot(p, launch));
+    RCHK(party_launch<true>(p, p->P.launches[launch], ring_slot(p, launch)));
     RCHK(hipDeviceSynchronize());      // kernel end = release: the tables are visible to the peer process
     return LGC_OK;
 }
@@ -291,7 +280,7 @@ extern "C" int lgc_party_evaluate_ring(lgc_party *p, size_t launch) {
     if (!p->labels_ready) return lgc_fail(LGC_ESTATE, "input labels have not been set");
     if (launch >= p->P.launches.size()) return lgc_fail(LGC_EINVAL, "launch out of range");
     RCHK(hipSetDevice(p->device));
-    party_launch<false>(p, p->P.launches[launch], ring_slot(p, launch));
+    RCHK(party_launch<false>(p, p->P.launches[launch], ring_slot(p, launch)));
     RCHK(hipDeviceSynchronize());
     return LGC_OK;
 }

@@ -62,6 +62,7 @@ struct W64 {
 template <bool GARBLER>
 struct CpuBackend {
     typedef W64 W;
+    static const bool kPairSteps = false;
     __m128i R;
     __m128i *words;
     __m128i *tab;
@@ -154,6 +155,41 @@ int gcc_plain_run(const Rec *recs, size_t nrec, int w, int p, uint64_t *words, u
     if (steps) *steps = m.steps;
     if (gates) *gates = m.gates;
     return 0;
+}
+
+// the same with the step order of the latency-bound GPU kernels (B::kPairSteps: independent gate steps
+// of the multiplier issued as dual steps); step0 is not checked record by record, only the totals
+struct PlainMachinePaired : PlainMachine {
+    static const bool kPairSteps = true;
+    PlainMachinePaired(uint64_t *w_, uint64_t *d_) : PlainMachine(w_, d_) {}
+};
+int gcc_plain_run_paired(const Rec *recs, size_t nrec, int w, int p, uint64_t *words, uint64_t *decode,
+                         uint64_t *steps, uint64_t *gates) {
+    PlainMachinePaired m(words, decode);
+    for (size_t i = 0; i < nrec; i++) {
+        if (recs[i].step0 != m.steps) return 1;
+        exec_record(m, recs[i], w, p);
+    }
+    if (steps) *steps = m.steps;
+    if (gates) *gates = m.gates;
+    return 0;
+}
+
+// one word operation on many operand pairs (op-level fuzzing of gc_circuits.h against the semantic
+// oracle): out[i] = op(a[i], b[i]); c is the public constant of OP_IDIVC.  Returns the gate steps of one op.
+uint64_t gcc_plain_op(uint32_t op, int w, int p, uint32_t c, int paired, const uint64_t *a, const uint64_t *b,
+                      uint64_t *out, size_t n) {
+    uint64_t words[4];
+    uint64_t steps = 0;
+    for (size_t i = 0; i < n; i++) {
+        words[0] = 0; words[1] = a[i]; words[2] = b[i]; words[3] = 0;
+        Rec r;
+        r.op = op; r.cnt = 1; r.dst = 3; r.a = 1; r.b = 2; r.c = c; r.sa = 1; r.sb = 1; r.step0 = 0;
+        if (paired) { PlainMachinePaired m(words, 0); exec_record(m, r, w, p); steps = m.steps; }
+        else { PlainMachine m(words, 0); exec_record(m, r, w, p); steps = m.steps; }
+        out[i] = words[3];
+    }
+    return steps;
 }
 
 void gcc_derive_R(const uint8_t seed[16], uint8_t out[16]) {

@@ -19,6 +19,10 @@ class GcCpu:
         vp, ci, sz, u64, u32 = C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.c_uint32
         L.gcc_plain_run.restype = ci
         L.gcc_plain_run.argtypes = [vp, sz, ci, ci, vp, vp, C.POINTER(u64), C.POINTER(u64)]
+        L.gcc_plain_run_paired.restype = ci
+        L.gcc_plain_run_paired.argtypes = [vp, sz, ci, ci, vp, vp, C.POINTER(u64), C.POINTER(u64)]
+        L.gcc_plain_op.restype = u64
+        L.gcc_plain_op.argtypes = [u32, ci, ci, u32, ci, vp, vp, vp, sz]
         L.gcc_derive_R.argtypes = [C.c_char_p, vp]
         L.gcc_input_labels.argtypes = [C.c_char_p, vp, vp, u32, u32, ci, vp, vp]
         L.gcc_garble_run.restype = u64
@@ -41,6 +45,14 @@ class GcCpu:
         if rc:
             raise RuntimeError("step accounting mismatch between builder and execution")
         return steps.value, gates.value
+
+    def plain_op(self, op, w, p, a, b=None, c=0, paired=False):
+        """one word operation of gc_circuits.h (plaintext backend) on arrays of operands"""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.zeros_like(a) if b is None else np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros_like(a)
+        steps = self.lib.gcc_plain_op(op, w, p, c, int(paired), _p(a), _p(b), _p(out), a.size)
+        return out, steps
 
     def derive_R(self, seed):
         out = np.zeros(16, dtype=np.uint8)
