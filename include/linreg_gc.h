@@ -14,9 +14,10 @@
  *                           with linear_system_t (src/linear.h:16-26) as lgc_system
  *   lgc_solver_set_shares   the circuit-input side of dcrRecvIntArray / feedOblivLLong
  *                           (src/input.c:81-113, src/linear.oc:31-49, :116-127)
- *   lgc_agg_*               inner_product_local and the diagonal special case
+ *   lgc_p1_local            inner_product_local and the diagonal special case
  *                           (src/phase1.c:14-20, 562-571)
- *   lgc_ti_*                run_trusted_initializer / inner_product_ti arithmetic
+ *   lgc_p1_* / lgc_ti_generate
+ *                           inner_product_ti arithmetic / run_trusted_initializer
  *                           (src/phase1.c:148-236, 241-339)
  *   lgc_ot_*                honest[Correlated]OTExt{Send,Recv}1Of2 (IKNP) as used at
  *                           src/phase1.c:58-65,84-89 and src/input.c:44,108

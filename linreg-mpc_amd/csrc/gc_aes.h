@@ -1,15 +1,16 @@
 // gc_aes.h -- fixed-key AES-128 and the garbling hash, host + device.
 //
-// CDNA4 has no AES instruction: the device path is a T-table AES whose single
-// 256-entry table Te0 is staged in LDS, replicated 64x (one 256-byte row per
-// entry) so that lane l always reads bank (l mod 32) -- conflict-free
-// ds_read_b32 regardless of the data (MI355X_MICROARCH.md, LDS: ds_read_b32
-// bank = (addr/4) mod 32) -- and so that the LDS byte address (x << 8 | l << 2)
-// is formed by ONE v_perm_b32 from the state word and a per-lane constant.
-// The three other classic tables are rotations of Te0 (v_alignbit); XORs are
-// fused with v_bitop3_b32.  Integer VALU issue is 16 lanes/clk/SIMD on CDNA4,
-// so instruction count per block (about 370) is what bounds the cipher until
-// the LDS roof (160 lookups x 2 clk per wave) takes over.
+// CDNA4 has no AES instruction: the device path is a T-table AES with the tables staged in LDS
+// (layouts in gc_device.h).  A ds_read_b32 is serviced in two groups of 32 lanes over 32 banks
+// (MI355X_MICROARCH.md, LDS), so 32 replicas of an entry -- lane l reads replica l mod 32 -- are
+// conflict-free whatever the data, and the LDS byte address (entry << 8 | table bits | replica << 2)
+// is formed by ONE v_perm_b32 from the state word and a per-lane constant.  The MAC kernels and the
+// one-workgroup-per-CU generic kernels keep all four rotated tables Te_t = rotl(Te0, 8t) resident
+// (128 KiB): a round is 16 lookups + 8 three-input XORs (v_bitop3_b32), no rotates -- 240 VALU + 160
+// ds_read_b32 per block.  Kernels that need two workgroups per CU use Te0 | Te2 in 64 KiB (one
+// rotate per column); the single-table image (three v_alignbit per column) remains for the small
+// input-label and PRG kernels.  Integer VALU issue is 16 lanes/clk/SIMD on CDNA4, so instruction
+// count per block bounds the cipher until the LDS roof (160 lookups x 2 clk per wave) takes over.
 //
 // Conventions: a 128-bit block / label is 4 little-endian u32 words; word c
 // is AES state column c, byte r of the word is state row r -- the byte order

@@ -33,7 +33,7 @@ int lgc_fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *lgc_last_error(void) { return g_err; }
-extern "C" const char *lgc_version(void) { return "linreg-mpc_amd gc engine r1 (gfx950, half-gates, LDS T-table AES)"; }
+extern "C" const char *lgc_version(void) { return "linreg-mpc_amd gc engine r2 (gfx950, half-gates, LDS T-table AES)"; }
 extern "C" int lgc_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -159,8 +159,6 @@ static int check_system(const lgc_system *sys) {
     if (sys->nshares < 1) return lgc_fail(LGC_EINVAL, "nshares must be >= 1");
     if (sys->algorithm < 0 || sys->algorithm > 2) return lgc_fail(LGC_EINVAL, "Algorithm must be cholesky, ldlt, or cgd.");
     if (sys->algorithm == LGC_ALG_CGD && sys->num_iterations < 0) return lgc_fail(LGC_EINVAL, "negative iteration count");
-    if (sys->algorithm == LGC_ALG_CHOLESKY && sys->width == 64 && sys->precision > 60)
-        return lgc_fail(LGC_EINVAL, "cholesky at width 64 supports precision <= 60 (square-root datapath is 64 lanes)");
     return LGC_OK;
 }
 

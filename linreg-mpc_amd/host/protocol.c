@@ -23,9 +23,15 @@
 size_t idx(size_t i, size_t j) { if (j > i) { size_t t = i; i = j; j = t; } return (i * (i + 1)) / 2 + j; }
 
 /* (fixed_t)(d * (1ll << p)) with the phase-2 type (src/fixed.c:3-5, src/linear.c:51) */
+/* Out of range the C cast is undefined; the reference runs on x86-64, where cvttsd2si yields the
+ * "integer indefinite" value (INT_MIN of the type) -- the rule the oracle states (orc_double_to_fixed). */
 int64_t double_to_fixed(double d, int p, int w) {
     double t = d * (double)(1ll << p);
-    if (w == 32) return (int64_t)(int32_t)t;
+    if (w == 32) {
+        if (!(t > -2147483649.0 && t < 2147483648.0)) return (int64_t)INT32_MIN;
+        return (int64_t)(int32_t)t;
+    }
+    if (!(t >= -9223372036854775808.0 && t < 9223372036854775808.0)) return INT64_MIN;
     return (int64_t)t;
 }
 double fixed_to_double(int64_t f, int p) { return ((double)f) / (double)(1ll << p); }

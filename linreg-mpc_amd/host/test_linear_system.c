@@ -74,6 +74,13 @@ int main(int argc, char **argv) {
     check(!node_new(&self, party, 2, eps), "Could not connect");
     double time = wall_clock();
     if (party == 2) printf("\nAlgorithm: %s\n", algorithm);
+    {   /* "check if inputs have equal dimensions" (src/linear.oc:109-114).  The reference compares the two
+         * d inside the circuit (31 AND gates) and reveals the bit to both; d is public here -- it fixes the
+         * circuit both sides build -- so the two sides simply exchange it. */
+        uint64_t d_mine = d, d_peer = 0;
+        check(!send_blob(self, 3 - party, &d_mine, 8) && !recv_blob(self, 3 - party, &d_peer, 8), "could not exchange dimensions");
+        check(d_mine == d_peer, "Inputs of the two parties differ.");
+    }
 
     lgc_system sys;
     memset(&sys, 0, sizeof sys);
