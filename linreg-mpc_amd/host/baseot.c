@@ -55,7 +55,7 @@ int baseot_ext_sender(node *n, int peer, uint8_t delta[16], uint8_t seeds[128][1
     EC_POINT *A = EC_POINT_new(g), *B = EC_POINT_new(g), *T = EC_POINT_new(g);
     uint8_t buf[128 * PT_LEN];
     EC_GROUP_get_order(g, order, ctx);
-    RAND_bytes(delta, 16);
+    if (RAND_bytes(delta, 16) != 1) goto done;
     if (net_recv(n, peer, buf, PT_LEN)) goto done;
     if (!EC_POINT_oct2point(g, A, buf, PT_LEN, ctx)) goto done;
     for (int j = 0; j < 128; j++) {

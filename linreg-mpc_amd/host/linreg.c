@@ -112,7 +112,7 @@ int main(int argc, char **argv) {
 
     if (party == 1) {                                                /* CSP: garbler */
         uint8_t seed[16];
-        RAND_bytes(seed, sizeof seed);
+        check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
         LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk));
         size_t bits = lgc_party_input_bits(party_obj);
         uint8_t *m0 = lgc_host_alloc(bits * 16), *m1 = lgc_host_alloc(bits * 16), *u = lgc_host_alloc(lgc_ot_u_bytes(bits)),

@@ -67,10 +67,16 @@ static uint8_t *frame_pmsg(const uint64_t *vec, size_t n, uint64_t value, size_t
     *len = sz + sizeof sz;
     return buf;
 }
+/* A phase-1 message holds at most n varints of <= 10 bytes plus two tags, one length and `value`
+ * (src/protobuf, the .proto files): a longer length prefix from a peer is rejected before anything is allocated. */
+static size_t g_pmsg_limit = (size_t)1 << 32;
+void pmsg_set_limit(size_t n_elements) { g_pmsg_limit = 10 * n_elements + 64; }
 int recv_pmsg(node *self, int from, uint64_t **vec, size_t *n, uint64_t *value) {
     size_t sz = 0;
     if (net_recv(self, from, &sz, sizeof sz)) return 1;
+    if (sz > g_pmsg_limit) { fprintf(stderr, "message of %zu bytes from party %d exceeds the protocol's bound\n", sz, from); return 1; }
     uint8_t *buf = malloc(sz ? sz : 1);
+    if (!buf) return 1;
     if (net_recv(self, from, buf, sz)) { free(buf); return 1; }
     int rc = pmsg_unpack(buf, sz, vec, n, value);
     free(buf);
@@ -222,11 +228,16 @@ static void tune_malloc(void) {
 }
 int run_trusted_initializer(node *self, config *c, int w1, int device) {
     tune_malloc();
+    pmsg_set_limit(c->n);
     uint8_t seed[16];
-    RAND_bytes(seed, sizeof seed);                       /* newBCipherRandomGen (src/phase1.c:243) */
-    const char *fixed = getenv("LINREG_TI_SEED");        /* tests only: 32 hex digits pin the TI stream */
+    if (RAND_bytes(seed, sizeof seed) != 1) { fprintf(stderr, "RAND_bytes failed\n"); return 1; }   /* newBCipherRandomGen (src/phase1.c:243) */
+#ifdef LINREG_TEST_HOOKS
+    /* bin/linreg_testhooks only (share-level parity tests): 32 hex digits pin the TI stream.  The
+     * production binaries are built without this: whoever sets the TI's seed knows every mask. */
+    const char *fixed = getenv("LINREG_TI_SEED");
     if (fixed && strlen(fixed) == 32)
         for (int i = 0; i < 16; i++) { unsigned v = 0; sscanf(fixed + 2 * i, "%2x", &v); seed[i] = (uint8_t)v; }
+#endif
     const size_t n = c->n;
     /* enumerate the cross-party pairs in the loop order of src/phase1.c:256-258, then generate the
      * randomness in batches on the GPU and send the two messages of every pair in that order */
@@ -681,6 +692,7 @@ static void *ot_recv_starter(void *arg) {
 int run_party(node *self, config *c, int precision, int precision_p2, int w1, int w2, int use_ot, int device,
                      uint64_t **res_A, uint64_t **res_b) {
     tune_malloc();
+    pmsg_set_limit(c->n);
     const double t_start = wall_clock();
     const size_t n = c->n, d = c->d, T = d * (d + 1) / 2;
     const int me = c->party - 1, last = c->num_parties - 1;
@@ -759,7 +771,7 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
             size_t sz = 0;
             double r0 = timing_r ? now_s() : 0, r1, r2;
             if (timing_r) {
-                if (net_recv(self, 1, &sz, sizeof sz)) { failed = 1; break; }
+                if (net_recv(self, 1, &sz, sizeof sz) || sz > g_pmsg_limit) { failed = 1; break; }
                 r1 = now_s();
                 if (!(it.raw = malloc(sz ? sz : 1)) || net_recv(self, 1, it.raw, sz)) { failed = 1; free(it.raw); break; }
                 r2 = now_s();
@@ -768,7 +780,7 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
                 rd_hdr += r1 - r0; rd_body += r2 - r1; rd_push += now_s() - r2;
                 continue;
             }
-            if (net_recv(self, 1, &sz, sizeof sz) || !(it.raw = malloc(sz ? sz : 1)) || net_recv(self, 1, it.raw, sz)) {
+            if (net_recv(self, 1, &sz, sizeof sz) || sz > g_pmsg_limit || !(it.raw = malloc(sz ? sz : 1)) || net_recv(self, 1, it.raw, sz)) {
                 fprintf(stderr, "Could not receive message from TI\n"); failed = 1; free(it.raw); break;
             }
             it.len = sz;

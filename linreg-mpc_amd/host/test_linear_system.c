@@ -90,7 +90,7 @@ int main(int argc, char **argv) {
     const size_t chunk = ring_slots > 0 ? (size_t)1 << 30 : (size_t)64 << 20;
     if (party == 1) {
         uint8_t seed[16];
-        RAND_bytes(seed, sizeof seed);
+        check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
         LGC(lgc_party_create(&po, device, &sys, LGC_ROLE_GARBLER, seed, chunk));
         size_t bits = lgc_party_input_bits(po);
         uint8_t *lab = malloc(bits * 16), *m0 = malloc(bits * 16), *m1 = malloc(bits * 16), *u = malloc(lgc_ot_u_bytes(bits)), *e = malloc(bits * 32);

@@ -196,16 +196,19 @@ static size_t owner_of(size_t row, size_t P, const size_t *start) {
     return party;
 }
 
-int orc_phase1_ti_shares(const int64_t *Xq, const int64_t *yq, size_t n, size_t d,
-                         int p1, int w1, size_t P, const size_t *start,
-                         const uint64_t *rnd, size_t *rnd_words,
-                         uint64_t *shares_A, uint64_t *shares_b) {
-    size_t T = d * (d + 1) / 2, used = 0, cap = *rnd_words;
+/* The TI's randomness arrives through `next`: every cross-party pair asks for its 2n+1 words (x, y, r
+ * in this order, phase1.c:271-273), so a full-size run never holds the whole stream in memory. */
+int orc_phase1_ti_shares_cb(const int64_t *Xq, const int64_t *yq, size_t n, size_t d,
+                            int p1, int w1, size_t P, const size_t *start,
+                            orc_rnd_fn next, void *ctx, size_t *rnd_words,
+                            uint64_t *shares_A, uint64_t *shares_b) {
+    size_t T = d * (d + 1) / 2, used = 0;
     uint64_t m = mask_w(w1);
     memset(shares_A, 0, P * T * sizeof(uint64_t));
     memset(shares_b, 0, P * d * sizeof(uint64_t));
     uint64_t *bx = malloc(n * sizeof(uint64_t)), *ay = malloc(n * sizeof(uint64_t));
-    if (!bx || !ay) { free(bx); free(ay); return 1; }
+    uint64_t *rnd = malloc((2 * n + 1) * sizeof(uint64_t));
+    if (!bx || !ay || !rnd) { free(bx); free(ay); free(rnd); return 1; }
     /* loop order of run_party / run_trusted_initializer (phase1.c:256-258, 534-545) */
     for (size_t i = 0; i <= d; i++) {
         const int64_t *row_i = i < d ? Xq + i : yq;
@@ -222,9 +225,9 @@ int orc_phase1_ti_shares(const int64_t *Xq, const int64_t *yq, size_t n, size_t 
             } else {
                 /* TI: x, y, r in this order (phase1.c:271-273); a = owner(i) gets
                  * (y, <x,y>-r), b = owner(j) gets (x, r) (phase1.c:253-254, 277-284) */
-                if (used + 2 * n + 1 > cap) { free(bx); free(ay); return 2; }
-                const uint64_t *x = rnd + used, *y = rnd + used + n;
-                uint64_t r = rnd[used + 2 * n] & m;
+                if (next(ctx, used, 2 * n + 1, rnd)) { free(bx); free(ay); free(rnd); return 2; }
+                const uint64_t *x = rnd, *y = rnd + n;
+                uint64_t r = rnd[2 * n] & m;
                 used += 2 * n + 1;
                 uint64_t xy = 0;
                 for (size_t k = 0; k < n; k++) xy += (x[k] & m) * (y[k] & m);
@@ -252,9 +255,24 @@ int orc_phase1_ti_shares(const int64_t *Xq, const int64_t *yq, size_t n, size_t 
             }
         }
     }
-    free(bx); free(ay);
+    free(bx); free(ay); free(rnd);
     *rnd_words = used;
     return 0;
+}
+
+struct rnd_array { const uint64_t *words; size_t cap; };
+static int rnd_from_array(void *ctx, size_t first, size_t count, uint64_t *out) {
+    const struct rnd_array *a = ctx;
+    if (first + count > a->cap) return 1;
+    memcpy(out, a->words + first, count * sizeof(uint64_t));
+    return 0;
+}
+int orc_phase1_ti_shares(const int64_t *Xq, const int64_t *yq, size_t n, size_t d,
+                         int p1, int w1, size_t P, const size_t *start,
+                         const uint64_t *rnd, size_t *rnd_words,
+                         uint64_t *shares_A, uint64_t *shares_b) {
+    struct rnd_array a = {rnd, *rnd_words};
+    return orc_phase1_ti_shares_cb(Xq, yq, n, d, p1, w1, P, start, rnd_from_array, &a, rnd_words, shares_A, shares_b);
 }
 
 /* one Gilboa inner product (src/phase1.c:38-96): receiver holds a (choice

@@ -58,6 +58,12 @@ void orc_aggregate(const int64_t *Xq, const int64_t *yq, size_t n, size_t d,
  * rnd: stream of uniformly random w1-bit words consumed exactly as the TI
  * does (x[n], y[n], r per cross-party pair in (i, j) order).  rnd_words in:
  * capacity; out: words consumed.  shares_A: P x T, shares_b: P x d. */
+/* words [first, first + count) of the TI's random stream -> out; non-zero = stream exhausted */
+typedef int (*orc_rnd_fn)(void *ctx, size_t first, size_t count, uint64_t *out);
+int orc_phase1_ti_shares_cb(const int64_t *Xq, const int64_t *yq, size_t n, size_t d,
+                            int p1, int w1, size_t P, const size_t *start,
+                            orc_rnd_fn next, void *ctx, size_t *rnd_words,
+                            uint64_t *shares_A, uint64_t *shares_b);
 int orc_phase1_ti_shares(const int64_t *Xq, const int64_t *yq, size_t n, size_t d,
                          int p1, int w1, size_t P, const size_t *start,
                          const uint64_t *rnd, size_t *rnd_words,

@@ -93,6 +93,28 @@ class Oracle:
         return sA, sb, used.value
 
     def ti_shares(self, *a): return self._shares(self.lib.orc_phase1_ti_shares, *a)
+
+    def ti_shares_stream(self, Xq, yq, n, d, p1, w1, start, words_fn):
+        """as ti_shares, the TI's stream supplied pair by pair: words_fn(first_word, count) -> uint64 array"""
+        Xq = np.ascontiguousarray(Xq, dtype=np.int64); yq = np.ascontiguousarray(yq, dtype=np.int64)
+        start = np.ascontiguousarray(start, dtype=np.uint64); P = len(start)
+        T = d * (d + 1) // 2
+        sA = np.zeros((P, T), dtype=np.uint64); sb = np.zeros((P, d), dtype=np.uint64)
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64))
+
+        def cb(_ctx, first, count, out):
+            w = np.ascontiguousarray(words_fn(first, count), dtype=np.uint64)
+            C.memmove(out, w.ctypes.data, count * 8)
+            return 0
+        used = C.c_size_t(0)
+        fn = self.lib.orc_phase1_ti_shares_cb
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_void_p, CB, C.c_void_p,
+                       C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p]
+        rc = fn(_p(Xq), _p(yq), n, d, p1, w1, P, _p(start), CB(cb), None, C.byref(used), _p(sA), _p(sb))
+        if rc:
+            raise RuntimeError("oracle share simulation failed rc=%d" % rc)
+        return sA, sb, used.value
     def ot_shares(self, *a): return self._shares(self.lib.orc_phase1_ot_shares, *a)
 
     def convert_shares(self, s, p1, p2, w1, w2):

@@ -102,8 +102,8 @@ def _rewrite_ports(src, dst):
     return P
 
 
-def _run_all(infile, P, args, timeout=300):
-    exe = os.path.join(HOST, "bin", "linreg")
+def _run_all(infile, P, args, timeout=300, exe_name="linreg"):
+    exe = os.path.join(HOST, "bin", exe_name)
     procs = []
     for party in range(1, P + 3):
         cmd = [exe, infile, args[0], str(party)] + args[1:]
@@ -271,7 +271,8 @@ def test_five_process_64_32_split_share_level(tmp_path, golden_dir, oracle, gccp
     seed = bytes(range(0x40, 0x50))
     os.environ["LINREG_TI_SEED"] = seed.hex()
     try:
-        outs = _run_all(infile, P, ["%d" % p1, "cgd", str(iters), str(lam), "--width_phase2=32", "--prec_phase2=%d" % p2])
+        outs = _run_all(infile, P, ["%d" % p1, "cgd", str(iters), str(lam), "--width_phase2=32", "--prec_phase2=%d" % p2],
+                        exe_name="linreg_testhooks")      # the production binary ignores LINREG_TI_SEED
     finally:
         del os.environ["LINREG_TI_SEED"]
     got = re.findall("-?[0-9]+\\.[0-9]+", outs[1].strip().splitlines()[-1])
