@@ -35,6 +35,159 @@ def ref_equiv_gates(d, iters):
     return (total20 - 20 * per_it) + iters * per_it
 
 
+def cpu_info():
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
+def measure_hbm_traffic(argv_tail, kernel_substr="gc_mac_kernel<true"):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured in THIS run:
+    two child processes of this same script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    (separate passes, counters only, the program directly after `--`; MI355X_MICROARCH.md, HBM
+    section), started before this process touches the GPU.  Returns (bytes_per_launch, detail)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"error": "rocprofv3 not found"}
+    work = tempfile.mkdtemp(prefix="lgc_pmc_")
+    env = dict(os.environ, TMPDIR=work)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    vals, launches = {}, 0
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__), "--child"] + argv_tail
+            r = subprocess.run(cmd, cwd=work, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode()[-300:])}
+            acc = []
+            for row in csv.DictReader(open(files[0])):
+                if kernel_substr in row["Kernel_Name"] and row.get("Counter_Name", counter) == counter:
+                    acc.append(float(row["Counter_Value"]))
+            if not acc:
+                return None, {"error": "no %s rows for %s" % (counter, kernel_substr)}
+            vals[counter] = sum(acc) / len(acc)
+            launches = len(acc)
+    except Exception as e:                                   # a profiler problem must not cost the bench line
+        return None, {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    # gfx950: FETCH_SIZE counts wide coalesced reads at half (guide's correction) -> x2; both are in KiB
+    total = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return total, {"source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of bench.py --child",
+                   "fetch_kib_per_launch": vals["FETCH_SIZE"], "write_kib_per_launch": vals["WRITE_SIZE"],
+                   "launches_sampled": launches, "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+
+
+def _free_ports(k):
+    import socket
+    socks = [socket.socket() for _ in range(k)]
+    for s_ in socks:
+        s_.bind(("127.0.0.1", 0))
+    ports = [s_.getsockname()[1] for s_ in socks]
+    for s_ in socks:
+        s_.close()
+    return ports
+
+
+def phase12_wall(np, name, n, d, starts, alg, iters, extra, device_index):
+    """phases 1 + 2 end to end through bin/linreg, every party its own process on this box (the second
+    half of the metric string): synthetic instance of experiments/generate_tests.py:159-169, wall-clock
+    from the first spawn to the last exit, Result line checked against the oracle."""
+    import re, subprocess, tempfile
+    host = os.path.join(ROOT, "linreg-mpc_amd", "host")
+    exe = os.path.join(host, "bin", "linreg")
+    if not os.path.exists(exe):
+        return {"config": name, "error": "bin/linreg not built"}
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((n, d)); X /= np.abs(X).max(axis=0)
+    y = X @ rng.random(d) + 0.1 * rng.standard_normal(n)
+    ports = _free_ports(len(starts) + 2)
+    tmp = tempfile.mkdtemp(prefix="lgc_e2e_")
+    path = os.path.join(tmp, name + ".in")
+    with open(path, "w") as f:
+        f.write("%d %d %d\n127.0.0.1:%d\n127.0.0.1:%d\n" % (n, d, len(starts), ports[0], ports[1]))
+        for k, st in enumerate(starts):
+            f.write("127.0.0.1:%d %d\n" % (ports[2 + k], st))
+        f.write("%d %d\n" % (n, d))
+        np.savetxt(f, X, fmt="%.17g")
+        f.write("%d\n" % n)
+        np.savetxt(f, y[None, :], fmt="%.17g")
+    env = dict(os.environ, LINREG_DEVICE=str(device_index))
+    args = ["56", alg, str(iters), "0.001"] + extra
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([exe, path, args[0], str(k)] + args[1:], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+             for k in range(1, len(starts) + 3)]
+    outs = [q.communicate(timeout=600) for q in procs]
+    wall = time.perf_counter() - t0
+    res = {"config": name, "n": n, "d": d, "providers": len(starts), "algorithm": alg, "iterations": iters, "options": extra,
+           "phase12_wall_s": wall, "processes": len(procs)}
+    if any(q.returncode != 0 for q in procs):
+        res["error"] = outs[[q.returncode != 0 for q in procs].index(True)][1].decode()[-300:]
+        return res
+    ev = outs[1][0].decode()
+    m = re.search("Time elapsed: ([0-9.]+)", ev)
+    res["evaluator_time_elapsed_s"] = float(m.group(1)) if m else None
+    try:                                                     # checker only: the oracle on the same file
+        import orc
+        beta = orc.load().linreg_file(path, 56, -1, 64, 64, {"cholesky": 0, "ldlt": 1, "cgd": 2}[alg], iters, 0.001)
+        got = re.findall("-?[0-9]+\\.[0-9]+", ev.strip().splitlines()[-1])
+        res["exact_vs_oracle"] = got == ["%.15f" % (int(v) / 2.0 ** 56) for v in beta]
+    except Exception as e:
+        res["exact_vs_oracle"] = None
+        res["oracle_error"] = str(e)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
+def two_process_ring(np, d, iters, p, Af, bf, gates, device_index):
+    """the deployment-shaped figure: CSP and Evaluator as two processes (bin/test_linear_system), garbled
+    tables handed over through the device-resident hipIpc ring; rate = gates / (time of the last iteration)"""
+    import re, subprocess, tempfile
+    exe = os.path.join(ROOT, "linreg-mpc_amd", "host", "bin", "test_linear_system")
+    if not os.path.exists(exe):
+        return {"error": "bin/test_linear_system not built"}
+    tmp = tempfile.mkdtemp(prefix="lgc_ring_")
+    path = os.path.join(tmp, "ls.in")
+    with open(path, "w") as f:
+        f.write("%d %d\n" % (d, d))
+        np.savetxt(f, Af, fmt="%.17g")
+        f.write("%d\n" % d)
+        np.savetxt(f, bf[None, :], fmt="%.17g")
+        f.write("%d\n" % d)
+        np.savetxt(f, np.zeros((1, d)), fmt="%g")
+    port = _free_ports(1)[0]
+    env = dict(os.environ, LINREG_DEVICE=str(device_index))
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([exe, str(port), str(k), path, "cgd", str(iters), str(p), "--host=127.0.0.1", "--table_ring=8"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for k in (1, 2)]
+    outs = [q.communicate(timeout=900) for q in procs]
+    wall = time.perf_counter() - t0
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    if any(q.returncode != 0 for q in procs):
+        return {"error": outs[0][1].decode()[-200:] + outs[1][1].decode()[-200:]}
+    ev = outs[1][0].decode()
+    its = [float(v) for v in re.findall("Iteration [0-9]+ time: ([0-9.]+)", ev)]
+    g = re.search("Number of gates: ([0-9]+)", ev)
+    if not its or not g:
+        return {"error": "could not parse the evaluator's output"}
+    return {"seconds_garble_eval": its[-1], "and_gates": int(g.group(1)), "and_gates_per_s": int(g.group(1)) / its[-1],
+            "wall_all_s": wall, "note": "iteration clock of cgd.oc:190-194 on the evaluator: first table to last reveal; "
+                                        "wall_all_s also holds process start, parsing of the 250 000-entry text file, base OTs and input OT"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +199,9 @@ def main():
     ap.add_argument("--precision", type=int, default=56)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the phase-1+2 bin/linreg runs and the two-process ring run")
+    ap.add_argument("--child", action="store_true", help="(internal) one bare solve, for the PMC passes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -53,6 +209,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    # HBM counters first: the profiled children must start before this process initialises the GPU
+    traffic, traffic_detail = None, {"source": "not measured (--no-traffic, N > 1, or a non-default workload)"}
+    if rank == 0 and world == 1 and not args.child and not args.no_traffic:
+        traffic, traffic_detail = measure_hbm_traffic(["--d", str(args.d), "--iters", str(args.iters), "--width", str(args.width),
+                                                       "--precision", str(args.precision)])
 
     import numpy as np
     import torch                       # first: one HIP runtime per process (shared SONAME)
@@ -114,6 +276,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.child:                     # PMC pass: one solve, nothing else
+        solver.run()
+        solver.close()
+        return
     for _ in range(args.warmup):
         solver.run()
     barrier()
@@ -167,19 +333,8 @@ def main():
         aes_achieved = 4.0 * mac_gates / xg if xg > 0 else 0.0
         aes_achieved_eval = 2.0 * mac_gates / xe if xe > 0 else 0.0
         achieved_excl = alg_bytes_per_launch / (xg / n_launch_per_solve) / 1e9 if xg > 0 else 0.0
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs of this same command, gfx950 correction applied); only valid for the profiled workload
-        traffic = None
-        try:
-            pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc_hbm.json"))
-            if pmcs and (d, iters, w, p) == (500, 15, 64, 56):
-                pm = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
-                key = [k for k in pm["kernels"] if "gc_mac_kernel<true" in k][0]
-                traffic = pm["kernels"][key]["hbm_bytes_per_launch_corrected"]
-        except Exception:
-            traffic = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                     "kernel": "gc_mac_kernel<garbler>", "avg_launch_ms": avg_dur * 1e3,
                     "alg_bytes_per_launch": alg_bytes_per_launch,
                     "achieved_exclusive": achieved_excl, "avg_launch_ms_exclusive": xg / n_launch_per_solve * 1e3,
@@ -200,9 +355,17 @@ def main():
             rate1, _, s1 = g.baseline_mac(w, p, 40, 4)
             nrec = max(40, int(40 * args.cpu_seconds / max(s1, 1e-3)))
             rate, cg, cs = g.baseline_mac(w, p, nrec, 4)
-            cpu = {"value": rate, "unit": "AND-gates/s", "cores": 2, "kind": "port",
+            model, total_cores = cpu_info()
+            cpu = {"value": rate, "unit": "AND-gates/s", "cores": 2, "kind": "port", "model": model, "total_cores": total_cores,
                    "sample": "%d OP_MAC records x 4 products (%d AND gates, %.1f s): AES-NI half-gates, one "
                              "garbler thread + one evaluator thread, gates in program order" % (nrec, cg, cs)}
+        # the second half of the metric string and the deployment-shaped rate, measured in this run
+        e2e, ring = None, None
+        if world == 1 and not args.no_e2e:
+            e2e = [phase12_wall(np, "c2", 1000, 20, [0, 10], "cholesky", 0, ["--table_ring"], device_index),
+                   phase12_wall(np, "c3-ti", 10000, 100, [0, 50], "cgd", 15, ["--table_ring"], device_index)]
+            if (w, p) == (64, 56):
+                ring = two_process_ring(np, d, iters, p, Af, bf, gates, device_index)
         refg = ref_equiv_gates(d, iters) if w == 64 else None
         out = {
             "metric": "AND-gates/sec (garble+eval) d=500 CGD-15; phase1+2 wall-clock",
@@ -223,6 +386,7 @@ def main():
             "seconds_exclusive_per_solve": {"mac_garble": xg, "mac_eval": xe, "all_garble": stx["seconds_garble"],
                                             "all_eval": stx["seconds_eval"]},
             "roofline": roofline, "aes_roofline": aes_roofline, "cpu_baseline": cpu,
+            "phase12": e2e, "two_process_ring": ring,
             "beta0": float(int(beta_fixed[0]) / scale),
         }
         print(json.dumps(out), flush=True)
