@@ -202,6 +202,10 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the phase-1+2 bin/linreg runs and the two-process ring run")
     ap.add_argument("--child", action="store_true", help="(internal) one bare solve, for the PMC passes")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the 64-lambda sweep (BASELINE config 5)")
+    ap.add_argument("--sweep-d", type=int, default=100)
+    ap.add_argument("--sweep-iters", type=int, default=15)
+    ap.add_argument("--sweep-lambdas", type=int, default=64)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -306,6 +310,66 @@ def main():
     total_gates = gates * args.steps * world
     value = total_gates / elapsed
 
+    # ---- BASELINE config 5: the 64-lambda sweep of the d=100 CGD-15 circuit, sharded over the ranks.  The
+    # lambda-independent prefix (input labels + garbled share summation) is garbled on rank 0 and broadcast
+    # (RCCL over xGMI at N > 1), every rank runs its contiguous block as one merged program, all_gather
+    # collects the results (python/sweep.py).  Timed like the main region: barrier + synchronize, max over ranks.
+    sweep_res = None
+    if not args.no_sweep:
+        import sweep
+        sd, sit, nl = args.sweep_d, args.sweep_iters, args.sweep_lambdas
+        srng = np.random.default_rng(5)
+        sT = sd * (sd + 1) // 2
+        sn = 4 * sd
+        sX = srng.standard_normal((sn, sd)); sX /= np.abs(sX).max(axis=0)
+        sy = sX @ srng.random(sd) + 0.1 * srng.standard_normal(sn)
+        sA = sX.T @ sX / sn; sb = sX.T @ sy / sn                       # aggregate before the in-circuit division by d
+        stot = np.concatenate([[int(sA[i, j] * scale) for i in range(sd) for j in range(i + 1)],
+                               [int(v * scale) for v in sb]]).astype(np.int64).astype(np.uint64)
+        smask = srng.integers(0, 2 ** 63, size=stot.size, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            sshares = np.stack([stot - smask, smask])
+        if w == 32:
+            sshares &= np.uint64(0xffffffff)
+        lams = sweep.c5_lambdas(nl)
+        make = sweep.gpu_block_solver_factory(sd, w, p, "cgd", sit, 2, device_index)
+        sweep.shared_prefix_sweep(sshares if rank == 0 else None, lams[:max(2 * world, 2)], sd, make, dist=dist, tensor_device="cuda")  # warm-up
+        barrier()
+        ts = time.perf_counter()
+        sst = {}
+        sres = sweep.shared_prefix_sweep(sshares if rank == 0 else None, lams, sd, make, dist=dist, tensor_device="cuda", stats=sst)
+        barrier()
+        sdt = time.perf_counter() - ts
+        if dist is not None:
+            tmax = torch.tensor([sdt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            sdt = float(tmax.item())
+        dump = os.environ.get("LGC_BENCH_DUMP")
+        if dump:                                                   # tests: what every rank holds after the gather
+            json.dump({"rank": rank, "lambdas": lams, "beta": sres.tolist(), "shares": sshares.tolist(), "d": sd, "iters": sit,
+                       "width": w, "precision": p}, open(os.path.join(dump, "sweep_rank%d.json" % rank), "w"))
+        if rank == 0:
+            sprog = lgc.Program(lgc.make_system(sd, w, p, "cgd", sit, 0.0, 2, 1, 0, 0), lambdas=lams)
+            sgates = int(sprog.info.total_gates)
+            sweep_res = {"lambdas": nl, "d": sd, "iterations": sit, "n_gpus": world, "seconds": sdt,
+                         "circuits_per_s": nl / sdt, "and_gates": sgates, "and_gates_per_s": sgates / sdt,
+                         "prefix_bytes_broadcast": sst.get("prefix_bytes") if world > 1 else 0,
+                         "collectives": ("broadcast(seed, garbled prefix) + all_gather(results) over %s" % backend) if world > 1 else None,
+                         "sharding": "contiguous blocks of %d lambdas per rank; prefix (input labels + share-summation tables) garbled once on rank 0" % ((nl + world - 1) // world)}
+            if not args.no_cpu_baseline:
+                try:                                               # checker only
+                    import orc
+                    from helpers import oracle_solve
+                    orc_ = orc.load()
+                    ok = True
+                    for k in (0, nl - 1):
+                        exp, _, _ = oracle_solve(orc_, stot[:sT], stot[sT:], sd, w, p, "cgd", sit, lams[k], 1)
+                        ok = ok and [int(v) for v in exp] == [int(v) for v in sres[k]]
+                    sweep_res["exact_vs_oracle"] = ok
+                except Exception as e:
+                    sweep_res["exact_vs_oracle"] = None
+                    sweep_res["oracle_error"] = str(e)
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel (garbling of the MAC launches), HIP events on its stream
@@ -386,7 +450,7 @@ def main():
             "seconds_exclusive_per_solve": {"mac_garble": xg, "mac_eval": xe, "all_garble": stx["seconds_garble"],
                                             "all_eval": stx["seconds_eval"]},
             "roofline": roofline, "aes_roofline": aes_roofline, "cpu_baseline": cpu,
-            "phase12": e2e, "two_process_ring": ring,
+            "phase12": e2e, "two_process_ring": ring, "sweep64": sweep_res,
             "beta0": float(int(beta_fixed[0]) / scale),
         }
         print(json.dumps(out), flush=True)

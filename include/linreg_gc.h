@@ -96,15 +96,34 @@ int lgc_solver_set_shares(lgc_solver *s, const uint64_t *shares);
  * profile != 0 brackets every kernel with HIP events (slower; fills the per-kernel times). */
 int lgc_solver_run(lgc_solver *s, int profile);
 
-/* Per-lambda sweep (BASELINE config 5): `count` independent circuits that differ only in the public
+/* Per-lambda sweep (BASELINE config 5): `count` circuits that differ only in the public
  * regularisation constant added to the diagonal (src/linear.oc:52-57), garbled and evaluated as one
- * program -- the launches of all circuits are merged, so the latency-bound stages (dividers,
- * reveals) of different circuits fill the GPU together.  sys->lambda is ignored; sys->normalize
- * must be 1, trace and reveal_inputs 0.  All circuits read the shares given to
- * lgc_solver_set_shares; lgc_solver_get_beta returns count x d words (circuit-major). */
+ * program.  lambda enters AFTER the shares are summed, so the input labels and the garbled
+ * share-summation launches -- the shared prefix -- exist once for the whole sweep (a data provider
+ * runs one label OT whatever the number of lambdas); the launches of all circuits are merged, so the
+ * latency-bound stages (dividers, reveals) of different circuits fill the GPU together.
+ * sys->lambda is ignored; sys->normalize must be 1, trace and reveal_inputs 0.  All circuits read
+ * the shares given to lgc_solver_set_shares; lgc_solver_get_beta returns count x d words
+ * (circuit-major). */
 int lgc_solver_create_sweep(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16],
                             size_t count, const double *lambdas);
 size_t lgc_solver_num_circuits(const lgc_solver *s);
+/* One rank's block of a sweep sharded over several GPUs: circuits
+ * [first, first + count) of the whole sweep.  All ranks use the SAME seed: they share the prefix, hence
+ * the garbler's offset R, and `first` keeps the gate ids of different ranks' circuits disjoint.
+ *   rank 0:     lgc_solver_set_shares; lgc_solver_prefix_garble        (input labels + prefix tables)
+ *               lgc_solver_prefix_export(dev_buf)                      -> broadcast (RCCL over xGMI)
+ *   every rank: lgc_solver_prefix_import(dev_buf); lgc_solver_run      (evaluates the prefix from the
+ *               broadcast tables, then garbles + evaluates its own circuits)
+ * dev_buf: device memory of lgc_solver_prefix_bytes() bytes on the solver's GPU, owned by the caller
+ * (e.g. a torch tensor handed to torch.distributed.broadcast).  Layout: garbler words of the shared
+ * region | evaluator words of the shared region | tables of the prefix launches, in launch order. */
+int lgc_solver_create_sweep_at(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16],
+                               size_t count, const double *lambdas, size_t first);
+size_t lgc_solver_prefix_bytes(const lgc_solver *s);
+int lgc_solver_prefix_garble(lgc_solver *s);
+int lgc_solver_prefix_export(lgc_solver *s, void *dev_buf);
+int lgc_solver_prefix_import(lgc_solver *s, const void *dev_buf);
 
 /* Results (sign-extended to int64 when width == 32).  beta: d (sweep: count x d).
  * trace: num_iterations x (d + 4) (x, gamma, eta, q, ng), inputs: T + d. */
@@ -136,11 +155,15 @@ typedef struct {
     uint32_t n_words, n_reveal, in_base, rv_beta, rv_trace, rv_inputs;
     uint64_t total_steps, total_gates, max_launch_steps;
     uint32_t replicas, word_stride, reveal_stride;   /* sweep programs: circuit t uses words x + t * word_stride
-                                                        (x != 0) and decode slots r + t * reveal_stride */
+                                                        (x >= shared_end) and decode slots r + t * reveal_stride */
+    uint32_t shared_end, prefix_launches;            /* words [0, shared_end) and launches [0, prefix_launches) are */
+    uint64_t prefix_steps;                           /* the lambda-independent prefix (inputs, share sums) */
 } lgc_program_info;
 typedef struct lgc_program lgc_program;
 int lgc_program_build(lgc_program **out, const lgc_system *sys);
 int lgc_program_build_sweep(lgc_program **out, const lgc_system *sys, size_t count, const double *lambdas);
+/* the block [first, first + count) of a larger sweep (gate ids offset by `first` circuits) */
+int lgc_program_build_sweep_at(lgc_program **out, const lgc_system *sys, size_t count, const double *lambdas, size_t first);
 void lgc_program_destroy(lgc_program *p);
 int lgc_program_info_get(const lgc_program *p, lgc_program_info *info);
 const lgc_record *lgc_program_records(const lgc_program *p);

@@ -189,22 +189,37 @@ extern "C" int lgc_program_build(lgc_program **out, const lgc_system *sys) {
     *out = p;
     return LGC_OK;
 }
-extern "C" int lgc_program_build_sweep(lgc_program **out, const lgc_system *sys, size_t count, const double *lambdas) {
+static int check_sweep(const lgc_system *sys, size_t count, const double *lambdas) {
     int rc = check_system(sys);
     if (rc) return rc;
-    if (!out || !lambdas) return lgc_fail(LGC_EINVAL, "null argument");
+    if (!lambdas) return lgc_fail(LGC_EINVAL, "null lambdas");
     if (count < 1 || count > 4096) return lgc_fail(LGC_EINVAL, "count must be in 1..4096");
     if (!sys->normalize || sys->trace || sys->reveal_inputs)
         return lgc_fail(LGC_EINVAL, "a sweep needs normalize = 1 (lambda enters there), trace = 0, reveal_inputs = 0");
+    return LGC_OK;
+}
+// the merged program of `count` circuits; cap_steps as for build()
+static int build_sweep(Program &P, const lgc_system *sys, size_t count, const double *lambdas, size_t first, uint64_t cap_steps = 0) {
     Program base;
-    build(base, sys);
-    if ((uint64_t)base.n_words * count >= (1ull << 31)) return lgc_fail(LGC_EINVAL, "sweep too large");
+    build(base, sys, cap_steps);
+    if ((uint64_t)base.n_words * count >= (1ull << 31)) return lgc_fail(LGC_EINVAL, "sweep too large: %zu circuits x %u words", count, base.n_words);
     std::vector<uint64_t> lf(count);
     for (size_t t = 0; t < count; t++) lf[t] = lambda_to_fixed(lambdas[t], sys->precision, sys->width);
+    replicate_program(P, base, count, lf.data(), first);
+    return LGC_OK;
+}
+extern "C" int lgc_program_build_sweep_at(lgc_program **out, const lgc_system *sys, size_t count, const double *lambdas, size_t first) {
+    int rc = check_sweep(sys, count, lambdas);
+    if (rc) return rc;
+    if (!out) return lgc_fail(LGC_EINVAL, "null argument");
     lgc_program *p = new lgc_program();
-    replicate_program(p->P, base, count, lf.data());
+    rc = build_sweep(p->P, sys, count, lambdas, first);
+    if (rc) { delete p; return rc; }
     *out = p;
     return LGC_OK;
+}
+extern "C" int lgc_program_build_sweep(lgc_program **out, const lgc_system *sys, size_t count, const double *lambdas) {
+    return lgc_program_build_sweep_at(out, sys, count, lambdas, 0);
 }
 extern "C" int lgc_program_ring_plan(const lgc_program *p, size_t ring_bytes, size_t *ring_bytes_out, size_t *offsets, int64_t *wait_for) {
     if (!p || !offsets || !wait_for) return lgc_fail(LGC_EINVAL, "null argument");
@@ -233,6 +248,9 @@ extern "C" int lgc_program_info_get(const lgc_program *p, lgc_program_info *info
     info->replicas = P.replicas;
     info->word_stride = P.word_stride;
     info->reveal_stride = P.reveal_stride;
+    info->shared_end = P.shared_end;
+    info->prefix_launches = P.prefix_launches;
+    info->prefix_steps = P.prefix_steps;
     return LGC_OK;
 }
 static_assert(sizeof(lgc_record) == sizeof(Rec), "record layout");
@@ -276,9 +294,10 @@ struct lgc_solver {
     std::vector<hipEvent_t> ev_iter;     // end of each cgd iteration on the evaluator chain
     std::vector<double> t_iter;
     bool have_shares, ran;
+    bool prefix_ready;    // sweep: input labels and prefix tables are in place (garbled here or imported)
     lgc_stats st;
     lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), streamE(0), streamT(0), ev0(0), ev1(0), ev_in(0), ring_bytes(0),
-                   have_shares(false), ran(false) { memset(&st, 0, sizeof(st)); }
+                   have_shares(false), ran(false), prefix_ready(false) { memset(&st, 0, sizeof(st)); }
 };
 
 extern "C" void lgc_solver_destroy(lgc_solver *s) {
@@ -306,21 +325,23 @@ extern "C" void lgc_solver_destroy(lgc_solver *s) {
 }
 
 static int solver_create(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16], size_t count,
-                         const double *lambdas);
+                         const double *lambdas, size_t first);
 extern "C" int lgc_solver_create(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16]) {
-    return solver_create(out, device, sys, seed, 1, 0);
+    return solver_create(out, device, sys, seed, 1, 0, 0);
+}
+extern "C" int lgc_solver_create_sweep_at(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16],
+                                          size_t count, const double *lambdas, size_t first) {
+    int rc = check_sweep(sys, count, lambdas);
+    if (rc) return rc;
+    return solver_create(out, device, sys, seed, count, lambdas, first);
 }
 extern "C" int lgc_solver_create_sweep(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16],
                                        size_t count, const double *lambdas) {
-    if (!lambdas) return lgc_fail(LGC_EINVAL, "null lambdas");
-    if (count < 1 || count > 4096) return lgc_fail(LGC_EINVAL, "count must be in 1..4096");
-    if (sys && (!sys->normalize || sys->trace || sys->reveal_inputs))
-        return lgc_fail(LGC_EINVAL, "a sweep needs normalize = 1 (lambda enters there), trace = 0, reveal_inputs = 0");
-    return solver_create(out, device, sys, seed, count, lambdas);
+    return lgc_solver_create_sweep_at(out, device, sys, seed, count, lambdas, 0);
 }
 extern "C" size_t lgc_solver_num_circuits(const lgc_solver *s) { return s ? s->P.replicas : 0; }
 static int solver_create(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16], size_t count,
-                         const double *lambdas) {
+                         const double *lambdas, size_t first) {
     int rc = check_system(sys);
     if (rc) return rc;
     if (!out || !seed) return lgc_fail(LGC_EINVAL, "null argument");
@@ -332,15 +353,8 @@ static int solver_create(lgc_solver **out, int device, const lgc_system *sys, co
     s->sys = *sys;
     s->device = device;
     if (lambdas) {
-        Program base;
-        build(base, sys);
-        if ((uint64_t)base.n_words * count >= (1ull << 31)) {
-            delete s;
-            return lgc_fail(LGC_EINVAL, "sweep too large: %zu circuits x %u words", count, base.n_words);
-        }
-        std::vector<uint64_t> lf(count);
-        for (size_t t = 0; t < count; t++) lf[t] = lambda_to_fixed(lambdas[t], sys->precision, sys->width);
-        replicate_program(s->P, base, count, lf.data());
+        rc = build_sweep(s->P, sys, count, lambdas, first);
+        if (rc) { delete s; return rc; }
     } else {
         build(s->P, sys);
     }
@@ -428,14 +442,18 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
     }
     size_t next_iter = 0;
     HIPCHK(hipEventRecord(s->ev0, sG));
-    HIPCHK(hipMemsetAsync(s->wordsG, 0, wbytes, sG));
-    HIPCHK(hipMemsetAsync(s->wordsE, 0, wbytes, sG));
+    // sweep block whose shared prefix is already in place (lgc_solver_prefix_garble / _import): the words of
+    // the shared region and the prefix tables stay; only the evaluator runs the prefix launches
+    const bool pre = s->prefix_ready && P.prefix_launches > 0;
+    const size_t keep = pre ? (size_t)P.shared_end * 64 * sizeof(Lbl) : 0;
+    HIPCHK(hipMemsetAsync(reinterpret_cast<char *>(s->wordsG) + keep, 0, wbytes - keep, sG));
+    HIPCHK(hipMemsetAsync(reinterpret_cast<char *>(s->wordsE) + keep, 0, wbytes - keep, sG));
     HIPCHK(hipMemsetAsync(s->decG, 0, (P.n_reveal + 1) * sizeof(uint64_t), sG));
     HIPCHK(hipMemsetAsync(s->decE, 0, (P.n_reveal + 1) * sizeof(uint64_t), sG));
-    for (uint32_t t = 0; t < P.replicas; t++) {   // every circuit of a sweep gets its own labels for the same shares
+    if (!pre) {   // fresh input labels (one set for all circuits of a sweep: they share the prefix)
         dim3 grid((unsigned)((nin + 3) / 4)), block(256);
-        hipLaunchKernelGGL(gc_input_kernel, grid, block, 0, sG, s->wordsG, s->wordsE, s->vals,
-                           P.in_base + t * P.word_stride, (uint32_t)nin, s->R, s->seed, P.w);
+        hipLaunchKernelGGL(gc_input_kernel, grid, block, 0, sG, s->wordsG, s->wordsE, s->vals, P.in_base, (uint32_t)nin, s->R, s->seed, P.w);
+        HIPCHK(hipGetLastError());
     }
     if (!profile) {   // the evaluator chain starts after the input labels are in place
         HIPCHK(hipEventRecord(s->ev_in, sG));
@@ -454,7 +472,10 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
             HIPCHK(hipStreamWaitEvent(sG, s->evE[i - 1], 0));
 #endif
         if (timed) HIPCHK(hipEventRecord(s->evs[3 * i], sG));
-        if (profile || !gc_launch_is_crit(L)) {
+        if (pre && i < P.prefix_launches) {          // tables already in the ring
+            if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
+            if (!profile) HIPCHK(hipEventRecord(s->evG[i], sG));
+        } else if (profile || !gc_launch_is_crit(L)) {
             HIPCHK(gc_launch<true>(s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
             if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
             if (!profile) HIPCHK(hipEventRecord(s->evG[i], sG));
@@ -524,6 +545,69 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
         s->t_iter[t] = e * 1e-3;
     }
     s->ran = true;
+    s->prefix_ready = false;      // the ring regions of the prefix tables have been reused since
+    return LGC_OK;
+}
+
+// ---- shared prefix of a sweep block (multi-GPU sweep: garbled on one rank, broadcast to the others)
+extern "C" size_t lgc_solver_prefix_bytes(const lgc_solver *s) {
+    if (!s) return 0;
+    size_t b = 2 * (size_t)s->P.shared_end * 64 * sizeof(Lbl);
+    for (uint32_t i = 0; i < s->P.prefix_launches; i++) b += (size_t)s->P.launches[i].steps * 128 * sizeof(Lbl);
+    return b;
+}
+extern "C" int lgc_solver_prefix_garble(lgc_solver *s) {
+    if (!s) return lgc_fail(LGC_EINVAL, "null solver");
+    if (!s->have_shares) return lgc_fail(LGC_ESTATE, "lgc_solver_set_shares has not been called");
+    if (!s->P.prefix_launches) return lgc_fail(LGC_ESTATE, "not a sweep solver: there is no shared prefix");
+    HIPCHK(hipSetDevice(s->device));
+    const Program &P = s->P;
+    const size_t sbytes = (size_t)P.shared_end * 64 * sizeof(Lbl), nin = P.nshares * (P.T + P.d);
+    HIPCHK(hipMemsetAsync(s->wordsG, 0, sbytes, s->stream));
+    HIPCHK(hipMemsetAsync(s->wordsE, 0, sbytes, s->stream));
+    hipLaunchKernelGGL(gc_input_kernel, dim3((unsigned)((nin + 3) / 4)), dim3(256), 0, s->stream, s->wordsG, s->wordsE, s->vals,
+                       P.in_base, (uint32_t)nin, s->R, s->seed, P.w);
+    HIPCHK(hipGetLastError());
+    for (uint32_t i = 0; i < P.prefix_launches; i++) {
+        Lbl *tab = reinterpret_cast<Lbl *>(reinterpret_cast<char *>(s->tab) + s->tab_off[i]);
+        HIPCHK(gc_launch<true>(s->recs, P.launches[i], s->wordsG, s->decG, tab, s->R, P.w, P.p, s->stream));
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->prefix_ready = true;
+    return LGC_OK;
+}
+static int prefix_copy(lgc_solver *s, char *buf, bool out) {
+    const Program &P = s->P;
+    const size_t sbytes = (size_t)P.shared_end * 64 * sizeof(Lbl);
+    auto cp = [&](void *mine, char *theirs, size_t n) {
+        return out ? hipMemcpyAsync(theirs, mine, n, hipMemcpyDeviceToDevice, s->stream)
+                   : hipMemcpyAsync(mine, theirs, n, hipMemcpyDeviceToDevice, s->stream);
+    };
+    HIPCHK(cp(s->wordsG, buf, sbytes));
+    HIPCHK(cp(s->wordsE, buf + sbytes, sbytes));
+    size_t off = 2 * sbytes;
+    for (uint32_t i = 0; i < P.prefix_launches; i++) {
+        size_t n = (size_t)P.launches[i].steps * 128 * sizeof(Lbl);
+        if (n) HIPCHK(cp(reinterpret_cast<char *>(s->tab) + s->tab_off[i], buf + off, n));
+        off += n;
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return LGC_OK;
+}
+extern "C" int lgc_solver_prefix_export(lgc_solver *s, void *dev_buf) {
+    if (!s || !dev_buf) return lgc_fail(LGC_EINVAL, "null argument");
+    if (!s->prefix_ready) return lgc_fail(LGC_ESTATE, "the prefix has not been garbled (lgc_solver_prefix_garble)");
+    HIPCHK(hipSetDevice(s->device));
+    return prefix_copy(s, static_cast<char *>(dev_buf), true);
+}
+extern "C" int lgc_solver_prefix_import(lgc_solver *s, const void *dev_buf) {
+    if (!s || !dev_buf) return lgc_fail(LGC_EINVAL, "null argument");
+    if (!s->P.prefix_launches) return lgc_fail(LGC_ESTATE, "not a sweep solver: there is no shared prefix");
+    HIPCHK(hipSetDevice(s->device));
+    int rc = prefix_copy(s, const_cast<char *>(static_cast<const char *>(dev_buf)), false);
+    if (rc) return rc;
+    s->prefix_ready = true;
+    s->have_shares = true;        // the evaluator's input labels came with the prefix
     return LGC_OK;
 }
 

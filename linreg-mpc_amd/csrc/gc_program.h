@@ -51,6 +51,11 @@ struct Program {
     // uses words x + t * word_stride (x != 0) and decode slots r + t * reveal_stride
     uint32_t replicas, word_stride, reveal_stride;
     uint32_t lam_rec;            // index of the OP_CONST record holding lambda, or ~0u
+    // shared prefix of a sweep (data-provider path): words [0, shared_end) -- the constant zero, the input
+    // words and the share sums -- and the launches [0, prefix_launches) that produce the sums are the same
+    // for every lambda (lambda enters after them, linear.oc:52-57): garbled once, shared by all circuits
+    uint32_t shared_end, prefix_launches;
+    uint64_t prefix_steps;
 
     // ---- builder state
     uint64_t cap_steps;          // split launches above this many steps
@@ -60,8 +65,8 @@ struct Program {
 
     Program() : w(64), p(56), d(0), T(0), nshares(0), n_words(1), n_reveal(0), in_base(0), rv_beta(0),
                 rv_trace(~0u), rv_ab(~0u), total_steps(0), total_gates(0), max_launch_steps(0),
-                replicas(1), word_stride(0), reveal_stride(0), lam_rec(~0u),
-                cap_steps(1ull << 23), step_cursor(0), open(false) {}
+                replicas(1), word_stride(0), reveal_stride(0), lam_rec(~0u), shared_end(1), prefix_launches(0),
+                prefix_steps(0), cap_steps(1ull << 23), step_cursor(0), open(false) {}
 
     uint32_t alloc(size_t n) { uint32_t r = n_words; n_words += (uint32_t)n; return r; }
     uint32_t alloc_reveal(size_t n) { uint32_t r = n_reveal; n_reveal += (uint32_t)n; return r; }
@@ -317,31 +322,39 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
     const uint32_t D = (uint32_t)d;
     // word 0 is the constant zero (the word file starts zeroed on both sides)
     P.in_base = P.alloc(nshares * (T + d));
+    const uint32_t S_first = normalize ? P.alloc(T + d) : 0;   // share sums (see below): directly after the inputs
     const uint32_t M = P.alloc(d * d);       // full symmetric storage, M[i*d+j] == M[j*d+i]
     const uint32_t bv = P.alloc(d);
     auto Mi = [&](size_t i, size_t j) { return M + (uint32_t)(i * d + j); };
     auto idx = [](size_t i, size_t j) { return (uint32_t)(i * (i + 1) / 2 + j); };
 
-    // ---- a[ij] = sum of shares (linear.oc:31-49 / :116-127)
+    // ---- a[ij] = sum of shares (linear.oc:31-49 / :116-127).  On the data-provider path the sums go to
+    // their own words S (right after the inputs): everything up to here does not depend on lambda, so a
+    // sweep garbles it once and every circuit of the sweep reads S (replicate_program)
+    const uint32_t S = S_first;
     P.new_launch();
     for (size_t i = 0; i < d; i++)
         for (size_t j = 0; j <= i; j++)
-            P.emit(Program::mk(OP_SUM, Mi(i, j), P.in_base + idx(i, j), 0, 0, (uint32_t)nshares, (int32_t)(T + d)));
+            P.emit(Program::mk(OP_SUM, normalize ? S + idx(i, j) : Mi(i, j), P.in_base + idx(i, j), 0, 0, (uint32_t)nshares,
+                               (int32_t)(T + d)));
     for (size_t i = 0; i < d; i++)
-        P.emit(Program::mk(OP_SUM, bv + (uint32_t)i, P.in_base + (uint32_t)(T + i), 0, 0, (uint32_t)nshares,
-                           (int32_t)(T + d)));
+        P.emit(Program::mk(OP_SUM, normalize ? S + (uint32_t)(T + i) : bv + (uint32_t)i, P.in_base + (uint32_t)(T + i), 0, 0,
+                           (uint32_t)nshares, (int32_t)(T + d)));
     P.new_launch();
     if (normalize) {
+        P.shared_end = S + (uint32_t)(T + d);
+        P.prefix_launches = (uint32_t)P.launches.size();
+        P.prefix_steps = P.total_steps;
         const uint32_t lam = P.alloc(1);
         P.lam_rec = (uint32_t)P.recs.size();
         P.emit(Program::mk(OP_CONST, lam, (uint32_t)lambda_fixed, (uint32_t)(lambda_fixed >> 32)));
         P.new_launch();
         for (size_t i = 0; i < d; i++)
             for (size_t j = 0; j <= i; j++) {
-                if (i == j) P.emit(Program::mk(OP_ADD, Mi(i, j), Mi(i, j), lam));
-                else P.emit(Program::mk(OP_IDIVC, Mi(i, j), Mi(i, j), 0, D));
+                if (i == j) P.emit(Program::mk(OP_ADD, Mi(i, j), S + idx(i, j), lam));
+                else P.emit(Program::mk(OP_IDIVC, Mi(i, j), S + idx(i, j), 0, D));
             }
-        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_IDIVC, bv + (uint32_t)i, bv + (uint32_t)i, 0, D));
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_IDIVC, bv + (uint32_t)i, S + (uint32_t)(T + i), 0, D));
         P.new_launch();
     }
     // mirror the lower triangle
@@ -506,29 +519,43 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
 }
 
 
-// `count` independent copies of the circuit `P0` in one program: the per-lambda sweep (SURVEY.md
-// 8(e); lambda is a public constant added to the diagonal, linear.oc:52-57).  All copies read the
-// same input shares (each through its own fresh input labels) and differ only in the OP_CONST
-// record that holds lambda.  The records of all copies of one launch of P0 share launches, so the
-// dependent chains (dividers, reveals) of different circuits fill the GPU together.
-inline void replicate_program(Program &P, const Program &P0, size_t count, const uint64_t *lambda_fixed) {
+// `count` circuits of the per-lambda sweep in one program.  lambda is a public constant
+// added to the diagonal AFTER the shares are summed (linear.oc:52-57), so the input labels and the garbled
+// share summation -- P0's shared prefix -- exist once and every circuit starts from the same sums: the
+// data providers run ONE label OT whatever the number of lambdas.  Circuit t uses words x + t * word_stride
+// for x >= shared_end and decode slots r + t * reveal_stride, and differs only in the OP_CONST record that
+// holds lambda.  The records of all circuits of one launch of P0 share a launch, so the dependent chains
+// (dividers, reveals) of different circuits fill the GPU together.
+// first_copy: index of this program's first circuit in the whole sweep.  Ranks of a multi-GPU sweep share
+// the prefix -- hence the garbler's offset R -- so their gate ids must not collide: circuit k of the sweep
+// owns the gate steps [prefix + k * per_circuit, prefix + (k + 1) * per_circuit) on whichever rank it runs.
+inline void replicate_program(Program &P, const Program &P0, size_t count, const uint64_t *lambda_fixed, size_t first_copy = 0) {
     P.w = P0.w; P.p = P0.p; P.d = P0.d; P.T = P0.T; P.nshares = P0.nshares;
     P.cap_steps = P0.cap_steps;
-    P.word_stride = P0.n_words - 1;             // word 0 (constant zero) is shared
+    P.shared_end = P0.shared_end;
+    P.word_stride = P0.n_words - P0.shared_end;
     P.reveal_stride = P0.n_reveal;
     P.replicas = (uint32_t)count;
-    P.n_words = 1 + (uint32_t)count * P.word_stride;
+    P.n_words = P0.shared_end + (uint32_t)count * P.word_stride;
     P.n_reveal = (uint32_t)count * P.reveal_stride;
     P.in_base = P0.in_base; P.rv_beta = P0.rv_beta; P.rv_trace = P0.rv_trace; P.rv_ab = P0.rv_ab;
     P.lam_rec = ~0u;
     size_t next_iter = 0;
+    const uint32_t shared_end = P0.shared_end;
     for (size_t li = 0; li < P0.launches.size(); li++) {
         const Launch &L = P0.launches[li];
-        for (size_t t = 0; t < count; t++) {
+        const bool prefix = li < P0.prefix_launches;
+        if (li == P0.prefix_launches) {
+            P.new_launch();
+            P.prefix_launches = (uint32_t)P.launches.size();
+            P.prefix_steps = P.total_steps;
+            P.step_cursor = P0.prefix_steps + (uint64_t)first_copy * (P0.total_steps - P0.prefix_steps);
+        }
+        for (size_t t = 0; t < (prefix ? 1 : count); t++) {
             const uint32_t wo = (uint32_t)t * P.word_stride, ro = (uint32_t)t * P.reveal_stride;
             for (uint32_t k = 0; k < L.nrec; k++) {
                 Rec r = P0.recs[L.first_rec + k];
-                auto mv = [wo](uint32_t x) { return x ? x + wo : 0u; };
+                auto mv = [wo, shared_end](uint32_t x) { return x >= shared_end ? x + wo : x; };
                 switch (r.op) {
                 case OP_CONST:
                     r.dst = mv(r.dst);
@@ -536,6 +563,12 @@ inline void replicate_program(Program &P, const Program &P0, size_t count, const
                     break;
                 case OP_IDIVC: r.dst = mv(r.dst); r.a = mv(r.a); break;          // c is an immediate
                 case OP_REVEAL: r.dst += ro; r.a = mv(r.a); break;               // dst is a decode slot
+                case OP_MAX: {
+                    // max_tree folds in the constant zero as the SECOND operand through a stride of -a
+                    const bool to_zero = r.cnt == 2 && r.sa == -(int32_t)r.a;
+                    r.dst = mv(r.dst); r.a = mv(r.a);
+                    if (to_zero) r.sa = -(int32_t)r.a;
+                } break;
                 default: r.dst = mv(r.dst); r.a = mv(r.a); r.b = mv(r.b); r.c = mv(r.c); break;
                 }
                 P.emit(r);

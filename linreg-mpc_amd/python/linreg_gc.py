@@ -53,7 +53,8 @@ class ProgramInfo(C.Structure):
                 ("n_reveal", C.c_uint32), ("in_base", C.c_uint32), ("rv_beta", C.c_uint32),
                 ("rv_trace", C.c_uint32), ("rv_inputs", C.c_uint32), ("total_steps", C.c_uint64),
                 ("total_gates", C.c_uint64), ("max_launch_steps", C.c_uint64),
-                ("replicas", C.c_uint32), ("word_stride", C.c_uint32), ("reveal_stride", C.c_uint32)]
+                ("replicas", C.c_uint32), ("word_stride", C.c_uint32), ("reveal_stride", C.c_uint32),
+                ("shared_end", C.c_uint32), ("prefix_launches", C.c_uint32), ("prefix_steps", C.c_uint64)]
 
 
 _lib = None
@@ -65,6 +66,8 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "or `make -C linreg-mpc_amd/csrc`)" % LIB_PATH)
+        # A process that also uses torch on the GPU must import torch BEFORE this library is loaded: torch ships
+        # its own libamdhip64 under the same SONAME and whichever loads first serves both (bench.py, tests/conftest.py)
         L = C.CDLL(LIB_PATH)
         vp, ci, sz = C.c_void_p, C.c_int, C.c_size_t
         L.lgc_last_error.restype = C.c_char_p
@@ -79,7 +82,10 @@ def lib():
             ("lgc_party_iteration_marks", [vp, vp, vp, sz]),
             ("lgc_program_build", [C.POINTER(vp), C.POINTER(System)]),
             ("lgc_program_build_sweep", [C.POINTER(vp), C.POINTER(System), sz, vp]),
+            ("lgc_program_build_sweep_at", [C.POINTER(vp), C.POINTER(System), sz, vp, sz]),
             ("lgc_solver_create_sweep", [C.POINTER(vp), ci, C.POINTER(System), C.c_char_p, sz, vp]),
+            ("lgc_solver_create_sweep_at", [C.POINTER(vp), ci, C.POINTER(System), C.c_char_p, sz, vp, sz]),
+            ("lgc_solver_prefix_garble", [vp]), ("lgc_solver_prefix_export", [vp, vp]), ("lgc_solver_prefix_import", [vp, vp]),
             ("lgc_program_info_get", [vp, C.POINTER(ProgramInfo)]),
             ("lgc_program_ring_plan", [vp, sz, C.POINTER(sz), vp, vp]),
             ("lgc_aes_bench", [ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
@@ -105,6 +111,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = ci, args
         L.lgc_solver_destroy.argtypes = [vp]; L.lgc_solver_destroy.restype = None
+        L.lgc_solver_prefix_bytes.argtypes = [vp]; L.lgc_solver_prefix_bytes.restype = sz
         L.lgc_program_destroy.argtypes = [vp]; L.lgc_program_destroy.restype = None
         L.lgc_p1_destroy.argtypes = [vp]; L.lgc_p1_destroy.restype = None
         L.lgc_party_destroy.argtypes = [vp]; L.lgc_party_destroy.restype = None
@@ -139,13 +146,13 @@ def make_system(d, width=64, precision=56, algorithm="cgd", num_iterations=0, la
 class Program:
     """The lowered circuit program (host only; needs no GPU)."""
 
-    def __init__(self, system, lambdas=None):
+    def __init__(self, system, lambdas=None, first=0):
         self._h = C.c_void_p()
         if lambdas is None:
             _chk(lib().lgc_program_build(C.byref(self._h), C.byref(system)))
         else:                                    # per-lambda sweep: len(lambdas) circuits in one program
-            lam = np.ascontiguousarray(lambdas, dtype=np.float64)
-            _chk(lib().lgc_program_build_sweep(C.byref(self._h), C.byref(system), lam.size, lam.ctypes.data_as(C.c_void_p)))
+            lam = np.ascontiguousarray(lambdas, dtype=np.float64)   # (circuits first .. of a larger sweep)
+            _chk(lib().lgc_program_build_sweep_at(C.byref(self._h), C.byref(system), lam.size, lam.ctypes.data_as(C.c_void_p), first))
         self.info = ProgramInfo()
         _chk(lib().lgc_program_info_get(self._h, C.byref(self.info)))
         self.system = system
@@ -182,9 +189,10 @@ class Solver:
 
     Replaces `execYaoProtocol(pd, solver, &ls)` (reference src/cmd/linreg.c:177)."""
 
-    def __init__(self, system, seed=b"\x01" * 16, device=0, lambdas=None):
+    def __init__(self, system, seed=b"\x01" * 16, device=0, lambdas=None, first=0):
         """lambdas: per-lambda sweep -- len(lambdas) circuits on the same shares in one program
-        (lgc_solver_create_sweep); beta() then returns (len(lambdas), d)."""
+        (lgc_solver_create_sweep); beta() then returns (len(lambdas), d).  first: index of lambdas[0]
+        in a sweep sharded over several GPUs (lgc_solver_create_sweep_at; all ranks share the seed)."""
         assert len(seed) == 16
         self._h = C.c_void_p()
         self.system = system
@@ -194,8 +202,22 @@ class Solver:
         else:
             lam = np.ascontiguousarray(lambdas, dtype=np.float64)
             self.count = int(lam.size)
-            _chk(lib().lgc_solver_create_sweep(C.byref(self._h), device, C.byref(system), seed, lam.size,
-                                               lam.ctypes.data_as(C.c_void_p)))
+            _chk(lib().lgc_solver_create_sweep_at(C.byref(self._h), device, C.byref(system), seed, lam.size,
+                                                  lam.ctypes.data_as(C.c_void_p), first))
+
+    # ---- shared prefix of a sweep block (input labels + garbled share summation): garbled on one rank,
+    # broadcast, imported by every rank.  dev_ptr: device memory of prefix_bytes() bytes (e.g. tensor.data_ptr())
+    def prefix_bytes(self):
+        return int(lib().lgc_solver_prefix_bytes(self._h))
+
+    def prefix_garble(self):
+        _chk(lib().lgc_solver_prefix_garble(self._h))
+
+    def prefix_export(self, dev_ptr):
+        _chk(lib().lgc_solver_prefix_export(self._h, C.c_void_p(dev_ptr)))
+
+    def prefix_import(self, dev_ptr):
+        _chk(lib().lgc_solver_prefix_import(self._h, C.c_void_p(dev_ptr)))
 
     def set_shares(self, shares):
         d = self.system.d

@@ -1,10 +1,14 @@
-"""Sharding of independent circuits over the GPUs of one node.
+"""Sharding of the per-lambda sweep over the GPUs of one node.
 
-A single solve is one dependent chain and stays on one GPU.  Independent circuits -- one per
-regularisation value lambda (lambda is a public constant added to the diagonal, reference
-src/linear.oc:52-57) or per bootstrap resample -- are dealt to ranks in contiguous blocks; there is
-no data-path collective: the only communication is the final gather of the revealed d-word results.
-One process per GPU (torch.distributed; backend "nccl" = RCCL on GPUs, "gloo" in the CPU tests).
+A single solve is one dependent chain and stays on one GPU.  The circuits of a regularisation sweep
+differ only in lambda, a public constant added to the diagonal AFTER the data providers' shares are
+summed (reference src/linear.oc:52-57), so they share a prefix: the input wire labels and the
+garbled share-summation launches.  shared_prefix_sweep garbles that prefix ONCE, on rank 0,
+broadcasts it (RCCL over xGMI: input-label words + prefix tables), and every rank then garbles and
+evaluates its contiguous block of lambdas as one merged program; an all_gather collects the d-word
+results.  One process per GPU (torch.distributed; backend "nccl" = RCCL on GPUs, "gloo" in the CPU
+tests and single-GPU dry runs).  lambda_sweep is the collective-free variant (independent circuits,
+e.g. bootstrap resamples): only the final gather communicates.
 """
 import numpy as np
 
@@ -56,6 +60,91 @@ def lambda_sweep(shares, lambdas, d, solve, dist=None, tensor_device="cpu"):
     buf = torch.from_numpy(mine).to(tensor_device)
     outs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf)
+    res = np.zeros((len(lambdas), d), dtype=np.int64)
+    for r in range(world):
+        rlo, rhi = partition(len(lambdas), world, r)
+        res[rlo:rhi] = outs[r].cpu().numpy()[:rhi - rlo]
+    return res
+
+
+def _bcast_bytes(buf, dist, src=0):
+    """broadcast a uint8 tensor in place; device tensors go over RCCL, or through the host when the
+    process group is gloo (CPU tests, N ranks sharing one GPU)"""
+    if dist is None:
+        return
+    if buf.is_cuda and dist.get_backend() != "nccl":
+        host = buf.cpu()
+        dist.broadcast(host, src=src)
+        buf.copy_(host)
+    else:
+        dist.broadcast(buf, src=src)
+
+
+def gpu_block_solver_factory(d, width, precision, algorithm, num_iterations, nshares, device):
+    """make_solver for shared_prefix_sweep: this rank's block on its GPU through the C ABI
+    (lgc_solver_create_sweep_at: same seed on all ranks, gate ids offset by the block's first circuit)"""
+    import linreg_gc as lgc
+
+    def make(block, first, seed):
+        sysm = lgc.make_system(d, width, precision, algorithm, num_iterations, 0.0, nshares, 1, 0, 0)
+        return lgc.Solver(sysm, seed=seed, device=device, lambdas=block, first=first)
+    return make
+
+
+def shared_prefix_sweep(shares, lambdas, d, make_solver, dist=None, tensor_device="cpu", seed=None, stats=None):
+    """One circuit per lambda with the lambda-independent prefix garbled once.
+
+    shares: (nshares, T + d) uint64, needed on rank 0 only (the other ranks receive the garbled
+    prefix, not the inputs).  make_solver(block_of_lambdas, first_index, seed16) returns an object with
+    set_shares / prefix_bytes / prefix_garble / prefix_export(ptr) / prefix_import(ptr) / run / beta /
+    close (linreg_gc.Solver).  Returns the (len(lambdas), d) int64 results on every rank."""
+    import os
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    lo, hi = partition(len(lambdas), world, rank)
+    # one garbler seed for the whole sweep: the ranks share the prefix, hence R and the input labels
+    sd = torch.tensor(list(seed if seed is not None else os.urandom(16)), dtype=torch.uint8)
+    if dist is not None:
+        if dist.get_backend() == "nccl":
+            sd = sd.to(tensor_device)
+        dist.broadcast(sd, src=0)
+    seed16 = bytes(sd.cpu().tolist())
+    solver = make_solver(list(lambdas[lo:hi]), lo, seed16) if hi > lo else None
+    nb = torch.tensor([solver.prefix_bytes() if rank == 0 else 0], dtype=torch.int64)
+    if dist is not None:
+        if dist.get_backend() == "nccl":
+            nb = nb.to(tensor_device)
+        dist.broadcast(nb, src=0)
+    nbytes = int(nb.item())
+    if rank == 0:
+        solver.set_shares(shares)
+        solver.prefix_garble()
+    if world > 1:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=tensor_device)
+        if rank == 0:
+            solver.prefix_export(buf.data_ptr())
+        _bcast_bytes(buf, dist)
+        if solver is not None and rank != 0:
+            solver.prefix_import(buf.data_ptr())
+        del buf
+    per = (len(lambdas) + world - 1) // world
+    mine = np.zeros((per, d), dtype=np.int64)
+    if solver is not None:
+        solver.run()
+        mine[:hi - lo] = solver.beta()
+        if stats is not None:
+            stats.update(solver.stats())
+        solver.close()
+    if stats is not None:
+        stats["prefix_bytes"] = nbytes
+    if dist is None:
+        return mine[:hi - lo]
+    out = torch.from_numpy(mine)
+    if dist.get_backend() == "nccl":
+        out = out.to(tensor_device)
+    outs = [torch.empty_like(out) for _ in range(world)]
+    dist.all_gather(outs, out)
     res = np.zeros((len(lambdas), d), dtype=np.int64)
     for r in range(world):
         rlo, rhi = partition(len(lambdas), world, r)

@@ -11,6 +11,11 @@ import sys
 
 import pytest
 
+try:                   # before anything loads liblinreg_gc.so: one HIP runtime per process (torch ships its own
+    import torch       # libamdhip64 under the same SONAME; whichever loads first serves both), as bench.py does
+except ImportError:    # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

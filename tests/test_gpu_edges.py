@@ -59,10 +59,11 @@ def test_extreme_precisions_cgd(lgc, oracle, w, p):
     _check(lgc, oracle, A, b, d, w, p, "cgd", 3, 2, 0, 0.0, rng)
 
 
-@pytest.mark.parametrize("w,p", [(64, 60), (64, 2), (32, 31), (32, 30), (32, 3)])
+@pytest.mark.parametrize("w,p", [(64, 63), (64, 62), (64, 61), (64, 60), (64, 2), (32, 31), (32, 30), (32, 3)])
 def test_extreme_precisions_cholesky_ldlt(lgc, oracle, w, p):
     """square root with odd and even datapath widths (the 32-bit loop of fixed.oc:228-240 at odd
-    32+p, the 64-bit shifting form at its widest supported width), garbage operands included"""
+    32+p, the 64-bit non-restoring form at its widest single-word width (p = 60) and the two-word
+    remainder for precision 61..63, all allowed by src/cmd/linreg.c:85-88), garbage operands included"""
     rng = np.random.default_rng(100 + w + p)
     d = 3
     T = d * (d + 1) // 2
@@ -87,9 +88,7 @@ def test_extreme_operand_values(lgc, oracle):
 
 def test_rejects_unsupported_parameters(lgc):
     with pytest.raises(lgc.LgcError):
-        lgc.Solver(lgc.make_system(3, width=64, precision=61, algorithm="cholesky"))
-    with pytest.raises(lgc.LgcError):
-        lgc.Solver(lgc.make_system(3, width=64, precision=64))
+        lgc.Solver(lgc.make_system(3, width=64, precision=64))      # p < width (src/cmd/linreg.c:85-88)
     with pytest.raises(lgc.LgcError):
         lgc.Solver(lgc.make_system(0))
     s = lgc.Solver(lgc.make_system(2, algorithm="cgd", num_iterations=1))

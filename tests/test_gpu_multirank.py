@@ -1,0 +1,80 @@
+"""N > 1 on the GPU box: the driver only has one GPU per gpurun box, so two ranks share it (gloo
+process group, LGC_BENCH_BACKEND=gloo); the data path is the one an 8-GPU node runs -- same seed on
+all ranks, prefix garbled on rank 0, broadcast, imported, disjoint gate ids, all_gather.  The
+hipIpc table ring across two devices runs only where two GPUs are visible."""
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import oracle_solve
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path, oracle):
+    env = dict(os.environ, LGC_BENCH_BACKEND="gloo", LGC_BENCH_DUMP=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--dimension", "24", "--iters", "2", "--sweep-d", "6", "--sweep-iters", "3", "--sweep-lambdas", "5",
+           "--no-cpu-baseline", "--no-traffic", "--no-e2e"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["barrier_backend"] == "gloo"
+    sw = out["sweep64"]
+    assert sw["n_gpus"] == 2 and sw["lambdas"] == 5 and sw["prefix_bytes_broadcast"] > 0 and "broadcast" in sw["collectives"]
+    dumps = [json.load(open(os.path.join(str(tmp_path), "sweep_rank%d.json" % k))) for k in (0, 1)]
+    assert dumps[0]["beta"] == dumps[1]["beta"]                      # every rank holds the gathered results
+    d0 = dumps[0]
+    d, w, p, iters = d0["d"], d0["width"], d0["precision"], d0["iters"]
+    sh = np.array(d0["shares"], dtype=np.uint64)
+    tot = sh.sum(axis=0, dtype=np.uint64)
+    T = d * (d + 1) // 2
+    for k, lam in enumerate(d0["lambdas"]):                          # rank 0 ran 0..2, rank 1 ran 3..4 from the broadcast prefix
+        exp, _, _ = oracle_solve(oracle, tot[:T], tot[T:], d, w, p, "cgd", iters, lam, 1)
+        assert [int(v) for v in exp] == d0["beta"][k], (k, lam)
+
+
+def test_table_ring_across_two_gpus(tmp_path, oracle, lgc):
+    """CSP on GPU 0, Evaluator on GPU 1, garbled tables through the hipIpc ring (xGMI peer access)"""
+    if lgc.device_count() < 2:
+        pytest.skip("needs two visible GPUs (the driver's multi-GPU node; one-GPU boxes skip)")
+    from test_host import HOST, _free_ports
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(23)
+    d, iters, w, p = 6, 4, 64, 56
+    X = rng.standard_normal((60, d)); X /= np.abs(X).max(axis=0)
+    A = X.T @ X / (60 * d) + np.eye(d) * 1e-2
+    b = A @ rng.random(d)
+    path = str(tmp_path / "ls.in")
+    with open(path, "w") as f:
+        f.write("%d %d\n" % (d, d))
+        np.savetxt(f, A, fmt="%.17g")
+        f.write("%d\n" % d)
+        np.savetxt(f, b[None, :], fmt="%.17g")
+        f.write("%d\n" % d)
+        np.savetxt(f, np.zeros((1, d)), fmt="%g")
+    port = _free_ports(1)[0]
+    exe = os.path.join(HOST, "bin", "test_linear_system")
+    procs = [subprocess.Popen([exe, str(port), str(k), path, "cgd", str(iters), str(p), "--host=127.0.0.1", "--table_ring=4"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, LINREG_DEVICE=str(k - 1)))
+             for k in (1, 2)]
+    outs = [q.communicate(timeout=300) for q in procs]
+    for q, (o, e) in zip(procs, outs):
+        assert q.returncode == 0, e.decode()[-1000:]
+    got = re.findall("-?[0-9]+\\.[0-9]+", outs[1][0].decode().strip().splitlines()[-1])
+    aq = np.array([oracle.lib.orc_double_to_fixed(float(A[i, j]), p, w) for i in range(d) for j in range(i + 1)], dtype=np.int64)
+    bq = np.array([oracle.lib.orc_double_to_fixed(float(v), p, w) for v in b], dtype=np.int64)
+    assert got == ["%.15f" % (int(v) / 2.0 ** p) for v in oracle.cgd(aq, bq, d, p, w, iters)]

@@ -18,6 +18,10 @@ def test_aes_known_answer(gccpu):
     assert np.array_equal(gccpu.aes(rnd), gccpu.aes(rnd, ttable=True))
 
 
+REC = np.dtype([("op", "<u4"), ("cnt", "<u4"), ("dst", "<u4"), ("a", "<u4"), ("b", "<u4"), ("c", "<u4"),
+                ("sa", "<i4"), ("sb", "<i4"), ("step0", "<u8")])
+
+
 def _plain(lgc, gccpu, sysm, shares):
     prog = lgc.Program(sysm)
     info = prog.info
@@ -116,16 +120,20 @@ def test_sweep_program_matches_oracle_per_lambda(lgc, gccpu, oracle, w, p, alg):
     base = lgc.Program(lgc.make_system(d, w, p, alg, iters, lams[0], nsh, 1, 0, 0))
     prog = lgc.Program(sysm, lambdas=lams)
     info = prog.info
-    assert info.replicas == len(lams) and info.word_stride == base.info.n_words - 1
+    # shared prefix: the constant zero, the input words and the share sums exist once (lambda enters
+    # after the summation, linear.oc:52-57); everything else is per circuit
+    T = d * (d + 1) // 2
+    se = info.shared_end
+    assert se == base.info.shared_end == 1 + (nsh + 1) * (T + d) and info.prefix_launches == base.info.prefix_launches == 1
+    assert info.replicas == len(lams) and info.word_stride == base.info.n_words - se
     assert info.reveal_stride == base.info.n_reveal and info.n_reveal == len(lams) * base.info.n_reveal
-    assert info.n_words == 1 + len(lams) * (base.info.n_words - 1)
-    assert info.total_gates == len(lams) * base.info.total_gates
+    assert info.n_words == se + len(lams) * (base.info.n_words - se)
+    pre_gates = sum(l["gates"] for l in base.launches()[:base.info.prefix_launches])
+    assert info.total_gates == pre_gates + len(lams) * (base.info.total_gates - pre_gates)
     assert info.n_launches == base.info.n_launches                          # launches are merged, not appended
     words = np.zeros(info.n_words, dtype=np.uint64)
     m = np.uint64((1 << w) - 1)
-    for t in range(len(lams)):
-        lo = info.in_base + t * info.word_stride
-        words[lo:lo + shares.size] = shares.ravel() & m
+    words[info.in_base:info.in_base + shares.size] = shares.ravel() & m      # ONE set of input words
     dec = np.zeros(info.n_reveal + 1, dtype=np.uint64)
     steps, gates = gccpu.plain_run(prog.records(), info.n_records, w, p, words, dec)
     assert steps == info.total_steps and gates == info.total_gates
@@ -133,6 +141,32 @@ def test_sweep_program_matches_oracle_per_lambda(lgc, gccpu, oracle, w, p, alg):
         exp = oracle_solve(oracle, A, b, d, w, p, alg, iters, lam, 1)[0]
         lo = info.rv_beta + t * info.reveal_stride
         assert sx(dec[lo:lo + d], w).tolist() == exp.tolist(), (t, lam)
+    # blocks of a sharded sweep: same records, gate steps offset so that no two circuits of the whole sweep
+    # share a gate id (the ranks share the prefix and with it the garbler's offset R)
+    per = base.info.total_steps - base.info.prefix_steps
+    seen = []
+    for first, cnt in ((0, 2), (2, 3)):
+        blk = lgc.Program(sysm, lambdas=lams[first:first + cnt], first=first)
+        L = blk.launches()
+        npre = blk.info.prefix_launches
+        assert [(l["step0"], l["steps"]) for l in L[:npre]] == [(l["step0"], l["steps"]) for l in prog.launches()[:npre]]
+        lo = min(l["step0"] for l in L[npre:] if l["steps"]); hi = max(l["step0"] + l["steps"] for l in L[npre:])
+        assert lo == base.info.prefix_steps + first * per and hi == base.info.prefix_steps + (first + cnt) * per
+        seen.append((lo, hi))
+        words = np.zeros(blk.info.n_words, dtype=np.uint64)
+        words[blk.info.in_base:blk.info.in_base + shares.size] = shares.ravel() & m
+        dec = np.zeros(blk.info.n_reveal + 1, dtype=np.uint64)
+        recs = np.frombuffer(blk.records().tobytes(), dtype=REC)
+        # plain_run checks step0 against a running counter from 0: renumber the copy for the check
+        recs = recs.copy()
+        shift = recs["step0"] >= base.info.prefix_steps
+        recs["step0"][shift] -= np.uint64(first * per)
+        gccpu.plain_run(recs.view(np.uint8), blk.info.n_records, w, p, words, dec)
+        for t in range(cnt):
+            exp = oracle_solve(oracle, A, b, d, w, p, alg, iters, lams[first + t], 1)[0]
+            lo_r = blk.info.rv_beta + t * blk.info.reveal_stride
+            assert sx(dec[lo_r:lo_r + d], w).tolist() == exp.tolist(), (first, t)
+    assert seen[0][1] <= seen[1][0]
     with pytest.raises(RuntimeError):                                       # lambda only enters the DP input path
         lgc.Program(lgc.make_system(d, w, p, alg, iters, 0.0, 2, 0, 0, 0), lambdas=lams)
 
