@@ -189,6 +189,13 @@ int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[16], const u
 typedef struct lgc_party lgc_party;
 int lgc_party_create(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
                      size_t max_launch_table_bytes);
+/* The per-lambda sweep with the roles apart (see lgc_solver_create_sweep): ONE set of input labels and
+ * one garbled share summation for all `count` circuits, so every data provider runs its label OT
+ * (lgc_ot_labels_*, src/input.c:37-50) once whatever the number of lambdas; lgc_party_finish then
+ * returns count x d words of beta (circuit-major).  Both sides pass the same count and lambdas. */
+int lgc_party_create_sweep(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
+                           size_t max_launch_table_bytes, size_t count, const double *lambdas);
+size_t lgc_party_num_circuits(const lgc_party *p);
 void lgc_party_destroy(lgc_party *p);
 size_t lgc_party_num_launches(const lgc_party *p);
 size_t lgc_party_table_bytes(const lgc_party *p, size_t launch);

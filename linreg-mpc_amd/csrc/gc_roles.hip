@@ -79,8 +79,21 @@ extern "C" void lgc_party_destroy(lgc_party *p) {
     delete p;
 }
 
+static int party_create(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
+                        size_t max_launch_table_bytes, size_t count, const double *lambdas);
 extern "C" int lgc_party_create(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
                                 size_t max_launch_table_bytes) {
+    return party_create(out, device, sys, role, seed, max_launch_table_bytes, 1, 0);
+}
+extern "C" int lgc_party_create_sweep(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
+                                      size_t max_launch_table_bytes, size_t count, const double *lambdas) {
+    int rc = check_sweep(sys, count, lambdas);
+    if (rc) return rc;
+    return party_create(out, device, sys, role, seed, max_launch_table_bytes, count, lambdas);
+}
+extern "C" size_t lgc_party_num_circuits(const lgc_party *p) { return p ? p->P.replicas : 0; }
+static int party_create(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
+                        size_t max_launch_table_bytes, size_t count, const double *lambdas) {
     int rc = check_system(sys);
     if (rc) return rc;
     if (!out) return lgc_fail(LGC_EINVAL, "null out");
@@ -95,7 +108,13 @@ extern "C" int lgc_party_create(lgc_party **out, int device, const lgc_system *s
     p->words = 0; p->tab = 0; p->dec = 0; p->recs = 0; p->labels_ready = false;
     p->ring = 0; p->ring_slots = 0; p->ring_slot_bytes = 0; p->ring_imported = false;
     if (!max_launch_table_bytes) max_launch_table_bytes = (size_t)256 << 20;
-    build(p->P, sys, max_launch_table_bytes / 2048 ? max_launch_table_bytes / 2048 : 1);
+    const uint64_t cap = max_launch_table_bytes / 2048 ? max_launch_table_bytes / 2048 : 1;
+    if (lambdas) {
+        rc = build_sweep(p->P, sys, count, lambdas, 0, cap);
+        if (rc) { delete p; return rc; }
+    } else {
+        build(p->P, sys, cap);
+    }
     memset(&p->R, 0, sizeof(Lbl)); memset(&p->seed, 0, sizeof(Lbl));
     if (role == LGC_ROLE_GARBLER) {
         memcpy(&p->seed, seed, 16);
@@ -301,7 +320,9 @@ extern "C" int lgc_party_finish(lgc_party *p, const uint64_t *garbler_dec, int64
         uint64_t v = p->hdec[slot] ^ garbler_dec[slot];
         return P.w == 32 ? (int64_t)(int32_t)(uint32_t)v : (int64_t)v;
     };
-    if (beta) for (size_t i = 0; i < P.d; i++) beta[i] = val(P.rv_beta + (uint32_t)i);
+    if (beta)
+        for (uint32_t t = 0; t < P.replicas; t++)
+            for (size_t i = 0; i < P.d; i++) beta[(size_t)t * P.d + i] = val(P.rv_beta + t * P.reveal_stride + (uint32_t)i);
     if (trace && P.rv_trace != ~0u)
         for (size_t i = 0; i < (size_t)p->sys.num_iterations * (P.d + 4); i++) trace[i] = val(P.rv_trace + (uint32_t)i);
     if (inputs && P.rv_ab != ~0u)

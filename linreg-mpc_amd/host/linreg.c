@@ -38,7 +38,9 @@ int main(int argc, char **argv) {
           "Options: --use_ot: Enables the OT-based phase 1 protocol\n"
           "         --prec_phase2=<Precision phase 2>: Use different precision for phase 2 of the protocol\n"
           "         --width_phase1=<32|64>, --width_phase2=<32|64>: bit widths (default 64)\n"
-          "         --table_ring[=slots]: parties 1 and 2 share one node; garbled tables stay in HBM", argv[0]);
+          "         --table_ring[=slots]: parties 1 and 2 share one node; garbled tables stay in HBM\n"
+          "         --lambdas=l1,l2,...: regularisation sweep -- one circuit per value on the same shares (the data\n"
+          "                  providers share their inputs once); [Lambda] is then ignored", argv[0]);
     char *end;
     errno = 0;
     int precision = (int)strtol(argv[2], &end, 10);
@@ -55,8 +57,22 @@ int main(int argc, char **argv) {
     check(!*end, "lambda must be a number");
 
     int use_ot = 0, precision_phase2 = -1, w1 = 64, w2 = 64, ring_slots = 0;
+    double *lambdas = NULL;                     /* --lambdas: the per-lambda sweep (lambda enters at linear.oc:52-57) */
+    size_t n_lambdas = 0;
     for (int i = 7; i < argc; i++) {
         if (!strcmp(argv[i], "--use_ot")) use_ot = 1;
+        else if (!strncmp(argv[i], "--lambdas=", 10)) {
+            const char *q = argv[i] + 10;
+            while (*q) {
+                char *e2;
+                double v = strtod(q, &e2);
+                check(e2 != q && (*e2 == ',' || !*e2), "--lambdas wants a comma-separated list of numbers");
+                lambdas = realloc(lambdas, (n_lambdas + 1) * sizeof *lambdas);
+                lambdas[n_lambdas++] = v;
+                q = *e2 ? e2 + 1 : e2;
+            }
+            check(n_lambdas > 0, "--lambdas wants at least one value");
+        }
         else if (!strcmp(argv[i], "--table_ring")) ring_slots = 8;
         else if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) {}
         else if (sscanf(argv[i], "--width_phase1=%i", &w1) == 1) {}
@@ -106,6 +122,7 @@ int main(int argc, char **argv) {
     sys.algorithm = !strcmp(algorithm, "cholesky") ? LGC_ALG_CHOLESKY : (!strcmp(algorithm, "ldlt") ? LGC_ALG_LDLT : LGC_ALG_CGD);
     sys.num_iterations = num_iterations; sys.lambda = lambda; sys.nshares = (size_t)P;
     sys.normalize = 1; sys.reveal_inputs = 1; sys.trace = 1;
+    if (n_lambdas) { sys.reveal_inputs = 0; sys.trace = 0; }       /* merged program of n_lambdas circuits: results only */
     /* table bytes per launch: socket mode moves them through host buffers; ring mode keeps them
      * in HBM (CSP and Evaluator on one node), so launches can be as large as the fused solver's */
     const size_t kTableChunk = ring_slots > 0 ? (size_t)1 << 30 : (size_t)64 << 20;
@@ -113,7 +130,8 @@ int main(int argc, char **argv) {
     if (party == 1) {                                                /* CSP: garbler */
         uint8_t seed[16];
         check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
-        LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk));
+        if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk, n_lambdas, lambdas));
+        else LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk));
         size_t bits = lgc_party_input_bits(party_obj);
         uint8_t *m0 = lgc_host_alloc(bits * 16), *m1 = lgc_host_alloc(bits * 16), *u = lgc_host_alloc(lgc_ot_u_bytes(bits)),
                 *e = lgc_host_alloc(bits * 32);
@@ -139,7 +157,8 @@ int main(int argc, char **argv) {
     } else if (party == 2) {                                         /* Evaluator */
         double time_start = wall_clock();
         printf("\nAlgorithm: %s\n", algorithm);
-        LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_EVALUATOR, NULL, kTableChunk));
+        if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, LGC_ROLE_EVALUATOR, NULL, kTableChunk, n_lambdas, lambdas));
+        else LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_EVALUATOR, NULL, kTableChunk));
         size_t bits = lgc_party_input_bits(party_obj);
         uint8_t *labels = malloc(bits * 16);
         printf("party %d listening for %d inputs", party, P);
@@ -152,7 +171,7 @@ int main(int argc, char **argv) {
         double t_ot = wall_clock() - time_start;
         /* where cgd.oc:190-194 prints yaoGateCount() and the running time: after the launch that
          * completes each iteration */
-        size_t n_marks = sys.algorithm == LGC_ALG_CGD ? (size_t)num_iterations : 0;
+        size_t n_marks = (sys.algorithm == LGC_ALG_CGD && !n_lambdas) ? (size_t)num_iterations : 0;
         uint32_t *mark_launch = malloc((n_marks + 1) * sizeof *mark_launch);
         uint64_t *mark_gates = malloc((n_marks + 1) * sizeof *mark_gates);
         double *mark_time = malloc((n_marks + 1) * sizeof *mark_time);
@@ -162,9 +181,22 @@ int main(int argc, char **argv) {
         size_t nr = lgc_party_num_reveal(party_obj);
         uint64_t *dec = malloc((nr + 1) * 8);
         check(!recv_blob(self, 1, dec, nr * 8), "could not receive decode bits");
-        int64_t *beta = malloc(d * 8), *ab = malloc((T + d) * 8), *trace = malloc(((size_t)num_iterations * (d + 4) + 1) * 8);
-        LGC(lgc_party_finish(party_obj, dec, beta, trace, ab));
+        int64_t *beta = malloc((n_lambdas ? n_lambdas : 1) * d * 8), *ab = malloc((T + d) * 8),
+                *trace = malloc(((size_t)num_iterations * (d + 4) + 1) * 8);
+        LGC(lgc_party_finish(party_obj, dec, beta, n_lambdas ? NULL : trace, n_lambdas ? NULL : ab));
         free(dec);
+        if (n_lambdas) {                                         /* sweep: one Result line per lambda, in order */
+            printf("Time taken for OT: %f\nOT time: %f\n", t_ot, t_ot);
+            printf("Time elapsed: %f\n", wall_clock() - time);
+            printf("Number of gates: %lld\n", (long long)lgc_party_and_gates(party_obj));
+            for (size_t t = 0; t < n_lambdas; t++) {
+                printf("Lambda: %.17g\nResult: ", lambdas[t]);
+                for (size_t i = 0; i < d; i++) printf("%20.15f ", fixed_to_double(beta[t * d + i], precision));
+                printf("\n");
+            }
+            free(beta); free(ab); free(trace); free(mark_launch); free(mark_gates); free(mark_time);
+            goto done;
+        }
         /* debug reveal of A and b (src/linear.oc:68-88) */
         printf("A = \n");
         for (size_t i = 0; i < d; i++) {
@@ -219,11 +251,13 @@ int main(int argc, char **argv) {
         free(sel); free(u); free(e); free(labels);
     }
 
+done:
     if (party_obj) lgc_party_destroy(party_obj);
     node_destroy(&self);
     config_destroy(&c);
     free(share_A);
     free(share_b);
+    free(lambdas);
     return 0;
 error:
     if (party_obj) lgc_party_destroy(party_obj);

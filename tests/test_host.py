@@ -289,3 +289,28 @@ def test_five_process_64_32_split_share_level(tmp_path, golden_dir, oracle, gccp
     # and the per-share shift really matters here: shifting the total instead gives another input
     tot = oracle.aggregate(Xq.reshape(n, d), yq, n, d, p1, 64)
     assert not np.array_equal(oracle.sum_shares(cA, 32), oracle.sum_shares(oracle.convert_shares(tot[0], p1, p2, 64, 32)[None, :], 32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--table_ring"]], ids=["socket", "ring"])
+def test_five_process_lambda_sweep(tmp_path, golden_dir, oracle, extra):
+    """bin/linreg ... --lambdas=l1,l2,l3: CSP and Evaluator as separate processes run ONE merged program for
+    all lambdas; the three data providers share their inputs (label OT with the CSP) once.  Every Result
+    line equals the oracle's single-lambda run (src/linear.oc:52-57: lambda enters after the share sums)."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    src = os.path.join(golden_dir, "readme_example.in")
+    infile = str(tmp_path / "readme.in")
+    P = _rewrite_ports(src, infile)
+    lams = [0.001, 0.0, 0.25, 1e-6]
+    outs = _run_all(infile, P, ["56", "cgd", "10", "123"] + ["--lambdas=" + ",".join(repr(l) for l in lams)] + extra)
+    ev = outs[1].strip().splitlines()
+    got = [(float(ev[i].split()[1]), re.findall("-?[0-9]+\\.[0-9]+", ev[i + 1])) for i in range(len(ev) - 1)
+           if ev[i].startswith("Lambda:") and ev[i + 1].startswith("Result:")]
+    assert [g[0] for g in got] == lams
+    assert got[0][1] == README_RESULT                                 # lambda = 0.001 is the README run
+    for lam, res in got:
+        beta = oracle.linreg_file(src, 56, -1, 64, 64, 2, 10, lam)
+        assert res == ["%.15f" % (int(b) / 2.0 ** 56) for b in beta], lam
+    # the data providers ran exactly as in a single-lambda run
+    for k in range(2, P + 2):
+        assert "connected successfully to CSP and Evaluator" in outs[k]
