@@ -275,6 +275,12 @@ void lgc_ot_sender_destroy(lgc_ot_sender *s);
 int lgc_ot_receiver_create(lgc_ot_receiver **out, int device, const uint8_t seeds0[128][16], const uint8_t seeds1[128][16]);
 void lgc_ot_receiver_destroy(lgc_ot_receiver *r);
 size_t lgc_ot_u_bytes(uint64_t m);
+/* Device I/O: with on != 0 every data pointer of the transfer calls of this session (a, b, choice, u, y, e,
+ * messages, labels, shares) is DEVICE memory on the session's GPU and is used in place -- no host round
+ * trip between lgc_p1_* outputs, the OT and the consumer.  Default: host pointers (copied on the
+ * session's stream; page-locked buffers from lgc_host_alloc move at the full PCIe rate). */
+int lgc_ot_sender_set_device_io(lgc_ot_sender *s, int on);
+int lgc_ot_receiver_set_device_io(lgc_ot_receiver *r, int on);
 /* Gilboa inner products (inner_product_ot_recver / _sender, src/phase1.c:53-96), batched over
  * npairs: OT index (q*n + k)*width + bit; receiver choice = bit of a[q][k] (LSB first), sender
  * correlation 2^bit * b[q][k] + s.  y: npairs*n*width words.  shares: npairs words each side;

@@ -101,6 +101,7 @@ def lib():
             ("lgc_party_finish", [vp, vp, vp, vp, vp]),
             ("lgc_ot_sender_create", [C.POINTER(vp), ci, C.c_char_p, vp]),
             ("lgc_ot_receiver_create", [C.POINTER(vp), ci, vp, vp]),
+            ("lgc_ot_sender_set_device_io", [vp, ci]), ("lgc_ot_receiver_set_device_io", [vp, ci]),
             ("lgc_ot_gilboa_recv_start", [vp, vp, sz, sz, ci, vp]),
             ("lgc_ot_gilboa_send", [vp, vp, sz, sz, ci, vp, vp, vp]),
             ("lgc_ot_gilboa_recv_finish", [vp, vp, vp]),
@@ -131,6 +132,23 @@ def lib():
 def _chk(rc):
     if rc != 0:
         raise LgcError(rc, lib().lgc_last_error().decode())
+
+
+def host_alloc(nbytes):
+    """page-locked host buffer as a numpy uint8 array (lgc_host_alloc); free with host_free(arr)"""
+    L = lib()
+    L.lgc_host_alloc.restype = C.c_void_p; L.lgc_host_alloc.argtypes = [C.c_size_t]
+    p = L.lgc_host_alloc(nbytes)
+    if not p:
+        raise LgcError(-4, L.lgc_last_error().decode())
+    arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (nbytes,))
+    return arr
+
+
+def host_free(arr):
+    L = lib()
+    L.lgc_host_free.restype = None; L.lgc_host_free.argtypes = [C.c_void_p]
+    L.lgc_host_free(C.c_void_p(arr.ctypes.data))
 
 
 def device_count():
@@ -431,6 +449,14 @@ class OtSender:
         _chk(lib().lgc_ot_gilboa_send(self._h, _vp(b), npairs, n, width, _vp(u), _vp(y), _vp(sh)))
         return y, sh
 
+    # raw-pointer forms (integer addresses): page-locked host buffers (host_alloc) or, after
+    # set_device_io(True), device memory used in place
+    def set_device_io(self, on):
+        _chk(lib().lgc_ot_sender_set_device_io(self._h, 1 if on else 0))
+
+    def gilboa_ptr(self, b_ptr, npairs, n, width, u_ptr, y_ptr, shares_ptr):
+        _chk(lib().lgc_ot_gilboa_send(self._h, C.c_void_p(b_ptr), npairs, n, width, C.c_void_p(u_ptr), C.c_void_p(y_ptr), C.c_void_p(shares_ptr)))
+
     def labels(self, m0, m1, u):
         m0 = np.ascontiguousarray(m0, dtype=np.uint8).reshape(-1, 16); m1 = np.ascontiguousarray(m1, dtype=np.uint8).reshape(-1, 16)
         e = np.zeros((len(m0), 32), dtype=np.uint8)
@@ -465,6 +491,15 @@ class OtReceiver:
             self._nps = []
         self._nps.append(npairs)               # several receives may be in flight; finishes complete the oldest
         return u
+
+    def set_device_io(self, on):
+        _chk(lib().lgc_ot_receiver_set_device_io(self._h, 1 if on else 0))
+
+    def gilboa_start_ptr(self, a_ptr, npairs, n, width, u_ptr):
+        _chk(lib().lgc_ot_gilboa_recv_start(self._h, C.c_void_p(a_ptr), npairs, n, width, C.c_void_p(u_ptr)))
+
+    def gilboa_finish_ptr(self, y_ptr, shares_ptr):
+        _chk(lib().lgc_ot_gilboa_recv_finish(self._h, C.c_void_p(y_ptr), C.c_void_p(shares_ptr)))
 
     def gilboa_finish(self, y):
         if not getattr(self, "_nps", None):
