@@ -123,12 +123,13 @@ ot_gilboa_send_kernel(const uint4 *rows, uint4 delta, const uint64_t *bvals, uin
     lds_tab4_fill(lds_te0);
     const LdsTab4 lt = lds_tab4_make(lds_te0);
     const uint64_t mask = w == 32 ? 0xffffffffull : ~0ull;
+    const int lw = w == 32 ? 5 : 6;
     for (uint64_t q = blockIdx.y; q < npairs; q += gridDim.y) {
         uint64_t acc = 0;
         for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m_per_pair; t += (uint64_t)gridDim.x * blockDim.x) {
             const uint64_t i = q * m_per_pair + t;
-            const uint64_t k = t / (uint64_t)w;
-            const int bit = (int)(t % (uint64_t)w);
+            const uint64_t k = t >> lw;                 // w is 32 or 64: no 64-bit division in the inner loop
+            const int bit = (int)(t & (uint64_t)(w - 1));
             Lbl x[2] = {u4_lbl(rows[i]), lxor(u4_lbl(rows[i]), u4_lbl(delta))};
             uint64_t tw[2] = {tweak0 + i, tweak0 + i};
             Lbl h[2];
@@ -151,12 +152,13 @@ ot_gilboa_recv_kernel(const uint4 *rows, const uint64_t *avals, uint64_t n, int 
     lds_tab4_fill(lds_te0);
     const LdsTab4 lt = lds_tab4_make(lds_te0);
     const uint64_t mask = w == 32 ? 0xffffffffull : ~0ull;
+    const int lw = w == 32 ? 5 : 6;
     for (uint64_t q = blockIdx.y; q < npairs; q += gridDim.y) {
         uint64_t acc = 0;
         for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m_per_pair; t += (uint64_t)gridDim.x * blockDim.x) {
             const uint64_t i = q * m_per_pair + t;
-            const uint64_t k = t / (uint64_t)w;
-            const int bit = (int)(t % (uint64_t)w);
+            const uint64_t k = t >> lw;                 // w is 32 or 64: no 64-bit division in the inner loop
+            const int bit = (int)(t & (uint64_t)(w - 1));
             Lbl x = u4_lbl(rows[i]);
             uint64_t tw = tweak0 + i;
             Lbl h;

@@ -45,6 +45,9 @@ if "mid" in args:      # overlap of the garbler and evaluator chains on latency-
         run(100, "cgd", 15, profile=prof)
     for prof in (False, True):
         run(20, "cholesky", 0, profile=prof)
+if "chol" in args:     # latency-bound launches only (4-wave kernels)
+    for _ in range(3):
+        run(20, "cholesky", 0)
 if "trace" in args:
     run(100, "cgd", 2)
 if "w32big" in args:

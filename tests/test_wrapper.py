@@ -113,3 +113,77 @@ def test_result_file_layout(tmp_path):
     assert rows[0] == '{"n":"10", "d":"5", "p":"3"}'
     assert rows[1] == '{"party":"4", "cputime":"1.500000", "wait_time":0.250000, "realtime":"2.000000"}'
     assert rows[2:] == ["[0, 10]", "[0, 2]"]
+
+
+def _fit_side(own, other, csv_path, spec, args, q):
+    """one MPCLinearRegression.fit() in its own process; keeps the MPC input file it wrote"""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "linreg-mpc_amd", "python"))
+    import mpc_linear_regression as m
+    r = m.MPCLinearRegression(own, other, mpc_args=args)
+    kept = {}
+    make_csv = r.make_csv
+    def keep(matrix):
+        path = make_csv(matrix)
+        kept["text"] = open(path).read()
+        return path
+    r.make_csv = keep
+    r.fit(csv_path, spec)
+    q.put((spec, r.result, kept["text"], r.predict({"age": 40.0, "sex": "m", "height": 1.82, "weight": 77.0})))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["cgd", "cholesky"])
+def test_fit_two_instances_end_to_end(tmp_path, oracle, alg):
+    """python_interface/MPCLinearRegression.py:165-194, 229-244: two wrapper instances on localhost
+    exchange parameters over msgpack, write their input files, spawn DP1 + CSP / DP2 + Evaluator
+    (bin/linreg on the GPU), the evaluator side parses the last stdout line and hands the
+    coefficients to the peer.  The coefficients equal the oracle's on the combined data set."""
+    import multiprocessing as mp
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "linreg-mpc_amd", "host")], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(3)
+    n = 60
+    age = rng.integers(20, 70, n).astype(float); sex = rng.integers(0, 2, n)
+    height = 1.5 + 0.4 * rng.random(n); weight = 50 + 40 * rng.random(n)
+    income = 800 + 35 * age + 400 * sex + 900 * height - 3 * weight + 50 * rng.standard_normal(n)
+    csvf = tmp_path / "people.csv"
+    with open(csvf, "w") as f:
+        f.write("age;sex;height;weight;income\n")
+        for i in range(n):
+            f.write("%r;%s;%r;%r;%r\n" % (float(age[i]), "mw"[1 - int(sex[i])], float(height[i]), float(weight[i]), float(income[i])))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); base = s.getsockname()[1]; s.close()
+    base = 20000 + (base % 20000)
+    a_ip, b_ip = "127.0.0.1:%d" % base, "127.0.0.1:%d" % (base + 100)
+    args = ["56", alg, "12", "0.001"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pa = ctx.Process(target=_fit_side, args=(a_ip, b_ip, str(csvf), "0 c1", args, q))          # age, sex
+    pb = ctx.Process(target=_fit_side, args=(b_ip, a_ip, str(csvf), "2 3 r4", args, q))        # height, weight, income
+    pa.start(); pb.start()
+    try:
+        outs = dict((o[0], o[1:]) for o in (q.get(timeout=120), q.get(timeout=120)))
+    finally:
+        pa.join(20); pb.join(20)
+        for pr in (pa, pb):
+            if pr.is_alive():
+                pr.kill()
+    assert pa.exitcode == 0 and pb.exitcode == 0
+    res_a, file_a, pred_a = outs["0 c1"]
+    res_b, file_b, pred_b = outs["2 3 r4"]
+    assert res_a == res_b and len(res_b) == 4                     # the peer received what the evaluator side parsed
+    assert pred_a == pred_b
+    # the data set the four processes computed on: columns 0..1 from side a's file, 2..3 and y from side b's
+    ta, tb = file_a.split("\n"), file_b.split("\n")
+    assert ta[:6] == tb[:6]                                       # same header: n d P, CSP, Evaluator, the two providers
+    rows = [ra.split()[:2] + rb.split()[2:] for ra, rb in zip(ta[6:6 + n], tb[6:6 + n])]
+    comb = tmp_path / "combined.in"
+    comb.write_text("\n".join(ta[:6] + [" ".join(r) for r in rows] + tb[6 + n:]))
+    beta = oracle.linreg_file(str(comb), 56, -1, 64, 64, {"cholesky": 0, "cgd": 2}[alg], 12, 0.001)
+    assert res_b == [float("%.15f" % (int(v) / 2.0 ** 56)) for v in beta]
+    # and it is a sensible regression: close to least squares on the studentised data
+    X = np.array([[float(v) for v in r] for r in rows]); y = np.array([float(v) for v in tb[6 + n + 1].split()])
+    ls = np.linalg.solve(X.T @ X / (n * 4) + 0.001 * np.eye(4), X.T @ y / (n * 4))
+    assert np.allclose(res_b, ls, atol=5e-3 if alg == "cgd" else 1e-6)
