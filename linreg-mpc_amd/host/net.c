@@ -33,11 +33,33 @@ int net_send(node *n, int to, const void *buf, size_t len) {
     if (to < 1 || to > n->num_parties || n->fd[to - 1] < 0) return -1;
     n->sent[to - 1] += len;
     n->nsend[to - 1]++;
+    __atomic_fetch_add(&n->pending[to - 1], len, __ATOMIC_RELAXED);
     return io_all(n->fd[to - 1], (void *)buf, len, 1);
 }
 int net_recv(node *n, int from, void *buf, size_t len) {
     if (from < 1 || from > n->num_parties || n->fd[from - 1] < 0) return -1;
+    /* a buffered transport flushes its pending output before it blocks in a read */
+    if (__atomic_exchange_n(&n->pending[from - 1], 0, __ATOMIC_RELAXED)) __atomic_fetch_add(&n->nflush[from - 1], 1, __ATOMIC_RELAXED);
     return io_all(n->fd[from - 1], buf, len, 0);
+}
+/* send + explicit flush as one accounting event (a concurrent reader on the same connection must not see the
+ * message as pending output and count a second, implicit flush) */
+int net_send_flush(node *n, int to, const void *buf, size_t len) {
+    if (to < 1 || to > n->num_parties || n->fd[to - 1] < 0) return -1;
+    n->sent[to - 1] += len;
+    n->nsend[to - 1]++;
+    __atomic_store_n(&n->pending[to - 1], 0, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&n->nflush[to - 1], 1, __ATOMIC_RELAXED);
+    return io_all(n->fd[to - 1], (void *)buf, len, 1);
+}
+void net_flush(node *n, int to) {
+    if (to < 1 || to > n->num_parties || n->fd[to - 1] < 0) return;
+    __atomic_store_n(&n->pending[to - 1], 0, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&n->nflush[to - 1], 1, __ATOMIC_RELAXED);
+}
+uint64_t net_flush_count(const node *n, int party) {
+    if (party < 1 || party > n->num_parties || n->fd[party - 1] < 0) return 0;
+    return n->nflush[party - 1] + 1;                   /* + the flush of cleanupProtocol */
 }
 
 static int split_endpoint(const char *ep, char *host, size_t hl, char *port, size_t pl) {
@@ -90,6 +112,8 @@ int node_new(node **out, int party, int num_parties, char **endpoints) {
     n->sent = calloc((size_t)num_parties, sizeof(uint64_t));
     n->nsend = calloc((size_t)num_parties, sizeof(uint64_t));
     n->wait_ns = calloc((size_t)num_parties, sizeof(uint64_t));
+    n->pending = calloc((size_t)num_parties, sizeof(uint64_t));
+    n->nflush = calloc((size_t)num_parties, sizeof(uint64_t));
     for (int i = 0; i < num_parties; i++) n->fd[i] = -1;
     char host[256], port[32];
     for (int q = 1; q < party; q++) {                       /* lower-numbered peers listen */
@@ -97,7 +121,9 @@ int node_new(node **out, int party, int num_parties, char **endpoints) {
         int s = connect_retry(host, port);
         n->fd[q - 1] = s;
         int32_t me = party;
-        if (io_all(s, &me, sizeof me, 1)) goto fail;      /* announce ourselves (node.c:37) */
+        if (io_all(s, &me, sizeof me, 1)) goto fail;      /* announce ourselves (node.c:35-37) ... */
+        n->sent[q - 1] += sizeof me; n->nsend[q - 1]++;
+        net_flush(n, q);                                  /* ... and flush */
     }
     if (party < num_parties) {
         if (split_endpoint(endpoints[party - 1], host, sizeof host, port, sizeof port)) goto fail;
@@ -136,7 +162,7 @@ void node_destroy(node **nn) {
     if (!nn || !*nn) return;
     node *n = *nn;
     if (n->fd) for (int i = 0; i < n->num_parties; i++) if (n->fd[i] >= 0) close(n->fd[i]);
-    free(n->fd); free(n->sent); free(n->nsend); free(n->wait_ns); free(n);
+    free(n->fd); free(n->sent); free(n->nsend); free(n->wait_ns); free(n->pending); free(n->nflush); free(n);
     *nn = 0;
 }
 
@@ -147,6 +173,9 @@ int net_barrier(node *n) {
         if (net_send(n, n->party + 1, &flag, sizeof flag)) return -1;
         if (net_recv(n, n->party + 1, &flag, sizeof flag)) return -1;
     }
-    if (n->party != 1 && net_send(n, n->party - 1, &flag, sizeof flag)) return -1;
+    if (n->party != 1) {
+        if (net_send(n, n->party - 1, &flag, sizeof flag)) return -1;
+        net_flush(n, n->party - 1);
+    }
     return 0;
 }

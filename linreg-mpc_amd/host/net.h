@@ -12,13 +12,23 @@ typedef struct {
     int *fd;            /* fd[q-1] = socket to party q, -1 for self */
     uint64_t *sent;     /* bytes sent per peer (PROFILE_NETWORK-style accounting) */
     uint64_t *wait_ns;  /* time spent waiting for a peer data provider's message, per peer (src/phase1.c:177-183) */
-    uint64_t *nsend;    /* send calls per peer (each one reaches the socket: the "flush count") */
+    uint64_t *nsend;    /* send calls per peer */
+    /* Obliv-C's -DPROFILE_NETWORK counts FLUSHES of its buffered transport, not writes: one per explicit
+     * flush (the orecv(pd,0,NULL,0) idiom: after every protobuf message, src/phase1.c:141; after the party
+     * announcement, src/node.c:37; at the end of a barrier, src/cmd/secure_multiplication.c:31), one whenever
+     * a read finds unflushed output pending, and one when the connection is cleaned up.  The sockets here
+     * are unbuffered, so the same events are counted where the reference's code has them. */
+    uint64_t *pending;  /* bytes written to a peer since its last flush event */
+    uint64_t *nflush;   /* flush events per peer (net_flush_count adds the one of the final cleanup) */
 } node;
 
 int node_new(node **out, int party, int num_parties, char **endpoints);
 void node_destroy(node **n);
 int net_send(node *n, int to_party, const void *buf, size_t len);
 int net_recv(node *n, int from_party, void *buf, size_t len);
+void net_flush(node *n, int to_party);               /* explicit flush point */
+int net_send_flush(node *n, int to_party, const void *buf, size_t len);   /* send followed by an explicit flush */
+uint64_t net_flush_count(const node *n, int party);  /* as "Total flush done" would report it at cleanup */
 int net_barrier(node *n);    /* chain barrier of src/cmd/linreg.c:19-41 */
 double wall_clock(void);
 #endif

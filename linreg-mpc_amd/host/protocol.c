@@ -53,7 +53,7 @@ int send_pmsg(node *self, int to, const uint64_t *vec, size_t n, uint64_t value)
     uint8_t *buf = malloc(sz + sizeof(size_t));
     memcpy(buf, &sz, sizeof sz);
     pmsg_pack(vec, n, value, buf + sizeof sz);
-    int rc = net_send(self, to, buf, sz + sizeof sz);
+    int rc = net_send_flush(self, to, buf, sz + sizeof sz);   /* flush: orecv(pd,0,NULL,0) at src/phase1.c:141 */
     free(buf);
     return rc;
 }
@@ -207,8 +207,8 @@ static void *ti_sender_main(void *arg) {
         const int *pa = R->pa_of + S->q0, *pb = R->pb_of + S->q0;
         int bad = 0;
         for (size_t q = 0; q < S->nb && !bad; q++) {
-            if (pa[q] == t->owner) bad |= net_send(R->self, t->owner + 1, S->frames[2 * q].buf, S->frames[2 * q].len);
-            if (pb[q] == t->owner) bad |= net_send(R->self, t->owner + 1, S->frames[2 * q + 1].buf, S->frames[2 * q + 1].len);
+            if (pa[q] == t->owner) bad |= net_send_flush(R->self, t->owner + 1, S->frames[2 * q].buf, S->frames[2 * q].len);
+            if (pb[q] == t->owner) bad |= net_send_flush(R->self, t->owner + 1, S->frames[2 * q + 1].buf, S->frames[2 * q + 1].len);
         }
         pthread_mutex_lock(&R->mu);
         if (bad) R->failed = 1;

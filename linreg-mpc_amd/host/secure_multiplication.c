@@ -57,6 +57,13 @@ int main(int argc, char **argv) {
     for (int q = 0; q < self->num_parties; q++) printf("%s%llu", q ? ", " : "", (unsigned long long)self->nsend[q]);
     printf("]}\n");
     check(!net_barrier(self), "barrier failed");
+    /* what Obliv-C built with -DPROFILE_NETWORK prints per connection at cleanup, in party order -- the lines
+     * experiments/test_phase1_aws.py:245-250 collects into the [bytes...] / [flushes...] rows of the .out files */
+    for (int q = 1; q <= self->num_parties; q++) {
+        if (q == party) continue;
+        printf("Total bytes sent: %llu\n", (unsigned long long)self->sent[q - 1]);
+        printf("Total flush done: %llu\n", (unsigned long long)net_flush_count(self, q));
+    }
     node_destroy(&self);
     config_destroy(&c);
     free(sa); free(sb);

@@ -314,3 +314,46 @@ def test_five_process_lambda_sweep(tmp_path, golden_dir, oracle, extra):
     # the data providers ran exactly as in a single-lambda run
     for k in range(2, P + 2):
         assert "connected successfully to CSP and Evaluator" in outs[k]
+
+
+@pytest.mark.gpu
+def test_network_accounting_matches_profile_network(tmp_path):
+    """-DPROFILE_NETWORK parity (experiments/test_phase1_aws.py:61, 245-252).  The published run
+    experiments/results/phase1_network/test_LR_1000000x100_2_0_p{1..4}.out reads, per peer in party order,
+        p1 (TI):  bytes [8, 24215018695, 24215000228]   flushes [3, 2551, 2551]
+        p2:       bytes [12, 8, 0]                      flushes [4, 3, 1]
+        p3 (DP1): bytes [4, 12, 24214997062]            flushes [2, 4, 2553]
+        p4 (DP2): bytes [4, 4, 24215024180]             flushes [2, 2, 2554]
+    with 2550 cross-party pairs: bytes per element 24215018695 / (2550 * 1e6) = 9.4961 (64-bit varints) and
+    flushes = pairs + 1 (+ barrier flushes between neighbours).  Same structure here at n = 20000."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    n, d = 20000, 6
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((n, d)); X /= np.abs(X).max(axis=0)
+    y = X @ rng.random(d)
+    ports = _free_ports(4)
+    path = str(tmp_path / "net.in")
+    with open(path, "w") as f:
+        f.write("%d %d 2\n127.0.0.1:%d\n127.0.0.1:%d\n127.0.0.1:%d 0\n127.0.0.1:%d 3\n%d %d\n" % (n, d, ports[0], ports[1], ports[2], ports[3], n, d))
+        np.savetxt(f, X, fmt="%.17g")
+        f.write("%d\n" % n)
+        np.savetxt(f, y[None, :], fmt="%.17g")
+    exe = os.path.join(HOST, "bin", "secure_multiplication")
+    procs = [subprocess.Popen([exe, path, "56", str(k)], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for k in range(1, 5)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-1000:]
+    pairs = 3 * 3 + 3                                   # columns 0-2 vs 3-5, and the target row vs columns 0-2
+    byt, flu = [], []
+    for o, _ in outs:
+        t = o.decode()
+        byt.append([int(v) for v in re.findall(r"Total bytes sent: (\d+)", t)])
+        flu.append([int(v) for v in re.findall(r"Total flush done: (\d+)", t)])
+    # control traffic: byte for byte the reference's
+    assert byt[0][0] == 8 and byt[1] == [12, 8, 0] and byt[2][:2] == [4, 12] and byt[3][:2] == [4, 4]
+    assert flu[0] == [3, pairs + 1, pairs + 1] and flu[1] == [4, 3, 1]
+    assert flu[2] == [2, 4, pairs + 3] and flu[3] == [2, 2, pairs + 4]
+    # payload: 64-bit values as varints, 9.4961 bytes per element in the reference's run
+    ref = 24215018695 / (2550 * 1e6)
+    for b in (byt[0][1], byt[0][2], byt[2][2], byt[3][2]):
+        assert abs(b / (pairs * n) / ref - 1) < 1e-3, (b / (pairs * n), ref)
