@@ -255,6 +255,9 @@ int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const uint32_t *
  * -1) followed by lgc_p1_dot, with half the device operations. */
 int lgc_p1_ti_a(lgc_p1 *h, uint32_t col, const uint64_t *y, const uint64_t *in, uint64_t sub,
                 uint64_t *out_mask, uint64_t *share);
+/* the same for a run of pairs with one peer in ONE device call (y, in, out_mask: npairs x n words) */
+int lgc_p1_ti_a_batch(lgc_p1 *h, const uint32_t *cols, size_t npairs, const uint64_t *y, const uint64_t *in,
+                      const uint64_t *sub, uint64_t *out_mask, uint64_t *shares);
 /* Trusted initializer (src/phase1.c:241-287): pairs [first_pair, first_pair + npairs) of the
  * cross-party (i, j) enumeration; x, y: npairs x n words, r, xy_minus_r: npairs words, drawn in the
  * order x, y, r from one AES-128-CTR stream keyed by seed (newBCipherRandomGen / randomizeBuffer). */

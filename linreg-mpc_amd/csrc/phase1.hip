@@ -10,6 +10,7 @@
 // the host and is out of scope here; these entry points take and return host buffers.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -192,6 +193,23 @@ p1_ti_a_kernel(const int64_t *X, size_t n, size_t ld, uint32_t col, const uint64
     if (threadIdx.x == 0) atomicAdd((unsigned long long *)&out[n], (unsigned long long)t);   // out[n] zeroed by the host
 }
 
+// the same for a run of pairs with one peer: grid.y strides over the pairs; acc[q] zeroed by the host
+__global__ void __launch_bounds__(256)
+p1_ti_a_batch_kernel(const int64_t *X, size_t n, size_t ld, const uint32_t *cols, size_t npairs, const uint64_t *y, const uint64_t *in,
+                     uint64_t *out, uint64_t *acc_out) {
+    for (size_t q = blockIdx.y; q < npairs; q += gridDim.y) {
+        const uint32_t col = cols[q];
+        uint64_t acc = 0;
+        for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+            uint64_t yk = y[q * n + k];
+            out[q * n + k] = (uint64_t)X[k * ld + col] - yk;
+            acc += in[q * n + k] * yk;
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&acc_out[q], (unsigned long long)acc);
+    }
+}
+
 // ---- batched wrap-around dot products: out[q] = sum_k A[q][k] * B[q][k]; B is either a vector
 // batch (colsB == NULL) or columns of X
 __global__ void __launch_bounds__(256)
@@ -349,13 +367,40 @@ struct P1Scratch {
 };
 static thread_local P1Scratch t_scratch;
 
-// The per-pair calls of one process share ONE stream, taken in turn: a data provider runs a worker
-// thread per peer, and with a stream (= a hardware queue) per thread five providers on one GPU
-// oversubscribe the queues, which the scheduler then time-slices at millisecond granularity.
+// Stream policy of the per-pair / per-batch calls.  A data provider runs a worker thread per peer, and five
+// provider processes share one GPU in the single-box runs.  A stream (= a hardware queue) per worker thread
+// oversubscribes the queues, which the scheduler then time-slices at millisecond granularity: config 4 takes
+// 65.7 s that way against 21.5 s with all calls of a process taking turns on ONE stream -- measured again in
+// round 2 with one call per batch of 16 pairs (LGC_P1_THREAD_STREAMS=1 selects the per-thread streams).
 #include <mutex>
 static std::mutex g_p1_mutex;
-struct P1Serial { std::lock_guard<std::mutex> g; P1Serial() : g(g_p1_mutex) {} };
-static hipStream_t p1_stream() { return 0; }
+static bool p1_shared_stream() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("LGC_P1_THREAD_STREAMS"); v = (e && *e == '1') ? 0 : 1; }
+    return v == 1;
+}
+struct P1Serial {
+    bool locked;
+    P1Serial() : locked(p1_shared_stream()) { if (locked) g_p1_mutex.lock(); }
+    ~P1Serial() { if (locked) g_p1_mutex.unlock(); }
+};
+struct P1ThreadStream {
+    hipStream_t st; int device;
+    P1ThreadStream() : st(0), device(-1) {}
+    ~P1ThreadStream() { if (st) (void)hipStreamDestroy(st); }
+};
+static thread_local P1ThreadStream t_stream;
+static hipStream_t p1_stream() {
+    if (p1_shared_stream()) return 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!t_stream.st || t_stream.device != dev) {
+        if (t_stream.st) (void)hipStreamDestroy(t_stream.st);
+        t_stream.st = 0; t_stream.device = dev;
+        if (hipStreamCreateWithFlags(&t_stream.st, hipStreamNonBlocking) != hipSuccess) t_stream.st = 0;
+    }
+    return t_stream.st;
+}
 
 // out[q][k] = column cols[q] (d means y) +/- V[q][k]: the vectors a DP sends in inner_product_ti
 // (b + x at phase1.c:201-207, a - y at 186-191).  Safe to call from several threads on one handle.
@@ -462,6 +507,38 @@ extern "C" int lgc_p1_ti_a(lgc_p1 *h, uint32_t col, const uint64_t *y, const uin
     const uint64_t m = maskw(h->w);
     if (h->w == 32) for (size_t i = 0; i < n; i++) out_mask[i] &= m;
     *share = (acc - sub) & m;
+    return LGC_OK;
+}
+
+// Party a for a run of pairs with the same peer in one device call: y, in, out_mask are npairs x n words
+// (page-locked host buffers move at the PCIe rate), cols / sub / shares have npairs entries.
+extern "C" int lgc_p1_ti_a_batch(lgc_p1 *h, const uint32_t *cols, size_t npairs, const uint64_t *y, const uint64_t *in,
+                                 const uint64_t *sub, uint64_t *out_mask, uint64_t *shares) {
+    if (!h || !cols || !y || !in || !sub || !out_mask || !shares) return lgc_fail(LGC_EINVAL, "null argument");
+    if (npairs == 0) return LGC_OK;
+    for (size_t q = 0; q < npairs; q++) if (cols[q] > h->d) return lgc_fail(LGC_EINVAL, "column out of range");
+    P1CHK(hipSetDevice(h->device));
+    P1Serial serial_; hipStream_t st = p1_stream();
+    const size_t n = h->n, bytes = npairs * n * sizeof(uint64_t);
+    uint64_t *dy = 0, *din = 0, *dout = 0; uint32_t *dcols = 0;
+    P1CHK(t_scratch.get(h->device, 0, npairs * sizeof(uint32_t), (void **)&dcols));
+    P1CHK(t_scratch.get(h->device, 1, bytes, (void **)&dy));
+    P1CHK(t_scratch.get(h->device, 2, bytes, (void **)&din));
+    P1CHK(t_scratch.get(h->device, 3, bytes + npairs * sizeof(uint64_t), (void **)&dout));
+    P1CHK(hipMemcpyAsync(dcols, cols, npairs * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    P1CHK(hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, st));
+    P1CHK(hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, st));
+    P1CHK(hipMemsetAsync(dout + npairs * n, 0, npairs * sizeof(uint64_t), st));
+    unsigned gx = (unsigned)((n + 255) / 256); if (gx > 64) gx = 64;
+    unsigned gy = npairs > 65535 ? 65535u : (unsigned)npairs;
+    hipLaunchKernelGGL(p1_ti_a_batch_kernel, dim3(gx, gy), dim3(256), 0, st, h->X, n, h->d + 1, dcols, npairs, dy, din, dout, dout + npairs * n);
+    P1CHK(hipGetLastError());
+    P1CHK(hipMemcpyAsync(out_mask, dout, bytes, hipMemcpyDeviceToHost, st));
+    P1CHK(hipMemcpyAsync(shares, dout + npairs * n, npairs * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    P1CHK(hipStreamSynchronize(st));
+    const uint64_t m = maskw(h->w);
+    if (h->w == 32) for (size_t i = 0; i < npairs * n; i++) out_mask[i] &= m;
+    for (size_t q = 0; q < npairs; q++) shares[q] = (shares[q] - sub[q]) & m;
     return LGC_OK;
 }
 

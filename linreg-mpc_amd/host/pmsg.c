@@ -57,9 +57,10 @@ __attribute__((target("bmi2"))) static size_t pack_payload_bmi2(const uint64_t *
 }
 /* decodes varints from b[*pos..end) into vec while 10 readable bytes remain below `len`; returns
  * the count or (size_t)-1 on a malformed varint; *pos is advanced */
-__attribute__((target("bmi2"))) static size_t unpack_payload_bmi2(const uint8_t *b, size_t *ppos, size_t end, size_t len, uint64_t *vec) {
+__attribute__((target("bmi2"))) static size_t unpack_payload_bmi2(const uint8_t *b, size_t *ppos, size_t end, size_t len, uint64_t *vec, size_t maxcnt) {
     size_t cnt = 0, pos = *ppos;
     while (pos < end && pos + 10 <= len) {
+        if (cnt == maxcnt) return (size_t)-1;
         uint64_t x;
         memcpy(&x, b + pos, 8);
         uint64_t stop = ~x & 0x8080808080808080ull;
@@ -130,7 +131,7 @@ int pmsg_unpack(const uint8_t *b, size_t len, uint64_t **vector, size_t *n, uint
 #if PMSG_FAST
             if (have_bmi2() && plen >= 64) {                 /* every varint is at least one byte */
                 if (cnt + (size_t)plen > cap) { cap = cnt + (size_t)plen; vec = realloc(vec, cap * sizeof *vec); if (!vec) return 1; }
-                size_t got = unpack_payload_bmi2(b, &pos, end, len, vec + cnt);
+                size_t got = unpack_payload_bmi2(b, &pos, end, len, vec + cnt, (size_t)plen);
                 if (got == (size_t)-1) goto bad;
                 cnt += got;
             }
@@ -157,4 +158,42 @@ int pmsg_unpack(const uint8_t *b, size_t len, uint64_t **vector, size_t *n, uint
 bad:
     free(vec);
     return 1;
+}
+
+/* as pmsg_unpack, into a caller-owned vector of `cap` words (no allocation: the phase-1 workers decode
+ * straight into page-locked batch buffers); more than cap elements is an error */
+int pmsg_unpack_into(const uint8_t *b, size_t len, uint64_t *vec, size_t cap, size_t *n, uint64_t *value) {
+    size_t pos = 0, cnt = 0;
+    int have_value = 0;
+    while (pos < len) {
+        uint64_t key;
+        if (get_varint(b, len, &pos, &key)) return 1;
+        if (key == 0x0a) {
+            uint64_t plen;
+            if (get_varint(b, len, &pos, &plen) || pos + plen > len) return 1;
+            size_t end = pos + (size_t)plen;
+#if PMSG_FAST
+            if (have_bmi2() && plen >= 64) {
+                size_t got = unpack_payload_bmi2(b, &pos, end, len, vec + cnt, cap - cnt);
+                if (got == (size_t)-1) return 1;
+                cnt += got;
+            }
+#endif
+            while (pos < end) {
+                uint64_t v;
+                if (cnt == cap || get_varint(b, end, &pos, &v)) return 1;
+                vec[cnt++] = v;
+            }
+        } else if (key == 0x08) {
+            uint64_t v;
+            if (cnt == cap || get_varint(b, len, &pos, &v)) return 1;
+            vec[cnt++] = v;
+        } else if (key == 0x10) {
+            if (get_varint(b, len, &pos, value)) return 1;
+            have_value = 1;
+        } else return 1;
+    }
+    if (!have_value) return 1;
+    *n = cnt;
+    return 0;
 }

@@ -11,4 +11,6 @@ size_t pmsg_packed_size(const uint64_t *vector, size_t n, uint64_t value);
 size_t pmsg_pack(const uint64_t *vector, size_t n, uint64_t value, uint8_t *out);
 /* returns 0 on success; *vector is malloc'd (caller frees) */
 int pmsg_unpack(const uint8_t *buf, size_t len, uint64_t **vector, size_t *n, uint64_t *value);
+/* into a caller-owned vector of cap words; more elements than cap is an error */
+int pmsg_unpack_into(const uint8_t *buf, size_t len, uint64_t *vector, size_t cap, size_t *n, uint64_t *value);
 #endif

@@ -388,11 +388,39 @@ static int recv_pmsg_timed(node *self, int from, uint64_t **vec, size_t *n, uint
     return rc;
 }
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+/* non-blocking pop: 1 when the queue is empty right now */
+static int ti_queue_try_pop(ti_queue *q, ti_item *it) {
+    pthread_mutex_lock(&q->mu);
+    if (q->count == 0) { pthread_mutex_unlock(&q->mu); return 1; }
+    *it = q->items[q->head]; q->head = (q->head + 1) % q->cap; q->count--;
+    pthread_cond_broadcast(&q->cv);
+    pthread_mutex_unlock(&q->mu);
+    return 0;
+}
+/* one message from a peer data provider, decoded straight into `dst` (n words, page-locked); raw / rawcap:
+ * the caller's reusable receive buffer.  Timed like the reference's wait_total. */
+static int recv_pmsg_into_timed(node *self, int from, uint8_t **raw, size_t *rawcap, uint64_t *dst, size_t n, uint64_t *value) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    size_t sz = 0, got = 0;
+    int rc = net_recv(self, from, &sz, sizeof sz) || sz > g_pmsg_limit;
+    if (!rc && sz > *rawcap) { free(*raw); *raw = malloc(sz + sz / 8); *rawcap = *raw ? sz + sz / 8 : 0; rc = !*raw; }
+    if (!rc) rc = net_recv(self, from, *raw, sz);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    self->wait_ns[from - 1] += (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
+    if (!rc) rc = pmsg_unpack_into(*raw, sz, dst, n, &got, value) || got != n;
+    return rc;
+}
+/* The per-peer workers batch: a run of pairs with one peer is one device call (lgc_p1_mask / lgc_p1_dot /
+ * lgc_p1_ti_a_batch over up to kTiBatch pairs) on page-locked buffers the messages are decoded into, instead
+ * of one call per pair from pageable memory.  A batch is whatever has arrived (at least one pair), so
+ * nothing waits for a batch to fill.  Same bytes, same order on every socket. */
+enum { kTiBatch = 16, kTiSlots = 32 };
+
 /* Party b of a run of pairs with one peer, pipelined.  b's first message (b + x) depends only on
  * the TI's message, so this thread sends the masks of successive pairs back to back, while a second
  * thread receives party a's replies and finishes the shares (<a - y, b> - r): party b then never
- * idles for a round trip, and party a always finds its next input waiting.  Both directions of the
- * socket carry the same bytes in the same order as the one-pair-at-a-time exchange. */
+ * idles for a round trip, and party a always finds its next input waiting. */
 typedef struct {
     ti_worker *w;
     const ti_pair **pr;        /* this worker's pairs, in order */
@@ -408,21 +436,28 @@ static void *ti_b_finisher(void *arg) {
     ti_worker *w = bp->w;
     const size_t n = w->n;
     const int to = w->peer + 1;
-    for (size_t k = 0; k < bp->total; k++) {
+    uint64_t *in = lgc_host_alloc(kTiBatch * n * 8);
+    uint8_t *raw = NULL; size_t rawcap = 0;
+    uint32_t cols[kTiBatch]; uint64_t shares[kTiBatch];
+    if (!in) w->failed = 1;
+    for (size_t k = 0; k < bp->total && !w->failed;) {
         pthread_mutex_lock(&bp->mu);
         while (bp->sent <= k && !bp->stop) pthread_cond_wait(&bp->cv, &bp->mu);
-        int stop = bp->sent <= k;
+        size_t avail = bp->sent - k;
         pthread_mutex_unlock(&bp->mu);
-        if (stop) break;
-        uint64_t *in = 0, inval = 0, share = 0, sub = bp->r[k];
-        size_t in_n = 0;
-        uint32_t col = bp->pr[k]->col;
-        if (recv_pmsg_timed(w->self, to, &in, &in_n, &inval) || in_n != n) { fprintf(stderr, "Could not receive message from party A (%d)\n", w->peer); w->failed = 1; }
-        else if (lgc_p1_dot(w->p1, in, 0, &col, 1, &sub, &share)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* <a-y, b> - r */
-        free(in);
+        if (!avail) break;
+        size_t nb = avail < kTiBatch ? avail : kTiBatch;
+        for (size_t i = 0; i < nb && !w->failed; i++) {
+            uint64_t inval = 0;
+            cols[i] = bp->pr[k + i]->col;
+            if (recv_pmsg_into_timed(w->self, to, &raw, &rawcap, in + i * n, n, &inval)) { fprintf(stderr, "Could not receive message from party A (%d)\n", w->peer); w->failed = 1; }
+        }
         if (w->failed) break;
-        *bp->pr[k]->dst = share;
+        if (lgc_p1_dot(w->p1, in, 0, cols, nb, bp->r + k, shares)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; break; }   /* <a-y, b> - r */
+        for (size_t i = 0; i < nb; i++) *bp->pr[k + i]->dst = shares[i];
+        k += nb;
     }
+    free(raw); lgc_host_free(in);
     return NULL;
 }
 static int ti_worker_b_pipelined(ti_worker *w, const ti_pair **mine, size_t total) {
@@ -432,40 +467,48 @@ static int ti_worker_b_pipelined(ti_worker *w, const ti_pair **mine, size_t tota
     memset(&bp, 0, sizeof bp);
     bp.w = w; bp.pr = mine; bp.total = total;
     bp.r = malloc((total + 1) * sizeof *bp.r);
-    uint64_t *tmp = malloc(n * 8);
+    uint64_t *x = lgc_host_alloc(kTiBatch * n * 8), *m = lgc_host_alloc(kTiBatch * n * 8);
+    uint32_t cols[kTiBatch];
     pthread_mutex_init(&bp.mu, NULL); pthread_cond_init(&bp.cv, NULL);
     pthread_t fin;
-    int have_fin = bp.r && tmp && !pthread_create(&fin, NULL, ti_b_finisher, &bp);
+    int have_fin = bp.r && x && m && !pthread_create(&fin, NULL, ti_b_finisher, &bp);
     if (!have_fin) w->failed = 1;
-    for (size_t k = 0; k < total && !w->failed; k++) {
-        ti_item it = {0, 0, 0, 0};
-        size_t ti_n = 0;
-        uint32_t col = mine[k]->col;
-        if (ti_queue_pop(w->q, &it)) { w->failed = 1; break; }
-        if (pmsg_unpack(it.raw, it.len, &it.vec, &ti_n, &it.val) || ti_n != n) { fprintf(stderr, "Could not decode message from TI\n"); w->failed = 1; }
-        else if (lgc_p1_mask(w->p1, &col, 1, it.vec, +1, tmp)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }        /* b + x */
-        else if (send_pmsg(w->self, to, tmp, n, 0)) { fprintf(stderr, "Could not send message to party A (%d)\n", w->peer); w->failed = 1; }
-        free(it.raw); free(it.vec);
+    for (size_t k = 0; k < total && !w->failed;) {
+        size_t nb = 0;
+        while (nb < kTiBatch && k + nb < total) {
+            ti_item it = {0, 0, 0, 0};
+            size_t ti_n = 0;
+            if (nb == 0 ? ti_queue_pop(w->q, &it) : ti_queue_try_pop(w->q, &it)) { if (nb == 0) w->failed = 1; break; }
+            if (pmsg_unpack_into(it.raw, it.len, x + nb * n, n, &ti_n, &it.val) || ti_n != n) { fprintf(stderr, "Could not decode message from TI\n"); w->failed = 1; }
+            free(it.raw);
+            if (w->failed) break;
+            cols[nb] = mine[k + nb]->col;
+            bp.r[k + nb] = it.val;
+            nb++;
+        }
+        if (w->failed || !nb) break;
+        if (lgc_p1_mask(w->p1, cols, nb, x, +1, m)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; break; }        /* b + x */
+        for (size_t i = 0; i < nb && !w->failed; i++)
+            if (send_pmsg(w->self, to, m + i * n, n, 0)) { fprintf(stderr, "Could not send message to party A (%d)\n", w->peer); w->failed = 1; }
         if (w->failed) break;
-        bp.r[k] = it.val;
-        pthread_mutex_lock(&bp.mu); bp.sent = k + 1; pthread_cond_broadcast(&bp.cv); pthread_mutex_unlock(&bp.mu);
+        k += nb;
+        pthread_mutex_lock(&bp.mu); bp.sent = k; pthread_cond_broadcast(&bp.cv); pthread_mutex_unlock(&bp.mu);
     }
     pthread_mutex_lock(&bp.mu); bp.stop = 1; pthread_cond_broadcast(&bp.cv); pthread_mutex_unlock(&bp.mu);
     if (have_fin) pthread_join(fin, NULL);
     pthread_mutex_destroy(&bp.mu); pthread_cond_destroy(&bp.cv);
-    free(bp.r); free(tmp);
+    free(bp.r); lgc_host_free(x); lgc_host_free(m);
     return w->failed;
 }
 
 /* Party a of a run of pairs with one peer, as two stages: a prefetch thread takes the TI's message
- * and party b's message off the queues / socket and decodes both, while this thread runs the fused
- * device step and sends the reply.  Same bytes, same order on the socket. */
-enum { kTiAhead = 4 };
-typedef struct { uint64_t *y, *in, sub; } ti_a_input;
+ * and party b's message off the queue / socket and decodes both into a ring of page-locked slots, while
+ * this thread runs the fused device step over the slots that are ready and sends the replies. */
 typedef struct {
     ti_worker *w;
     size_t total;
-    ti_a_input slot[kTiAhead];
+    uint64_t *y, *in;          /* kTiSlots x n words each, page-locked */
+    uint64_t sub[kTiSlots];
     size_t produced, consumed;
     int stop;
     pthread_mutex_t mu;
@@ -476,32 +519,30 @@ static void *ti_a_prefetch(void *arg) {
     ti_worker *w = ap->w;
     const size_t n = w->n;
     const int to = w->peer + 1;
+    uint8_t *raw = NULL; size_t rawcap = 0;
     for (size_t k = 0; k < ap->total; k++) {
+        pthread_mutex_lock(&ap->mu);
+        while (ap->produced - ap->consumed == kTiSlots && !ap->stop) pthread_cond_wait(&ap->cv, &ap->mu);
+        int stop = ap->stop;
+        pthread_mutex_unlock(&ap->mu);
+        if (stop) break;
+        const size_t slot = k % kTiSlots;
         ti_item it = {0, 0, 0, 0};
-        ti_a_input x = {0, 0, 0};
-        size_t ti_n = 0, in_n = 0;
+        size_t ti_n = 0;
         uint64_t inval = 0;
         int bad = 0;
         if (ti_queue_pop(w->q, &it)) bad = 1;
-        else if (pmsg_unpack(it.raw, it.len, &it.vec, &ti_n, &it.val) || ti_n != n) { fprintf(stderr, "Could not decode message from TI\n"); bad = 1; }
-        else if (recv_pmsg_timed(w->self, to, &x.in, &in_n, &inval) || in_n != n) { fprintf(stderr, "Could not receive message from party B (%d)\n", w->peer); bad = 1; }
+        else if (pmsg_unpack_into(it.raw, it.len, ap->y + slot * n, n, &ti_n, &it.val) || ti_n != n) { fprintf(stderr, "Could not decode message from TI\n"); bad = 1; }
+        else if (recv_pmsg_into_timed(w->self, to, &raw, &rawcap, ap->in + slot * n, n, &inval)) { fprintf(stderr, "Could not receive message from party B (%d)\n", w->peer); bad = 1; }
         free(it.raw);
-        x.y = it.vec; x.sub = it.val;
         pthread_mutex_lock(&ap->mu);
-        while (!bad && ap->produced - ap->consumed == kTiAhead && !ap->stop) pthread_cond_wait(&ap->cv, &ap->mu);
-        if (bad || ap->stop) {
-            ap->stop = 1;
-            if (bad) w->failed = 1;
-            pthread_cond_broadcast(&ap->cv);
-            pthread_mutex_unlock(&ap->mu);
-            free(x.y); free(x.in);
-            return NULL;
-        }
-        ap->slot[ap->produced % kTiAhead] = x;
-        ap->produced++;
+        if (bad) { ap->stop = 1; w->failed = 1; }
+        else { ap->sub[slot] = it.val; ap->produced++; }
         pthread_cond_broadcast(&ap->cv);
         pthread_mutex_unlock(&ap->mu);
+        if (bad) break;
     }
+    free(raw);
     return NULL;
 }
 static int ti_worker_a_pipelined(ti_worker *w, const ti_pair **mine, size_t total) {
@@ -510,30 +551,37 @@ static int ti_worker_a_pipelined(ti_worker *w, const ti_pair **mine, size_t tota
     ti_a_pipe ap;
     memset(&ap, 0, sizeof ap);
     ap.w = w; ap.total = total;
+    ap.y = lgc_host_alloc((size_t)kTiSlots * n * 8); ap.in = lgc_host_alloc((size_t)kTiSlots * n * 8);
+    uint64_t *out = lgc_host_alloc((size_t)kTiBatch * n * 8);
+    uint32_t cols[kTiBatch]; uint64_t shares[kTiBatch], sub[kTiBatch];
     pthread_mutex_init(&ap.mu, NULL); pthread_cond_init(&ap.cv, NULL);
-    uint64_t *tmp = malloc(n * 8);
     pthread_t pre;
-    int have = tmp && !pthread_create(&pre, NULL, ti_a_prefetch, &ap);
+    int have = ap.y && ap.in && out && !pthread_create(&pre, NULL, ti_a_prefetch, &ap);
     if (!have) w->failed = 1;
-    for (size_t k = 0; k < total && !w->failed; k++) {
+    for (size_t k = 0; k < total && !w->failed;) {
         pthread_mutex_lock(&ap.mu);
         while (ap.produced == ap.consumed && !ap.stop) pthread_cond_wait(&ap.cv, &ap.mu);
-        int empty = ap.produced == ap.consumed;
-        ti_a_input x = ap.slot[ap.consumed % kTiAhead];
+        size_t avail = ap.produced - ap.consumed;
         pthread_mutex_unlock(&ap.mu);
-        if (empty) { w->failed = 1; break; }
-        uint64_t share = 0;
-        if (lgc_p1_ti_a(w->p1, mine[k]->col, x.y, x.in, x.sub, tmp, &share)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; }   /* a - y and <b+x, y> - (xy - r) */
-        else if (send_pmsg(w->self, to, tmp, n, 0)) { fprintf(stderr, "Could not send message to party B (%d)\n", w->peer); w->failed = 1; }
-        free(x.y); free(x.in);
-        pthread_mutex_lock(&ap.mu); ap.consumed++; pthread_cond_broadcast(&ap.cv); pthread_mutex_unlock(&ap.mu);
-        if (!w->failed) *mine[k]->dst = share;
+        if (!avail) { w->failed = 1; break; }
+        const size_t slot = k % kTiSlots;
+        size_t nb = avail < kTiBatch ? avail : kTiBatch;
+        if (nb > kTiSlots - slot) nb = kTiSlots - slot;          /* a batch is contiguous in the ring */
+        for (size_t i = 0; i < nb; i++) { cols[i] = mine[k + i]->col; sub[i] = ap.sub[slot + i]; }
+        /* a - y and <b+x, y> - (xy - r) for the whole batch */
+        if (lgc_p1_ti_a_batch(w->p1, cols, nb, ap.y + slot * n, ap.in + slot * n, sub, out, shares)) { fprintf(stderr, "%s\n", lgc_last_error()); w->failed = 1; break; }
+        for (size_t i = 0; i < nb && !w->failed; i++)
+            if (send_pmsg(w->self, to, out + i * n, n, 0)) { fprintf(stderr, "Could not send message to party B (%d)\n", w->peer); w->failed = 1; }
+        if (w->failed) break;
+        for (size_t i = 0; i < nb; i++) *mine[k + i]->dst = shares[i];
+        k += nb;
+        pthread_mutex_lock(&ap.mu); ap.consumed = k; pthread_cond_broadcast(&ap.cv); pthread_mutex_unlock(&ap.mu);
     }
     pthread_mutex_lock(&ap.mu); ap.stop = 1; pthread_cond_broadcast(&ap.cv); pthread_mutex_unlock(&ap.mu);
+    if (w->failed) ti_queue_close(w->q);                         /* the prefetch thread may be blocked in a pop */
     if (have) pthread_join(pre, NULL);
-    for (; ap.consumed < ap.produced; ap.consumed++) { free(ap.slot[ap.consumed % kTiAhead].y); free(ap.slot[ap.consumed % kTiAhead].in); }
     pthread_mutex_destroy(&ap.mu); pthread_cond_destroy(&ap.cv);
-    free(tmp);
+    lgc_host_free(ap.y); lgc_host_free(ap.in); lgc_host_free(out);
     return w->failed;
 }
 
