@@ -427,7 +427,10 @@ def main():
         e2e, ring = None, None
         if world == 1 and not args.no_e2e:
             e2e = [phase12_wall(np, "c2", 1000, 20, [0, 10], "cholesky", 0, ["--table_ring"], device_index),
-                   phase12_wall(np, "c3-ti", 10000, 100, [0, 50], "cgd", 15, ["--table_ring"], device_index)]
+                   phase12_wall(np, "c3-ti", 10000, 100, [0, 50], "cgd", 15, ["--table_ring"], device_index),
+                   # BASELINE config 3 proper: --use_ot phase 1 (1.6e9 extended OTs); both providers on this node,
+                   # so u / y of the extension stay in HBM (--ot_ring = --use_ot through device rings)
+                   phase12_wall(np, "c3-ot", 10000, 100, [0, 50], "cgd", 15, ["--ot_ring", "--table_ring"], device_index)]
             if (w, p) == (64, 56):
                 ring = two_process_ring(np, d, iters, p, Af, bf, gates, device_index)
         refg = ref_equiv_gates(d, iters) if w == 64 else None

@@ -231,6 +231,16 @@ int lgc_party_evaluate(lgc_party *p, size_t launch, const uint8_t *tables_in);
 int lgc_party_decode_bits(lgc_party *p, uint64_t *dec_out);       /* garbler -> evaluator */
 int lgc_party_finish(lgc_party *p, const uint64_t *garbler_dec, int64_t *beta, int64_t *trace, int64_t *inputs);
 
+/* Device buffers for C host code: zero-filled device memory, optionally with a 64-byte hipIpc handle that a
+ * peer process on the same node opens (same GPU, or an xGMI peer) -- the hand-off of the OT extension's
+ * u / y between two data providers without the socket (bin/linreg --ot_ring), next to the table ring. */
+int lgc_dev_alloc(int device, size_t bytes, void **ptr, uint8_t handle_out[64] /* or NULL */);
+void lgc_dev_free(void *ptr);
+int lgc_dev_open(int device, const uint8_t handle[64], void **ptr);
+void lgc_dev_close(void *ptr);
+int lgc_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
+int lgc_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+
 /* ------------------------------------------------------------------ phase 1 */
 /* Quantised data of one data provider, resident on the device (src/phase1.c:473-476 result). */
 typedef struct lgc_p1 lgc_p1;

@@ -329,3 +329,50 @@ extern "C" int lgc_party_finish(lgc_party *p, const uint64_t *garbler_dec, int64
         for (size_t i = 0; i < P.T + P.d; i++) inputs[i] = val(P.rv_ab + (uint32_t)i);
     return LGC_OK;
 }
+
+// ---------------------------------------------------------------- device buffers for host code (C)
+// The host binaries are plain C: these give them device memory they can hand to the device-I/O forms of
+// the OT calls (lgc_ot_*_set_device_io), and a hipIpc handle so that a peer process on the same node maps
+// the buffer instead of receiving its bytes through a socket (u / y of the OT extension between two data
+// providers: bin/linreg --ot_ring).  Allocations are zero-filled: a peer never sees stale HBM.
+extern "C" int lgc_dev_alloc(int device, size_t bytes, void **ptr, uint8_t handle_out[64]) {
+    if (!ptr || !bytes) return lgc_fail(LGC_EINVAL, "null argument");
+    int rc = lgc_need_device(device);
+    if (rc) return rc;
+    void *p = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return lgc_fail(LGC_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess && handle_out) {
+        hipIpcMemHandle_t h;
+        e = hipIpcGetMemHandle(&h, p);
+        if (e == hipSuccess) memcpy(handle_out, &h, 64);
+    }
+    if (e != hipSuccess) { (void)hipFree(p); return lgc_fail(LGC_EHIP, "lgc_dev_alloc: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e)); }
+    *ptr = p;
+    return LGC_OK;
+}
+extern "C" void lgc_dev_free(void *ptr) { if (ptr) (void)hipFree(ptr); }
+extern "C" int lgc_dev_open(int device, const uint8_t handle[64], void **ptr) {
+    if (!handle || !ptr) return lgc_fail(LGC_EINVAL, "null argument");
+    int rc = lgc_need_device(device);
+    if (rc) return rc;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    void *p = 0;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return lgc_fail(LGC_EHIP, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+    *ptr = p;
+    return LGC_OK;
+}
+extern "C" void lgc_dev_close(void *ptr) { if (ptr) (void)hipIpcCloseMemHandle(ptr); }
+extern "C" int lgc_dev_upload(void *dst_dev, const void *src_host, size_t bytes) {
+    if (!dst_dev || !src_host) return lgc_fail(LGC_EINVAL, "null argument");
+    RCHK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return LGC_OK;
+}
+extern "C" int lgc_dev_download(void *dst_host, const void *src_dev, size_t bytes) {
+    if (!dst_host || !src_dev) return lgc_fail(LGC_EINVAL, "null argument");
+    RCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return LGC_OK;
+}

@@ -737,6 +737,83 @@ static void *ot_recv_starter(void *arg) {
     return NULL;
 }
 
+/* OT mode with both data providers on one node (--ot_ring): u and y of the OT extension stay in HBM.  The
+ * receiver owns a two-slot device ring for u, the sender one for y; each maps the other's through hipIpc
+ * and only one-byte tokens cross the socket: receiver -> sender 'U' (u of the next batch is complete) and
+ * 'A' (batch finished: its y slot and u slot are free again), sender -> receiver 'Y'.  Two batches in
+ * flight.  Same OT transcripts as the socket path (the bytes just do not travel). */
+static int ot_ring_token_send(node *self, int to, char t) { return net_send(self, to, &t, 1); }
+static int ot_ring_token_recv(node *self, int from, char *t) { return net_recv(self, from, t, 1); }
+static int ot_pair_ring(node *self, int peer_party, int i_am_sender, lgc_ot_sender *S, lgc_ot_receiver *R, int device,
+                        const int64_t *Xq, const int64_t *yq, size_t n, size_t d, int w1,
+                        const size_t *rows, size_t npairs, size_t per, uint64_t *shares) {
+    const uint64_t mmax = (uint64_t)per * n * (uint64_t)w1;
+    const size_t ub = lgc_ot_u_bytes(mmax), yb = (size_t)mmax * 8, vb = per * n * 8;
+    const size_t nbatch = (npairs + per - 1) / per;
+    void *mine = 0, *theirs = 0, *dvals = 0, *dsh = 0;
+    uint8_t hmine[64], htheirs[64];
+    uint64_t *vals = lgc_host_alloc(vb);
+    int rc = 1;
+    if (!vals) goto out;
+    if (lgc_dev_alloc(device, 2 * (i_am_sender ? yb : ub), &mine, hmine) || lgc_dev_alloc(device, 2 * vb, &dvals, NULL) ||
+        lgc_dev_alloc(device, per * 8 + 8, &dsh, NULL)) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
+    if (send_blob(self, peer_party, hmine, 64) || recv_blob(self, peer_party, htheirs, 64)) goto out;
+    if (lgc_dev_open(device, htheirs, &theirs)) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
+    if (i_am_sender) {
+        if (lgc_ot_sender_set_device_io(S, 1)) goto out;
+        size_t have_u = 0, have_a = 0;
+        for (size_t k = 0; k < nbatch; k++) {
+            const size_t q0 = k * per, nb = npairs - q0 < per ? npairs - q0 : per;
+            for (size_t q = 0; q < nb; q++) column_of(Xq, yq, n, d, rows[q0 + q], vals + q * n);
+            if (lgc_dev_upload((char *)dvals + (k & 1) * vb, vals, nb * n * 8)) goto out;
+            while (have_u <= k || (k >= 2 && have_a + 2 <= k)) {        /* u of batch k is there, y slot of batch k - 2 is free */
+                char t = 0;
+                if (ot_ring_token_recv(self, peer_party, &t)) goto out;
+                if (t == 'U') have_u++; else if (t == 'A') have_a++; else goto out;
+            }
+            if (lgc_ot_gilboa_send(S, (const uint64_t *)((char *)dvals + (k & 1) * vb), nb, n, w1, (const uint8_t *)theirs + (k & 1) * ub,
+                                   (uint64_t *)((char *)mine + (k & 1) * yb), (uint64_t *)dsh)) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
+            if (lgc_dev_download(shares + q0, dsh, nb * 8)) goto out;
+            if (w1 == 32) for (size_t q = 0; q < nb; q++) shares[q0 + q] &= 0xffffffffull;
+            if (ot_ring_token_send(self, peer_party, 'Y')) goto out;
+        }
+        while (have_a < nbatch) {                                        /* the receiver is done with every y slot */
+            char t = 0;
+            if (ot_ring_token_recv(self, peer_party, &t)) goto out;
+            if (t == 'A') have_a++; else if (t != 'U') goto out;
+        }
+    } else {
+        if (lgc_ot_receiver_set_device_io(R, 1)) goto out;
+        size_t started = 0;
+        for (size_t k = 0; k < nbatch + 2; k++) {
+            if (k >= 2) {                                                /* finish batch k - 2 */
+                const size_t f = k - 2, q0 = f * per, nb = npairs - q0 < per ? npairs - q0 : per;
+                char t = 0;
+                if (ot_ring_token_recv(self, peer_party, &t) || t != 'Y') goto out;
+                if (lgc_ot_gilboa_recv_finish(R, (const uint64_t *)((char *)theirs + (f & 1) * yb), (uint64_t *)dsh)) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
+                if (lgc_dev_download(shares + q0, dsh, nb * 8)) goto out;
+                if (w1 == 32) for (size_t q = 0; q < nb; q++) shares[q0 + q] &= 0xffffffffull;
+                if (ot_ring_token_send(self, peer_party, 'A')) goto out;
+            }
+            if (started < nbatch) {                                      /* start the next batch: its slots are free now */
+                const size_t q0 = started * per, nb = npairs - q0 < per ? npairs - q0 : per;
+                for (size_t q = 0; q < nb; q++) column_of(Xq, yq, n, d, rows[q0 + q], vals + q * n);
+                if (lgc_dev_upload((char *)dvals + (started & 1) * vb, vals, nb * n * 8)) goto out;
+                if (lgc_ot_gilboa_recv_start(R, (const uint64_t *)((char *)dvals + (started & 1) * vb), nb, n, w1,
+                                             (uint8_t *)mine + (started & 1) * ub)) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
+                if (ot_ring_token_send(self, peer_party, 'U')) goto out;
+                started++;
+            }
+        }
+    }
+    rc = 0;
+out:
+    if (theirs) lgc_dev_close(theirs);
+    lgc_dev_free(mine); lgc_dev_free(dvals); lgc_dev_free(dsh);
+    lgc_host_free(vals);
+    return rc;
+}
+
 int run_party(node *self, config *c, int precision, int precision_p2, int w1, int w2, int use_ot, int device,
                      uint64_t **res_A, uint64_t **res_b) {
     tune_malloc();
@@ -880,7 +957,10 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
                     LGC(lgc_ot_receiver_create(&R, device, s0, s1));
                 }
                 double ot_t[4] = {0, 0, 0, 0};
-                if (i_am_sender) {
+                if (use_ot & 2) {                         /* --ot_ring: u / y through device rings (same node) */
+                    check(!ot_pair_ring(self, peer + 1, i_am_sender, S, R, device, Xq, yq, n, d, w1, i_am_sender ? ri : rj, npairs, per, shares),
+                          "OT-mode aggregation failed");
+                } else if (i_am_sender) {
                     ot_send_ctx sx;
                     memset(&sx, 0, sizeof sx);
                     sx.self = self; sx.peer = peer + 1; sx.n = n; sx.w1 = w1; sx.npairs = npairs; sx.per = per;

@@ -45,12 +45,14 @@ def _write_instance(path, n, d, starts, seed):
     return X, y
 
 
-def test_config3_use_ot_full_size(tmp_path, oracle):
-    """bin/linreg <file> 56 <party> cgd 15 0.001 --use_ot --table_ring with n = 1e4, d = 100, P = 2"""
+@pytest.mark.parametrize("ot", ["--use_ot", "--ot_ring"])
+def test_config3_use_ot_full_size(tmp_path, oracle, ot):
+    """bin/linreg <file> 56 <party> cgd 15 0.001 --use_ot --table_ring with n = 1e4, d = 100, P = 2
+    (--ot_ring: the 39 GB of OT-extension messages between the two providers stay in HBM)"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     path = str(tmp_path / "c3.in")
     _write_instance(path, 10000, 100, [0, 50], 3)
-    outs = _run_all(path, 2, ["56", "cgd", "15", "0.001", "--use_ot", "--table_ring"], timeout=900)
+    outs = _run_all(path, 2, ["56", "cgd", "15", "0.001", ot, "--table_ring"], timeout=900)
     got = re.findall("-?[0-9]+\\.[0-9]+", outs[1].strip().splitlines()[-1])
     beta = oracle.linreg_file(path, 56, -1, 64, 64, 2, 15, 0.001)
     assert got == ["%.15f" % (int(v) / 2.0 ** 56) for v in beta]

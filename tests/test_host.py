@@ -118,7 +118,7 @@ README_RESULT = ["0.984331027786964", "0.792399824970372", "0.754117840176144", 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--use_ot"], ["--table_ring"]], ids=["ti", "ot", "ti-ring"])
+@pytest.mark.parametrize("extra", [[], ["--use_ot"], ["--table_ring"], ["--ot_ring", "--table_ring"]], ids=["ti", "ot", "ti-ring", "ot-ring"])
 def test_five_process_readme_example(tmp_path, golden_dir, extra):
     """bin/linreg examples/readme_example.in 56 $party cgd 10 0.001 (README.md:81) -> README.md:87"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
