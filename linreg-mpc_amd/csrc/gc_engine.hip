@@ -66,29 +66,46 @@ int lgc_upload_constants() {
     return LGC_OK;
 }
 
-// host-side hash with the fixed key (used to derive R from the seed)
-static Lbl host_hash(Lbl x, uint64_t tweak) {
+// Garbler randomness.  The global offset R and the zero-labels of the input wires are AES-128 in counter mode
+// KEYED BY THE SEED (its own key schedule, as the OT column PRG and the TI generator do) -- not the public
+// fixed-key gate hash evaluated at seed-dependent points, which would let one guess of the seed be tested
+// against every observed label at once.  Block = (index lo, index hi, 0, domain): domain 1 = input label of
+// (word id, lane), domain 2 = R.
+struct SeedKeys { uint32_t rk[44]; };
+SeedKeys seed_keys(const Lbl &seed) {
+    AesTables t;
+    aes_build_tables(t, reinterpret_cast<const uint8_t *>(&seed));
+    SeedKeys k;
+    memcpy(k.rk, t.rk, sizeof(k.rk));
+    return k;
+}
+Lbl derive_R(const Lbl &seed) {
+    SeedKeys k = seed_keys(seed);
     HostTab ht = {tables().te0};
-    Lbl out;
-    hash_n<1, HostTab>(ht, tables().rk, &x, &tweak, &out);
-    return out;
+    uint32_t st[1][4] = {{0u, 0u, 0u, 2u}};
+    aes_encrypt_n<1, HostTab>(ht, k.rk, st);
+    Lbl R = {st[0][0] | 1u, st[0][1], st[0][2], st[0][3]};     // point-and-permute: lsb(R) = 1
+    return R;
 }
 
 // ------------------------------------------------------------------ kernels
-// fresh input labels: zero-label from a seeded PRG, evaluator side gets the
+// fresh input labels: zero-label from the seeded PRG, evaluator side gets the
 // label of the actual bit (what the OT / direct transfer would deliver)
 __global__ void __launch_bounds__(256)
-gc_input_kernel(Lbl *wordsG, Lbl *wordsE, const uint64_t *vals, uint32_t base, uint32_t n, Lbl R, Lbl seed, int w) {
+gc_input_kernel(Lbl *wordsG, Lbl *wordsE, const uint64_t *vals, uint32_t base, uint32_t n, Lbl R, SeedKeys keys, int w) {
     __shared__ uint32_t lds_te0[kLdsTabWords];
-    lds_tab_fill(lds_te0);
+    __shared__ uint32_t srk[44];
+    if (threadIdx.x < 44) srk[threadIdx.x] = keys.rk[threadIdx.x];
+    lds_tab_fill(lds_te0);                 // ends with a barrier
     const int lane = threadIdx.x & 63;
     const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (k >= n) return;
     LdsTab lt = lds_tab_make(lds_te0);
     const uint32_t id = base + k;
-    uint64_t tw = 0x8000000000000000ull | ((uint64_t)id * 64 + (uint64_t)lane);
-    Lbl z;
-    hash_n<1, LdsTab>(lt, c_rk, &seed, &tw, &z);
+    const uint64_t idx = (uint64_t)id * 64 + (uint64_t)lane;
+    uint32_t st[1][4] = {{(uint32_t)idx, (uint32_t)(idx >> 32), 0u, 1u}};
+    aes_encrypt_n<1, LdsTab>(lt, srk, st);
+    Lbl z = {st[0][0], st[0][1], st[0][2], st[0][3]};
     if (lane >= w) z = lzero();
     uint32_t bit = vals ? (uint32_t)(vals[k] >> lane) & 1u : 0u;
     if (lane >= w) bit = 0;
@@ -359,8 +376,7 @@ static int solver_create(lgc_solver **out, int device, const lgc_system *sys, co
         build(s->P, sys);
     }
     memcpy(&s->seed, seed, 16);
-    s->R = host_hash(s->seed, 0x52ull << 56);   // 'R'
-    s->R.x |= 1u;                               // point-and-permute: lsb(R) = 1
+    s->R = derive_R(s->seed);
     const Program &P = s->P;
     size_t wbytes = (size_t)P.n_words * 64 * sizeof(Lbl);
     size_t nin = P.nshares * (P.T + P.d);
@@ -452,7 +468,7 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
     HIPCHK(hipMemsetAsync(s->decE, 0, (P.n_reveal + 1) * sizeof(uint64_t), sG));
     if (!pre) {   // fresh input labels (one set for all circuits of a sweep: they share the prefix)
         dim3 grid((unsigned)((nin + 3) / 4)), block(256);
-        hipLaunchKernelGGL(gc_input_kernel, grid, block, 0, sG, s->wordsG, s->wordsE, s->vals, P.in_base, (uint32_t)nin, s->R, s->seed, P.w);
+        hipLaunchKernelGGL(gc_input_kernel, grid, block, 0, sG, s->wordsG, s->wordsE, s->vals, P.in_base, (uint32_t)nin, s->R, seed_keys(s->seed), P.w);
         HIPCHK(hipGetLastError());
     }
     if (!profile) {   // the evaluator chain starts after the input labels are in place
@@ -566,7 +582,7 @@ extern "C" int lgc_solver_prefix_garble(lgc_solver *s) {
     HIPCHK(hipMemsetAsync(s->wordsG, 0, sbytes, s->stream));
     HIPCHK(hipMemsetAsync(s->wordsE, 0, sbytes, s->stream));
     hipLaunchKernelGGL(gc_input_kernel, dim3((unsigned)((nin + 3) / 4)), dim3(256), 0, s->stream, s->wordsG, s->wordsE, s->vals,
-                       P.in_base, (uint32_t)nin, s->R, s->seed, P.w);
+                       P.in_base, (uint32_t)nin, s->R, seed_keys(s->seed), P.w);
     HIPCHK(hipGetLastError());
     for (uint32_t i = 0; i < P.prefix_launches; i++) {
         Lbl *tab = reinterpret_cast<Lbl *>(reinterpret_cast<char *>(s->tab) + s->tab_off[i]);

@@ -55,7 +55,10 @@ static constexpr uint32_t kQuadOnePerCu = GC_QUAD_ONE_PER_CU;
 // small d): they run in the 4-wave mode instead of the throughput-oriented MAC kernel
 static constexpr uint32_t kNarrowMac = 1024;
 // MAC launches of at least two garbler rounds get the chip to themselves (GC_MAC_EXCLUSIVE)
-static constexpr uint32_t kExclusiveMac = 8192;
+#ifndef GC_EXCLUSIVE_MAC_RECS
+#define GC_EXCLUSIVE_MAC_RECS 8192
+#endif
+static constexpr uint32_t kExclusiveMac = GC_EXCLUSIVE_MAC_RECS;
 static constexpr int kTpbTabfill = 1024;
 
 // MAC launches: one workgroup per CU and every record of a launch takes the same time, so a launch runs

@@ -118,8 +118,7 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
     memset(&p->R, 0, sizeof(Lbl)); memset(&p->seed, 0, sizeof(Lbl));
     if (role == LGC_ROLE_GARBLER) {
         memcpy(&p->seed, seed, 16);
-        p->R = host_hash(p->seed, 0x52ull << 56);
-        p->R.x |= 1u;
+        p->R = derive_R(p->seed);
     }
     const Program &P = p->P;
     size_t wbytes = (size_t)P.n_words * 64 * sizeof(Lbl);
@@ -135,7 +134,7 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
     if (role == LGC_ROLE_GARBLER) {   // fresh zero-labels for every input word
         size_t nin = P.nshares * (P.T + P.d);
         hipLaunchKernelGGL(gc_input_kernel, dim3((unsigned)((nin + 3) / 4)), dim3(256), 0, 0, p->words, (Lbl *)0,
-                           (const uint64_t *)0, P.in_base, (uint32_t)nin, p->R, p->seed, P.w);
+                           (const uint64_t *)0, P.in_base, (uint32_t)nin, p->R, seed_keys(p->seed), P.w);
         RCHK(hipDeviceSynchronize());
         p->labels_ready = true;
     }

@@ -192,30 +192,38 @@ uint64_t gcc_plain_op(uint32_t op, int w, int p, uint32_t c, int paired, const u
     return steps;
 }
 
+// AES-128 under the seed's own key schedule (mirror of seed_keys / derive_R / gc_input_kernel in gc_engine.hip)
+static void seed_rk(const uint8_t seed[16], __m128i rk[11]) {
+    AesTables t;
+    aes_build_tables(t, seed);
+    for (int i = 0; i < 11; i++) rk[i] = _mm_loadu_si128((const __m128i *)&t.rk[4 * i]);
+}
+static inline __m128i aes_with(const __m128i rk[11], __m128i s) {
+    s = _mm_xor_si128(s, rk[0]);
+    for (int r = 1; r < 10; r++) s = _mm_aesenc_si128(s, rk[r]);
+    return _mm_aesenclast_si128(s, rk[10]);
+}
 void gcc_derive_R(const uint8_t seed[16], uint8_t out[16]) {
     init();
-    __m128i s = _mm_loadu_si128((const __m128i *)seed);
-    __m128i k = hprep(s, 0x52ull << 56);
-    __m128i h[1] = {k};
-    aesni_n<1>(h);
-    h[0] = _mm_xor_si128(h[0], k);
-    h[0] = _mm_or_si128(h[0], _mm_set_epi32(0, 0, 0, 1));
-    _mm_storeu_si128((__m128i *)out, h[0]);
+    __m128i rk[11];
+    seed_rk(seed, rk);
+    __m128i h = aes_with(rk, _mm_set_epi32(2, 0, 0, 0));
+    h = _mm_or_si128(h, _mm_set_epi32(0, 0, 0, 1));
+    _mm_storeu_si128((__m128i *)out, h);
 }
 
 // mirror of gc_input_kernel (gc_engine.hip)
 void gcc_input_labels(const uint8_t seed[16], const uint8_t R[16], const uint64_t *vals, uint32_t base, uint32_t n,
                       int w, uint8_t *wordsG, uint8_t *wordsE) {
     init();
-    __m128i s = _mm_loadu_si128((const __m128i *)seed), r = _mm_loadu_si128((const __m128i *)R);
+    __m128i rk[11];
+    seed_rk(seed, rk);
+    __m128i r = _mm_loadu_si128((const __m128i *)R);
     for (uint32_t k = 0; k < n; k++) {
         uint32_t id = base + k;
         for (int lane = 0; lane < 64; lane++) {
-            uint64_t tw = 0x8000000000000000ull | ((uint64_t)id * 64 + (uint64_t)lane);
-            __m128i kk = hprep(s, tw);
-            __m128i h[1] = {kk};
-            aesni_n<1>(h);
-            __m128i z = _mm_xor_si128(h[0], kk);
+            uint64_t idx = (uint64_t)id * 64 + (uint64_t)lane;
+            __m128i z = aes_with(rk, _mm_set_epi32(1, 0, (int)(uint32_t)(idx >> 32), (int)(uint32_t)idx));
             int bit = (int)((vals[k] >> lane) & 1);
             if (lane >= w) { z = _mm_setzero_si128(); bit = 0; }
             _mm_storeu_si128((__m128i *)wordsG + (size_t)id * 64 + lane, z);
