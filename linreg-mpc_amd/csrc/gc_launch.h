@@ -51,6 +51,12 @@ static constexpr uint32_t kQuadOnePerCu = GC_QUAD_ONE_PER_CU;
 #ifndef GC_CRIT
 #define GC_CRIT 1
 #endif
+// ... and so do 4-wave launches of up to this many records (two workgroups per CU): their record kernel is
+// still paced by the dependent chain, and the table pass runs beside the small launches that follow
+#ifndef GC_CRIT_MAX_RECS
+#define GC_CRIT_MAX_RECS 256   /* 1024 measured: no gain on d=500 CGD-15 nor on 8- and 64-circuit sweep blocks */
+#endif
+static constexpr uint32_t kCritMaxRecs = GC_CRIT_MAX_RECS;
 // MAC launches with fewer records than this are latency-bound too (Cholesky / LDL^T stages at
 // small d): they run in the 4-wave mode instead of the throughput-oriented MAC kernel
 static constexpr uint32_t kNarrowMac = 1024;
@@ -95,7 +101,7 @@ static inline unsigned gc_mac_waves(uint32_t nrec, unsigned lo, unsigned hi) {
 static inline bool gc_launch_is_crit(const Launch &L) {
     const bool mac = L.mac_only && L.nrec >= kNarrowMac;
     const bool wide = L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps;
-    return GC_CRIT && !mac && !wide && L.nrec > 0 && L.nrec <= kQuadOnePerCu && L.steps > 0;
+    return GC_CRIT && !mac && !wide && L.nrec > 0 && L.nrec <= kCritMaxRecs && L.steps > 0;
 }
 // the table pass of a critical-path launch; it only has to finish before the launch is EVALUATED, so the
 // co-located solver runs it on a side stream while the garbler chain moves on to the next launch
@@ -124,6 +130,9 @@ static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words
                            recs + L.first_rec, L.nrec, words, tab, dec, L.step0, R, w, p);
     } else if (L.nrec <= kQuadOnePerCu) {
         hipLaunchKernelGGL((gc_exec_kernel<G, true, 4, 256, G && GC_CRIT>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec,
+                           L.nrec, words, tab, dec, L.step0, R, w, p);
+    } else if (L.nrec <= kCritMaxRecs) {
+        hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256, G && GC_CRIT>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec,
                            L.nrec, words, tab, dec, L.step0, R, w, p);
     } else {
         hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec, L.nrec, words,
