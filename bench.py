@@ -235,7 +235,9 @@ def main():
         import torch.distributed as dist
         if backend == "nccl":
             try:
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+                import datetime
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index),
+                                        timeout=datetime.timedelta(seconds=600))
                 dist.barrier()                       # creates the RCCL communicator now, not inside the timed region
             except Exception as e:                   # the data path has no collective: a CPU barrier is enough
                 sys.stderr.write("bench.py: RCCL init failed (%s); using gloo for the barrier\n" % e)
