@@ -234,20 +234,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            try:
-                import datetime
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index),
-                                        timeout=datetime.timedelta(seconds=600))
-                dist.barrier()                       # creates the RCCL communicator now, not inside the timed region
-            except Exception as e:                   # the data path has no collective: a CPU barrier is enough
-                sys.stderr.write("bench.py: RCCL init failed (%s); using gloo for the barrier\n" % e)
-                try:
-                    dist.destroy_process_group()
-                except Exception:
-                    pass
-                backend = "gloo"
-                import datetime
-                dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
+            # no per-rank fallback: a rank that silently switched to gloo while the others stay in the RCCL
+            # group would hang the job.  An RCCL failure ends this rank with a non-zero exit code;
+            # LGC_BENCH_BACKEND=gloo is the explicit choice for dry runs (N ranks on one GPU).
+            import datetime
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index),
+                                    timeout=datetime.timedelta(seconds=600))
+            dist.barrier()                           # creates the RCCL communicator now, not inside the timed region
         else:
             dist.init_process_group(backend=backend)
 
