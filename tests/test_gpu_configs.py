@@ -2,11 +2,10 @@
 solve -- every party a separate process where the config says so (bin/linreg on this box, one GPU).
 
   C3  n = 1e4, d = 100, 2 data providers, CGD-15, 64-bit, --use_ot phase 1        (Result line == oracle)
-  C4  d = 500, 5 data providers, CGD-20, phase 1 in 64 bits / phase 2 in 32 bits (--prec_phase2=30),
-      TI mode with a pinned TI seed: exact at SHARE level -- every share is shifted on its own
-      (src/phase1.c:609-638), so the oracle replays the TI's AES-CTR stream.  n = 5 000 here (the
-      oracle's replay of 1e5 cross pairs x (2n+1) words is what bounds n; the n = 5e4 run is
-      tests/tools/gpu_config_runs.py c4r, compared at the same share level offline)
+  C4  n = 5e4, d = 500, 5 data providers, CGD-20, phase 1 in 64 bits / phase 2 in 32 bits
+      (--prec_phase2=30), TI mode with a pinned TI seed: exact at SHARE level -- every share is shifted
+      on its own (src/phase1.c:609-638), so the oracle replays the TI's AES-CTR stream pair by pair
+      (1e5 cross pairs x (2n+1) words, ~35 s of host time; the protocol run itself takes ~22 s)
   C5  all 64 lambdas of the d = 100 CGD-15 circuit as one merged program, every beta == oracle
   Cholesky d = 500, 64-bit (1.9e11 AND gates)
 """
@@ -61,7 +60,7 @@ def test_config3_use_ot_full_size(tmp_path, oracle, ot):
 
 def test_config4_five_providers_64_32_split_share_level(tmp_path, oracle, gccpu):
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
-    n, d, starts = 5000, 500, [0, 100, 200, 300, 400]
+    n, d, starts = 50000, 500, [0, 100, 200, 300, 400]
     p1, p2, lam, iters = 56, 30, 0.001, 20
     path = str(tmp_path / "c4.in")
     _write_instance(path, n, d, starts, 4)

@@ -5,8 +5,10 @@ import sys, os, re, time, socket, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import orc
+import orc, gccpu
 oracle = orc.load()
+mirror = gccpu.load()
+TI_SEED = bytes(range(0x60, 0x70))
 HOST = os.path.join(ROOT, "linreg-mpc_amd", "host")
 
 def free_ports(k):
@@ -33,11 +35,12 @@ def write_instance(path, n, d, starts, seed):
 def run(name, n, d, starts, alg, iters, lam, extra, w2=64, p1=56, p2=None, seed=0):
     path = "/tmp/%s.in" % name
     t0 = time.time(); X, y = write_instance(path, n, d, starts, seed); t1 = time.time()
-    exe = os.path.join(HOST, "bin", "linreg")
+    exe = os.path.join(HOST, "bin", "linreg_testhooks" if w2 == 32 else "linreg")   # 64->32: the TI seed is pinned (below)
     P = len(starts)
     args = [str(p1), alg, str(iters), repr(lam)] + extra
     t2 = time.time()
-    procs = [subprocess.Popen([exe, path, args[0], str(k)] + args[1:], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for k in range(1, P + 3)]
+    env = dict(os.environ, LINREG_TI_SEED=TI_SEED.hex()) if w2 == 32 else dict(os.environ)
+    procs = [subprocess.Popen([exe, path, args[0], str(k)] + args[1:], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for k in range(1, P + 3)]
     outs = [p.communicate(timeout=3000) for p in procs]
     t3 = time.time()
     for p, (o, e) in zip(procs, outs):
@@ -56,6 +59,22 @@ def run(name, n, d, starts, alg, iters, lam, extra, w2=64, p1=56, p2=None, seed=
         inp = oracle.read_input(path)
         beta = oracle.linreg_file(path, p1, -1, 64, 64, {"cholesky": 0, "ldlt": 1, "cgd": 2}[alg], iters, lam)
         exact = got == ["%.15f" % (int(v) / 2.0 ** p1) for v in beta]
+    elif os.environ.get("CONFIG_RUNS_EXACT32", "1") != "0":
+        # 64 -> 32 bit: every share is shifted on its own (src/phase1.c:609-638), so the oracle replays the pinned
+        # TI stream pair by pair and converts share by share (as tests/test_gpu_configs.py does at n = 5 000)
+        import numpy as np
+        t_or = time.time()
+        inp = oracle.read_input(path)
+        Xq = oracle.quantize(inp["X"], p1, n, 32); yq = oracle.quantize(inp["y"], p1, n, 32)
+        sA, sb, used = oracle.ti_shares_stream(Xq.reshape(n, d), yq, n, d, p1, 64, starts,
+                                               lambda first, count: mirror.ti_stream_words(TI_SEED, first, count, 64))
+        p2v = [int(a.split("=")[1]) for a in extra if a.startswith("--prec_phase2=")][0]
+        cA = np.stack([oracle.convert_shares(r, p1, p2v, 64, 32) for r in sA])
+        cb = np.stack([oracle.convert_shares(r, p1, p2v, 64, 32) for r in sb])
+        a, bb = oracle.circuit_input(oracle.sum_shares(cA, 32), oracle.sum_shares(cb, 32), d, lam, p2v, 32)
+        beta = oracle.cgd(a, bb, d, p2v, 32, iters)
+        exact = got == ["%.15f" % (int(v) / 2.0 ** p2v) for v in beta]
+        print("oracle replay of the TI stream: %.0f s" % (time.time() - t_or), file=sys.stderr)
     # distance to the double-precision ridge solution of the same (normalised) system
     import numpy as np
     A = X.T @ X / (n * d); A[np.diag_indices(d)] += lam
@@ -73,6 +92,7 @@ subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
 if "c2" in which: run("c2", 1000, 20, [0, 10], "cholesky", 0, 0.001, [])
 if "c3ti" in which: run("c3ti", 10000, 100, [0, 50], "cgd", 15, 0.001, [])
 if "c3" in which: run("c3", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--use_ot"])
+if "c3or" in which: run("c3-otring", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--ot_ring", "--table_ring"])
 if "c4" in which: run("c4", 50000, 500, [0, 100, 200, 300, 400], "cgd", 20, 0.001, ["--width_phase2=32", "--prec_phase2=30"], w2=32)
 # --table_ring: CSP and Evaluator processes share the garbled tables in HBM (hipIpc) instead of the socket
 if "c2r" in which: run("c2-ring", 1000, 20, [0, 10], "cholesky", 0, 0.001, ["--table_ring"])
