@@ -268,11 +268,19 @@ int lgc_p1_ti_a(lgc_p1 *h, uint32_t col, const uint64_t *y, const uint64_t *in, 
 /* the same for a run of pairs with one peer in ONE device call (y, in, out_mask: npairs x n words) */
 int lgc_p1_ti_a_batch(lgc_p1 *h, const uint32_t *cols, size_t npairs, const uint64_t *y, const uint64_t *in,
                       const uint64_t *sub, uint64_t *out_mask, uint64_t *shares);
+/* Device I/O for the three calls above: V / out, A / B, y / in / out_mask are device memory used in place
+ * (cols, sub and the returned shares stay host arrays) -- the TI-mode exchange between parties on one
+ * node through device rings (bin/linreg --ti_ring). */
+int lgc_p1_set_device_io(lgc_p1 *h, int on);
 /* Trusted initializer (src/phase1.c:241-287): pairs [first_pair, first_pair + npairs) of the
  * cross-party (i, j) enumeration; x, y: npairs x n words, r, xy_minus_r: npairs words, drawn in the
  * order x, y, r from one AES-128-CTR stream keyed by seed (newBCipherRandomGen / randomizeBuffer). */
 int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t first_pair, size_t npairs, size_t n, int width,
                     uint64_t *x, uint64_t *y, uint64_t *r, uint64_t *xy_minus_r);
+
+/* as lgc_ti_generate, with x[q] / y[q] written to the device addresses x_dst[q] / y_dst[q] */
+int lgc_ti_generate_scatter(int device, const uint8_t seed[16], uint64_t first_pair, size_t npairs, size_t n, int width,
+                            void *const *x_dst, void *const *y_dst, uint64_t *r, uint64_t *xy_minus_r);
 
 /* ------------------------------------------------------------- OT extension */
 /* IKNP semi-honest OT extension, kappa = 128.  The base OTs (Naor-Pinkas in Obliv-C) run on the

@@ -36,6 +36,7 @@ struct lgc_p1 {
     size_t n, d;
     int64_t *X;      // n x (d + 1) row-major, column d = y (zero when this party does not own y)
     bool have_y;
+    bool dev_io;     // lgc_p1_set_device_io: the vector arguments of mask / dot / ti_a_batch are device memory
 };
 
 // ---- wrap-around Gram block: C[a][b] = sum_k X[k][cols[a]] * X[k][cols[b]]  (mod 2^64)
@@ -269,7 +270,7 @@ extern "C" int lgc_p1_create(lgc_p1 **out, int device, size_t n, size_t d, int w
     int rc = lgc_need_device(device);
     if (rc) return rc;
     lgc_p1 *h = new lgc_p1();
-    h->device = device; h->w = width; h->p = precision; h->n = n; h->d = d; h->X = 0; h->have_y = false;
+    h->device = device; h->w = width; h->p = precision; h->n = n; h->d = d; h->X = 0; h->have_y = false; h->dev_io = false;
     hipError_t e = hipMalloc(&h->X, n * (d + 1) * sizeof(int64_t));
     if (e != hipSuccess) { delete h; return lgc_fail(LGC_ENOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
     *out = h;
@@ -412,6 +413,18 @@ extern "C" int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const
     P1Serial serial_; hipStream_t st = p1_stream();
     uint32_t *dcols = 0; uint64_t *dV = 0, *dout = 0;
     size_t bytes = npairs * h->n * sizeof(uint64_t);
+    if (h->dev_io) {     // V and out are device memory (same-node rings): no copies
+        P1CHK(t_scratch.get(h->device, 0, npairs * sizeof(uint32_t), (void **)&dcols));
+        P1CHK(hipMemcpyAsync(dcols, cols, npairs * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        unsigned gx = (unsigned)((h->n + 255) / 256); if (gx > 64) gx = 64;
+        for (size_t q0 = 0; q0 < npairs; q0 += 65535) {
+            unsigned gy = (unsigned)(npairs - q0 < 65535 ? npairs - q0 : 65535);
+            hipLaunchKernelGGL(p1_mask_kernel, dim3(gx, gy), dim3(256), 0, st, h->X, h->n, h->d + 1, dcols + q0, V + q0 * h->n, sign, out + q0 * h->n);
+        }
+        P1CHK(hipGetLastError());
+        P1CHK(hipStreamSynchronize(st));
+        return LGC_OK;
+    }
     if (npairs == 1) {   // per-pair protocol step: three operations
         P1CHK(t_scratch.get(h->device, 1, bytes, (void **)&dV));
         P1CHK(t_scratch.get(h->device, 2, bytes, (void **)&dout));
@@ -448,6 +461,23 @@ extern "C" int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const
     P1Serial serial_; hipStream_t st = p1_stream();
     size_t bytes = npairs * h->n * sizeof(uint64_t);
     uint64_t *dA = 0, *dB = 0, *dout = 0; uint32_t *dcols = 0;
+    if (h->dev_io) {     // A (and B) are device memory; the sums still return to the host
+        if (npairs > 65535) return lgc_fail(LGC_EINVAL, "too many pairs in one call");
+        if (colsB) {
+            P1CHK(t_scratch.get(h->device, 0, npairs * sizeof(uint32_t), (void **)&dcols));
+            P1CHK(hipMemcpyAsync(dcols, colsB, npairs * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        }
+        P1CHK(t_scratch.get(h->device, 3, npairs * sizeof(uint64_t), (void **)&dout));
+        P1CHK(hipMemsetAsync(dout, 0, npairs * sizeof(uint64_t), st));
+        unsigned gx = (unsigned)((h->n + 255) / 256); if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(p1_dot_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, st, A, B, h->X, h->d + 1, dcols, h->n, dout);
+        P1CHK(hipGetLastError());
+        P1CHK(hipMemcpyAsync(out, dout, npairs * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        P1CHK(hipStreamSynchronize(st));
+        const uint64_t mm = maskw(h->w);
+        for (size_t q = 0; q < npairs; q++) out[q] = (out[q] - (sub ? sub[q] : 0)) & mm;
+        return LGC_OK;
+    }
     P1CHK(t_scratch.get(h->device, 1, bytes, (void **)&dA));
     P1CHK(hipMemcpyAsync(dA, A, bytes, hipMemcpyHostToDevice, st));
     if (npairs == 1) {   // per-pair protocol step: one workgroup writes the sum, no memset
@@ -521,6 +551,22 @@ extern "C" int lgc_p1_ti_a_batch(lgc_p1 *h, const uint32_t *cols, size_t npairs,
     P1Serial serial_; hipStream_t st = p1_stream();
     const size_t n = h->n, bytes = npairs * n * sizeof(uint64_t);
     uint64_t *dy = 0, *din = 0, *dout = 0; uint32_t *dcols = 0;
+    if (h->dev_io) {     // y, in and out_mask are device memory
+        uint64_t *dacc = 0;
+        P1CHK(t_scratch.get(h->device, 0, npairs * sizeof(uint32_t), (void **)&dcols));
+        P1CHK(t_scratch.get(h->device, 3, npairs * sizeof(uint64_t), (void **)&dacc));
+        P1CHK(hipMemcpyAsync(dcols, cols, npairs * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        P1CHK(hipMemsetAsync(dacc, 0, npairs * sizeof(uint64_t), st));
+        unsigned gx = (unsigned)((n + 255) / 256); if (gx > 64) gx = 64;
+        unsigned gy = npairs > 65535 ? 65535u : (unsigned)npairs;
+        hipLaunchKernelGGL(p1_ti_a_batch_kernel, dim3(gx, gy), dim3(256), 0, st, h->X, n, h->d + 1, dcols, npairs, y, in, out_mask, dacc);
+        P1CHK(hipGetLastError());
+        P1CHK(hipMemcpyAsync(shares, dacc, npairs * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        P1CHK(hipStreamSynchronize(st));
+        const uint64_t mm = maskw(h->w);
+        for (size_t q = 0; q < npairs; q++) shares[q] = (shares[q] - sub[q]) & mm;
+        return LGC_OK;
+    }
     P1CHK(t_scratch.get(h->device, 0, npairs * sizeof(uint32_t), (void **)&dcols));
     P1CHK(t_scratch.get(h->device, 1, bytes, (void **)&dy));
     P1CHK(t_scratch.get(h->device, 2, bytes, (void **)&din));
@@ -542,13 +588,26 @@ extern "C" int lgc_p1_ti_a_batch(lgc_p1 *h, const uint32_t *cols, size_t npairs,
     return LGC_OK;
 }
 
+extern "C" int lgc_p1_set_device_io(lgc_p1 *h, int on) {
+    if (!h) return lgc_fail(LGC_EINVAL, "null handle");
+    h->dev_io = on != 0;
+    return LGC_OK;
+}
+
+// scatter of the TI's vectors into per-pair destinations (device rings of the data providers)
+__global__ void p1_scatter_kernel(const uint64_t *src, uint64_t *const *dst, size_t n) {
+    const size_t q = blockIdx.y;
+    uint64_t *d = dst[q];
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) d[k] = src[q * n + k];
+}
+
 // Trusted initializer (phase1.c:241-287): for pairs [first_pair, first_pair + npairs) of the
 // (i, j) enumeration, words x[n], y[n], r drawn in this order from one AES-128-CTR stream keyed
 // by `seed`; xy_minus_r[q] = <x,y> - r.  Stream position of pair q is q * (2n + 1) words.
-extern "C" int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t first_pair, size_t npairs, size_t n, int width,
-                               uint64_t *x, uint64_t *y, uint64_t *r, uint64_t *xy_minus_r) {
+static int ti_generate(int device, const uint8_t seed[16], uint64_t first_pair, size_t npairs, size_t n, int width,
+                       uint64_t *x, uint64_t *y, void *const *x_dst, void *const *y_dst, uint64_t *r, uint64_t *xy_minus_r) {
     DevFree dev_guard;   // temporary device buffers are released on every return path
-    if (!seed || !x || !y || !r || !xy_minus_r) return lgc_fail(LGC_EINVAL, "null argument");
+    if (!seed || !r || !xy_minus_r || (!x && !x_dst) || (!y && !y_dst)) return lgc_fail(LGC_EINVAL, "null argument");
     if (width != 32 && width != 64) return lgc_fail(LGC_EINVAL, "width must be 32 or 64");
     if (npairs == 0) return LGC_OK;
     int rc = lgc_need_device(device);
@@ -577,11 +636,33 @@ extern "C" int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t firs
     unsigned gx = (unsigned)((n + 255) / 256); if (gx > 64) gx = 64;
     hipLaunchKernelGGL(p1_dot_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, dA, dB, (const int64_t *)0, (size_t)0,
                        (const uint32_t *)0, n, dout);
-    P1CHK(hipMemcpy(x, dA, bytes, hipMemcpyDeviceToHost));
-    P1CHK(hipMemcpy(y, dB, bytes, hipMemcpyDeviceToHost));
+    if (x_dst) {       // same-node rings: x and y of every pair go straight to device memory of its two data providers
+        if (npairs > 65535) return lgc_fail(LGC_EINVAL, "too many pairs in one call");
+        uint64_t **dptr = 0;
+        P1CHK(hipMalloc(&dptr, 2 * npairs * sizeof(void *))); dev_guard.add(dptr);
+        P1CHK(hipMemcpy(dptr, x_dst, npairs * sizeof(void *), hipMemcpyHostToDevice));
+        P1CHK(hipMemcpy(dptr + npairs, y_dst, npairs * sizeof(void *), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(p1_scatter_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, dA, dptr, n);
+        hipLaunchKernelGGL(p1_scatter_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, dB, dptr + npairs, n);
+        P1CHK(hipGetLastError());
+    } else {
+        P1CHK(hipMemcpy(x, dA, bytes, hipMemcpyDeviceToHost));
+        P1CHK(hipMemcpy(y, dB, bytes, hipMemcpyDeviceToHost));
+    }
     P1CHK(hipMemcpy(r, dr, npairs * 8, hipMemcpyDeviceToHost));
     P1CHK(hipMemcpy(xy_minus_r, dout, npairs * 8, hipMemcpyDeviceToHost));
 
     for (size_t q = 0; q < npairs; q++) xy_minus_r[q] = (xy_minus_r[q] - r[q]) & m;
     return LGC_OK;
+}
+extern "C" int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t first_pair, size_t npairs, size_t n, int width,
+                               uint64_t *x, uint64_t *y, uint64_t *r, uint64_t *xy_minus_r) {
+    if (!x || !y) return lgc_fail(LGC_EINVAL, "null argument");
+    return ti_generate(device, seed, first_pair, npairs, n, width, x, y, 0, 0, r, xy_minus_r);
+}
+// the same, x[q] / y[q] written to the device addresses x_dst[q] / y_dst[q] (host arrays of device pointers)
+extern "C" int lgc_ti_generate_scatter(int device, const uint8_t seed[16], uint64_t first_pair, size_t npairs, size_t n, int width,
+                                       void *const *x_dst, void *const *y_dst, uint64_t *r, uint64_t *xy_minus_r) {
+    if (!x_dst || !y_dst) return lgc_fail(LGC_EINVAL, "null argument");
+    return ti_generate(device, seed, first_pair, npairs, n, width, 0, 0, x_dst, y_dst, r, xy_minus_r);
 }

@@ -39,6 +39,7 @@ int main(int argc, char **argv) {
           "         --prec_phase2=<Precision phase 2>: Use different precision for phase 2 of the protocol\n"
           "         --width_phase1=<32|64>, --width_phase2=<32|64>: bit widths (default 64)\n"
           "         --table_ring[=slots]: parties 1 and 2 share one node; garbled tables stay in HBM\n"
+          "         --ti_ring: (TI mode) all parties on this node: the vectors of the multiplication protocol stay in HBM\n"
           "         --ot_ring: --use_ot with all data providers on this node: the OT extension's messages stay in HBM\n"
           "         --lambdas=l1,l2,...: regularisation sweep -- one circuit per value on the same shares (the data\n"
           "                  providers share their inputs once); [Lambda] is then ignored", argv[0]);
@@ -62,7 +63,8 @@ int main(int argc, char **argv) {
     size_t n_lambdas = 0;
     for (int i = 7; i < argc; i++) {
         if (!strcmp(argv[i], "--use_ot")) use_ot |= 1;
-        else if (!strcmp(argv[i], "--ot_ring")) use_ot |= 3;      /* --use_ot with u / y of the extension in device rings */
+        else if (!strcmp(argv[i], "--ot_ring")) use_ot |= 3;
+        else if (!strcmp(argv[i], "--ti_ring")) protocol_set_ti_ring(1);   /* TI mode, all parties on this node: vectors stay in HBM */      /* --use_ot with u / y of the extension in device rings */
         else if (!strncmp(argv[i], "--lambdas=", 10)) {
             const char *q = argv[i] + 10;
             while (*q) {

@@ -226,6 +226,204 @@ static void tune_malloc(void) {
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
     mallopt(M_TOP_PAD, 64 << 20);
 }
+
+/* ---------------------------------------------------------------- TI mode on one node: --ti_ring
+ * All parties of phase 1 share a node: the vectors of inner_product_ti never leave HBM.  The trusted
+ * initializer writes x / y of every cross-party pair straight into a device ring of the data provider that
+ * is entitled to it (one ring PER provider: party a never maps b's x), and two providers exchange b + x and
+ * a - y through one-slot device rings they map from each other (hipIpc).  The sockets carry one-byte tokens
+ * and the scalars (r, <x,y> - r).  Same values, same pair order, same shares as the socket protocol
+ * (src/phase1.c:148-339); what does not exist here is the byte stream.
+ *   batch t = cross pairs [t B, (t + 1) B) of the loop order; every party derives the same partition.
+ *   TI  : wait for a free slot of every provider that has entries in t (3 slots, acks 'K'), generate + scatter,
+ *         send 'T' + that provider's scalars
+ *   DP  : per batch with entries: wait 'T'; as party b (towards higher parties): masks -> own ring, token 'M';
+ *         as party a (towards lower parties): wait 'M', fused step -> replies in own ring + shares, token 'A';
+ *         as party b again: wait 'A', shares; ack 'K'.  One thread per process, no cycle in the waits. */
+static int g_ti_ring = 0;
+void protocol_set_ti_ring(int on) { g_ti_ring = on; }
+typedef struct { int pa, pb; uint32_t ci, cj; } xpair;
+static size_t enumerate_cross(config *c, xpair **out) {
+    size_t cap = 0, np = 0;
+    xpair *v = NULL;
+    for (size_t i = 0; i <= c->d; i++)
+        for (size_t j = 0; j <= i && j < c->d; j++) {
+            int pa = config_owner(c, i), pb = config_owner(c, j);
+            if (pa == pb) continue;
+            if (np == cap) { cap = cap ? 2 * cap : 1024; v = realloc(v, cap * sizeof *v); if (!v) return 0; }
+            xpair x = {pa, pb, (uint32_t)i, (uint32_t)j};
+            v[np++] = x;
+        }
+    *out = v;
+    return np;
+}
+enum { kTiRingSlots = 3 };
+static size_t ti_ring_batch(size_t n) {
+    size_t b = ((size_t)64 << 20) / (n * 8);
+    if (b < 1) b = 1;
+    if (b > 256) b = 256;
+    return b;
+}
+static int tok_send(node *self, int to, char t) { return net_send(self, to, &t, 1); }
+static int tok_expect(node *self, int from, char want) {
+    char t = 0;
+    if (net_recv(self, from, &t, 1) || t != want) { fprintf(stderr, "ring protocol: expected '%c' from party %d\n", want, from); return 1; }
+    return 0;
+}
+
+static int run_trusted_initializer_ring(node *self, config *c, int w1, int device, const uint8_t seed[16]) {
+    const size_t n = c->n;
+    const int NP = c->num_parties;
+    xpair *xp = NULL;
+    const size_t np = enumerate_cross(c, &xp), B = ti_ring_batch(n), slotb = B * n * 8;
+    void *ring[64] = {0};
+    size_t issued[64] = {0}, acked[64] = {0}, cnt[64];
+    uint64_t *scal[64] = {0};
+    void **xdst = malloc(B * sizeof(void *)), **ydst = malloc(B * sizeof(void *));
+    uint64_t *r = malloc(B * 8), *xyr = malloc(B * 8);
+    uint8_t *msg = malloc(1 + B * 8);
+    int rc = 1;
+    if (!xp || !xdst || !ydst || !r || !xyr || !msg || NP > 64) goto out;
+    for (int k = 2; k < NP; k++) {
+        uint8_t h[64];
+        if (lgc_dev_alloc(device, kTiRingSlots * slotb, &ring[k], h)) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
+        scal[k] = malloc(B * 8);
+        if (!scal[k] || send_blob(self, k + 1, h, 64)) goto out;
+    }
+    for (size_t q0 = 0; q0 < np; q0 += B) {
+        const size_t nb = np - q0 < B ? np - q0 : B;
+        int has[64] = {0};
+        for (size_t q = 0; q < nb; q++) { has[xp[q0 + q].pa] = 1; has[xp[q0 + q].pb] = 1; }
+        for (int k = 2; k < NP; k++) {                       /* a free slot for everybody involved */
+            cnt[k] = 0;
+            while (has[k] && issued[k] - acked[k] >= kTiRingSlots) { if (tok_expect(self, k + 1, 'K')) goto out; acked[k]++; }
+        }
+        for (size_t q = 0; q < nb; q++) {
+            const xpair *x = &xp[q0 + q];
+            ydst[q] = (char *)ring[x->pa] + ((issued[x->pa] % kTiRingSlots) * B + cnt[x->pa]) * n * 8;   /* a: (y, <x,y> - r) */
+            xdst[q] = (char *)ring[x->pb] + ((issued[x->pb] % kTiRingSlots) * B + cnt[x->pb]) * n * 8;   /* b: (x, r) */
+            cnt[x->pa]++; cnt[x->pb]++;
+        }
+        if (lgc_ti_generate_scatter(device, seed, q0, nb, n, w1, xdst, ydst, r, xyr)) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
+        for (int k = 2; k < NP; k++) cnt[k] = 0;
+        for (size_t q = 0; q < nb; q++) { scal[xp[q0 + q].pa][cnt[xp[q0 + q].pa]++] = xyr[q]; scal[xp[q0 + q].pb][cnt[xp[q0 + q].pb]++] = r[q]; }
+        for (int k = 2; k < NP; k++) {
+            if (!has[k]) continue;
+            msg[0] = 'T';
+            memcpy(msg + 1, scal[k], cnt[k] * 8);
+            if (net_send(self, k + 1, msg, 1 + cnt[k] * 8)) goto out;
+            issued[k]++;
+        }
+    }
+    for (int k = 2; k < NP; k++) while (acked[k] < issued[k]) { if (tok_expect(self, k + 1, 'K')) goto out; acked[k]++; }
+    rc = 0;
+out:
+    for (int k = 2; k < NP && k < 64; k++) { lgc_dev_free(ring[k]); free(scal[k]); }
+    free(xp); free(xdst); free(ydst); free(r); free(xyr); free(msg);
+    return rc;
+}
+
+static int run_party_ti_ring(node *self, config *c, lgc_p1 *p1, int device, uint64_t *share_A, uint64_t *share_b) {
+    const size_t n = c->n, d = c->d;
+    const int NP = c->num_parties, me = c->party - 1;
+    xpair *xp = NULL;
+    const size_t np = enumerate_cross(c, &xp), B = ti_ring_batch(n), slotb = B * n * 8;
+    void *ti = NULL, *mine[64] = {0}, *theirs[64] = {0};
+    int shared[64] = {0};
+    uint32_t *col = malloc(B * sizeof *col);
+    int *peer = malloc(B * sizeof *peer);
+    uint64_t **dst = malloc(B * sizeof *dst), *scal = malloc(B * 8 + 8), *shares = malloc(B * 8 + 8);
+    uint8_t *msg = malloc(1 + B * 8);
+    int rc = 1;
+    if (!xp || !col || !peer || !dst || !scal || !shares || !msg || NP > 64) goto out;
+    {
+        uint8_t h[64];
+        if (recv_blob(self, 1, h, 64) || lgc_dev_open(device, h, &ti)) { fprintf(stderr, "could not map the TI ring: %s\n", lgc_last_error()); goto out; }
+    }
+    for (size_t q = 0; q < np; q++) { if (xp[q].pa == me) shared[xp[q].pb] = 1; if (xp[q].pb == me) shared[xp[q].pa] = 1; }
+    for (int k = 2; k < NP; k++) {
+        if (!shared[k]) continue;
+        uint8_t hm[64], ht[64];
+        if (lgc_dev_alloc(device, slotb, &mine[k], hm)) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
+        if (send_blob(self, k + 1, hm, 64) || recv_blob(self, k + 1, ht, 64) || lgc_dev_open(device, ht, &theirs[k])) {
+            fprintf(stderr, "could not exchange ring handles with party %d: %s\n", k + 1, lgc_last_error()); goto out;
+        }
+    }
+    if (lgc_p1_set_device_io(p1, 1)) goto out;
+    size_t m = 0;
+    for (size_t q0 = 0; q0 < np; q0 += B) {
+        const size_t nb = np - q0 < B ? np - q0 : B;
+        size_t cnt = 0;
+        int has[64] = {0};
+        for (size_t q = 0; q < nb; q++) {
+            const xpair *x = &xp[q0 + q];
+            if (x->pa != me && x->pb != me) continue;
+            const int is_a = x->pa == me;
+            peer[cnt] = is_a ? x->pb : x->pa;
+            col[cnt] = is_a ? x->ci : x->cj;
+            dst[cnt] = x->ci < d ? share_A + idx(x->ci, x->cj) : share_b + x->cj;
+            has[peer[cnt]] = 1;
+            cnt++;
+        }
+        if (!cnt) continue;
+        if (net_recv(self, 1, msg, 1 + cnt * 8) || msg[0] != 'T') { fprintf(stderr, "ring protocol: no batch from the TI\n"); goto out; }
+        memcpy(scal, msg + 1, cnt * 8);
+        char *base = (char *)ti + (m % kTiRingSlots) * slotb;
+        /* party b towards the higher parties: b + x */
+        for (int k = me + 1; k < NP; k++) {
+            if (!has[k]) continue;
+            size_t pos = 0;
+            for (size_t e = 0; e < cnt;) {
+                if (peer[e] != k) { e++; continue; }
+                size_t len = 1;
+                while (e + len < cnt && peer[e + len] == k) len++;
+                if (lgc_p1_mask(p1, col + e, len, (const uint64_t *)(base + e * n * 8), +1, (uint64_t *)((char *)mine[k] + pos * n * 8))) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
+                pos += len; e += len;
+            }
+            if (tok_send(self, k + 1, 'M')) goto out;
+        }
+        /* party a towards the lower parties: a - y and <b + x, y> - (<x,y> - r) */
+        for (int k = 2; k < me; k++) {
+            if (!has[k]) continue;
+            if (tok_expect(self, k + 1, 'M')) goto out;
+            size_t pos = 0;
+            for (size_t e = 0; e < cnt;) {
+                if (peer[e] != k) { e++; continue; }
+                size_t len = 1;
+                while (e + len < cnt && peer[e + len] == k) len++;
+                if (lgc_p1_ti_a_batch(p1, col + e, len, (const uint64_t *)(base + e * n * 8), (const uint64_t *)((char *)theirs[k] + pos * n * 8),
+                                      scal + e, (uint64_t *)((char *)mine[k] + pos * n * 8), shares)) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
+                for (size_t i = 0; i < len; i++) *dst[e + i] = shares[i];
+                pos += len; e += len;
+            }
+            if (tok_send(self, k + 1, 'A')) goto out;
+        }
+        /* party b again: <a - y, b> - r */
+        for (int k = me + 1; k < NP; k++) {
+            if (!has[k]) continue;
+            if (tok_expect(self, k + 1, 'A')) goto out;
+            size_t pos = 0;
+            for (size_t e = 0; e < cnt;) {
+                if (peer[e] != k) { e++; continue; }
+                size_t len = 1;
+                while (e + len < cnt && peer[e + len] == k) len++;
+                if (lgc_p1_dot(p1, (const uint64_t *)((char *)theirs[k] + pos * n * 8), NULL, col + e, len, scal + e, shares)) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
+                for (size_t i = 0; i < len; i++) *dst[e + i] = shares[i];
+                pos += len; e += len;
+            }
+        }
+        if (tok_send(self, 1, 'K')) goto out;
+        m++;
+    }
+    rc = 0;
+out:
+    (void)lgc_p1_set_device_io(p1, 0);
+    for (int k = 2; k < NP && k < 64; k++) { if (theirs[k]) lgc_dev_close(theirs[k]); lgc_dev_free(mine[k]); }
+    if (ti) lgc_dev_close(ti);
+    free(xp); free(col); free(peer); free(dst); free(scal); free(shares); free(msg);
+    return rc;
+}
+
 int run_trusted_initializer(node *self, config *c, int w1, int device) {
     tune_malloc();
     pmsg_set_limit(c->n);
@@ -238,6 +436,7 @@ int run_trusted_initializer(node *self, config *c, int w1, int device) {
     if (fixed && strlen(fixed) == 32)
         for (int i = 0; i < 16; i++) { unsigned v = 0; sscanf(fixed + 2 * i, "%2x", &v); seed[i] = (uint8_t)v; }
 #endif
+    if (g_ti_ring) return run_trusted_initializer_ring(self, c, w1, device, seed);
     const size_t n = c->n;
     /* enumerate the cross-party pairs in the loop order of src/phase1.c:256-258, then generate the
      * randomness in batches on the GPU and send the two messages of every pair in that order */
@@ -847,7 +1046,11 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
         free(blk); free(bb);
     }
     va = malloc(n * 8); vb = malloc(n * 8); tmp = malloc(n * 8); tmp2 = malloc(n * 8);
-    if (!use_ot) {
+    if (!use_ot && g_ti_ring) {
+        check(!run_party_ti_ring(self, c, p1, device, share_A, share_b), "TI-mode aggregation (device rings) failed");
+        if (w1 == 32) { for (size_t k = 0; k < T; k++) share_A[k] &= 0xffffffffull; for (size_t k = 0; k < d; k++) share_b[k] &= 0xffffffffull; }
+        if (getenv("LINREG_TIMING")) fprintf(stderr, "party %d: TI-mode aggregation (rings) done after %.2fs\n", c->party, wall_clock() - t_start);
+    } else if (!use_ot) {
         /* TI mode.  The pairs are those of the loops at src/phase1.c:534-586 and every socket
          * carries its messages in that order (the TI socket: this party's pairs in loop order; a
          * peer socket: the pairs shared with that peer in loop order), so the byte streams are the

@@ -25,7 +25,8 @@ int send_pmsg(node *self, int to, const uint64_t *vec, size_t n, uint64_t value)
 int recv_pmsg(node *self, int from, uint64_t **vec, size_t *n, uint64_t *value);
 int send_blob(node *self, int to, const void *buf, uint64_t len);
 int recv_blob(node *self, int from, void *buf, uint64_t len);
-void pmsg_set_limit(size_t n_elements);   /* bound on the length prefix recv_pmsg accepts */
+void pmsg_set_limit(size_t n_elements);
+void protocol_set_ti_ring(int on);        /* TI mode with all parties on one node: vectors through device rings */   /* bound on the length prefix recv_pmsg accepts */
 
 /* The garbled-table stream of phase 2 (garbler -> evaluator; the reference's Yao runtime does this
  * with osend/orecv inside execYaoProtocol, linreg.c:177).  ring_slots == 0: the table bytes of each

@@ -58,7 +58,8 @@ def test_config3_use_ot_full_size(tmp_path, oracle, ot):
     assert "Number of gates:" in outs[1]
 
 
-def test_config4_five_providers_64_32_split_share_level(tmp_path, oracle, gccpu):
+@pytest.mark.parametrize("ring", [[], ["--ti_ring"]], ids=["sockets", "ti-ring"])
+def test_config4_five_providers_64_32_split_share_level(tmp_path, oracle, gccpu, ring):
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     n, d, starts = 50000, 500, [0, 100, 200, 300, 400]
     p1, p2, lam, iters = 56, 30, 0.001, 20
@@ -67,7 +68,7 @@ def test_config4_five_providers_64_32_split_share_level(tmp_path, oracle, gccpu)
     seed = bytes(range(0x60, 0x70))
     os.environ["LINREG_TI_SEED"] = seed.hex()
     try:
-        outs = _run_all(path, 5, [str(p1), "cgd", str(iters), str(lam), "--width_phase2=32", "--prec_phase2=%d" % p2, "--table_ring"],
+        outs = _run_all(path, 5, [str(p1), "cgd", str(iters), str(lam), "--width_phase2=32", "--prec_phase2=%d" % p2, "--table_ring"] + ring,
                         timeout=1500, exe_name="linreg_testhooks")
     finally:
         del os.environ["LINREG_TI_SEED"]

@@ -118,7 +118,8 @@ README_RESULT = ["0.984331027786964", "0.792399824970372", "0.754117840176144", 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--use_ot"], ["--table_ring"], ["--ot_ring", "--table_ring"]], ids=["ti", "ot", "ti-ring", "ot-ring"])
+@pytest.mark.parametrize("extra", [[], ["--use_ot"], ["--table_ring"], ["--ot_ring", "--table_ring"], ["--ti_ring", "--table_ring"]],
+                         ids=["ti", "ot", "table-ring", "ot-ring", "ti-ring"])
 def test_five_process_readme_example(tmp_path, golden_dir, extra):
     """bin/linreg examples/readme_example.in 56 $party cgd 10 0.001 (README.md:81) -> README.md:87"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
@@ -259,7 +260,8 @@ def test_config_parser_and_owner_map(hostlib, golden_dir):
 
 
 @pytest.mark.gpu
-def test_five_process_64_32_split_share_level(tmp_path, golden_dir, oracle, gccpu):
+@pytest.mark.parametrize("ring", [[], ["--ti_ring"]], ids=["sockets", "ti-ring"])
+def test_five_process_64_32_split_share_level(tmp_path, golden_dir, oracle, gccpu, ring):
     """BASELINE config 4's build: phase 1 in 64 bits, phase 2 in 32 bits (--prec_phase2).  Every
     share is shifted on its own (src/phase1.c:609-638), so the result depends on the TI's
     randomness: the TI seed is pinned and the oracle replays the same AES-CTR stream."""
@@ -271,7 +273,7 @@ def test_five_process_64_32_split_share_level(tmp_path, golden_dir, oracle, gccp
     seed = bytes(range(0x40, 0x50))
     os.environ["LINREG_TI_SEED"] = seed.hex()
     try:
-        outs = _run_all(infile, P, ["%d" % p1, "cgd", str(iters), str(lam), "--width_phase2=32", "--prec_phase2=%d" % p2],
+        outs = _run_all(infile, P, ["%d" % p1, "cgd", str(iters), str(lam), "--width_phase2=32", "--prec_phase2=%d" % p2] + ring,
                         exe_name="linreg_testhooks")      # the production binary ignores LINREG_TI_SEED
     finally:
         del os.environ["LINREG_TI_SEED"]

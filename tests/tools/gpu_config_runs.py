@@ -102,4 +102,7 @@ if "c4s" in which: run("c4-small-n-ring", 1000, 500, [0, 100, 200, 300, 400], "c
                        ["--width_phase2=32", "--prec_phase2=30", "--table_ring"], w2=32)
 if "c4r" in which: run("c4-ring", 50000, 500, [0, 100, 200, 300, 400], "cgd", 20, 0.001,
                        ["--width_phase2=32", "--prec_phase2=30", "--table_ring"], w2=32)
+if "c4tr" in which: run("c4-ti-ring", 50000, 500, [0, 100, 200, 300, 400], "cgd", 20, 0.001,
+                        ["--width_phase2=32", "--prec_phase2=30", "--table_ring", "--ti_ring"], w2=32)
+if "c3titr" in which: run("c3ti-ti-ring", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--table_ring", "--ti_ring"])
 if "c4m" in which: run("c4-mid", 50000, 200, [0, 40, 80, 120, 160], "cgd", 2, 0.001, ["--width_phase2=32", "--prec_phase2=30", "--table_ring"], w2=32)
