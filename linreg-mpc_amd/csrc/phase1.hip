@@ -594,11 +594,33 @@ extern "C" int lgc_p1_set_device_io(lgc_p1 *h, int on) {
     return LGC_OK;
 }
 
-// scatter of the TI's vectors into per-pair destinations (device rings of the data providers)
-__global__ void p1_scatter_kernel(const uint64_t *src, uint64_t *const *dst, size_t n) {
-    const size_t q = blockIdx.y;
-    uint64_t *d = dst[q];
-    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) d[k] = src[q * n + k];
+// the TI's keystream split straight into per-pair destinations (device rings of the data providers): word t of
+// pair q sits at stream word q (2n + 1) + t; x -> xdst[q], y -> ydst[q], r -> r[q].  Aligned word loads
+// (the stream offset of a batch is a multiple of the word size).
+template <typename WT>
+__global__ void ti_unpack_scatter_kernel(const WT *ks, size_t npairs, size_t n, uint64_t *const *xdst, uint64_t *const *ydst, uint64_t *r) {
+    const size_t per = 2 * n + 1;
+    for (size_t q = blockIdx.y; q < npairs; q += gridDim.y) {
+        const WT *src = ks + q * per;
+        uint64_t *dx = xdst[q], *dy = ydst[q];
+        for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < per; t += (size_t)gridDim.x * blockDim.x) {
+            const uint64_t v = (uint64_t)src[t];
+            if (t < n) dx[t] = v;
+            else if (t < 2 * n) dy[t - n] = v;
+            else r[q] = v;
+        }
+    }
+}
+// out[q] = <xdst[q], ydst[q]>  (mod 2^64); out zeroed by the host
+__global__ void __launch_bounds__(256)
+p1_dot_ptr_kernel(uint64_t *const *xdst, uint64_t *const *ydst, size_t npairs, size_t n, uint64_t *out) {
+    for (size_t q = blockIdx.y; q < npairs; q += gridDim.y) {
+        const uint64_t *a = xdst[q], *b = ydst[q];
+        uint64_t acc = 0;
+        for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) acc += a[k] * b[k];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&out[q], (unsigned long long)acc);
+    }
 }
 
 // Trusted initializer (phase1.c:241-287): for pairs [first_pair, first_pair + npairs) of the
@@ -636,15 +658,8 @@ static int ti_generate(int device, const uint8_t seed[16], uint64_t first_pair, 
     unsigned gx = (unsigned)((n + 255) / 256); if (gx > 64) gx = 64;
     hipLaunchKernelGGL(p1_dot_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, dA, dB, (const int64_t *)0, (size_t)0,
                        (const uint32_t *)0, n, dout);
-    if (x_dst) {       // same-node rings: x and y of every pair go straight to device memory of its two data providers
-        if (npairs > 65535) return lgc_fail(LGC_EINVAL, "too many pairs in one call");
-        uint64_t **dptr = 0;
-        P1CHK(hipMalloc(&dptr, 2 * npairs * sizeof(void *))); dev_guard.add(dptr);
-        P1CHK(hipMemcpy(dptr, x_dst, npairs * sizeof(void *), hipMemcpyHostToDevice));
-        P1CHK(hipMemcpy(dptr + npairs, y_dst, npairs * sizeof(void *), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(p1_scatter_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, dA, dptr, n);
-        hipLaunchKernelGGL(p1_scatter_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, dB, dptr + npairs, n);
-        P1CHK(hipGetLastError());
+    if (x_dst) {
+        return lgc_fail(LGC_EINVAL, "internal: scatter requests go through ti_generate_scatter");
     } else {
         P1CHK(hipMemcpy(x, dA, bytes, hipMemcpyDeviceToHost));
         P1CHK(hipMemcpy(y, dB, bytes, hipMemcpyDeviceToHost));
@@ -663,6 +678,43 @@ extern "C" int lgc_ti_generate(int device, const uint8_t seed[16], uint64_t firs
 // the same, x[q] / y[q] written to the device addresses x_dst[q] / y_dst[q] (host arrays of device pointers)
 extern "C" int lgc_ti_generate_scatter(int device, const uint8_t seed[16], uint64_t first_pair, size_t npairs, size_t n, int width,
                                        void *const *x_dst, void *const *y_dst, uint64_t *r, uint64_t *xy_minus_r) {
-    if (!x_dst || !y_dst) return lgc_fail(LGC_EINVAL, "null argument");
-    return ti_generate(device, seed, first_pair, npairs, n, width, 0, 0, x_dst, y_dst, r, xy_minus_r);
+    if (!x_dst || !y_dst || !seed || !r || !xy_minus_r) return lgc_fail(LGC_EINVAL, "null argument");
+    if (width != 32 && width != 64) return lgc_fail(LGC_EINVAL, "width must be 32 or 64");
+    if (npairs == 0) return LGC_OK;
+    int rc = lgc_need_device(device);
+    if (rc) return rc;
+    rc = lgc_upload_constants();
+    if (rc) return rc;
+    // keystream -> destinations -> <x, y>: three kernels on grow-only per-thread scratch, no allocation per batch
+    AesTables t;
+    aes_build_tables(t, seed);
+    const size_t wb = width / 8;
+    const uint64_t words_per_pair = 2 * n + 1;
+    const uint64_t byte0 = first_pair * words_per_pair * wb, byte1 = (first_pair + npairs) * words_per_pair * wb;
+    const uint64_t blk0 = byte0 / 16, blk1 = (byte1 + 15) / 16;
+    char *small = 0; uint4 *dks = 0;
+    const size_t ptr_bytes = 2 * npairs * sizeof(void *), small_bytes = 256 + ptr_bytes + 2 * npairs * 8;
+    P1CHK(t_scratch.get(device, 0, small_bytes, (void **)&small));
+    P1CHK(t_scratch.get(device, 1, (blk1 - blk0) * 16, (void **)&dks));
+    uint32_t *drk = reinterpret_cast<uint32_t *>(small);
+    uint64_t **dptr = reinterpret_cast<uint64_t **>(small + 256);
+    uint64_t *dr = reinterpret_cast<uint64_t *>(small + 256 + ptr_bytes), *dout = dr + npairs;
+    P1CHK(hipMemcpyAsync(drk, t.rk, sizeof(t.rk), hipMemcpyHostToDevice, 0));
+    P1CHK(hipMemcpyAsync(dptr, x_dst, npairs * sizeof(void *), hipMemcpyHostToDevice, 0));
+    P1CHK(hipMemcpyAsync(dptr + npairs, y_dst, npairs * sizeof(void *), hipMemcpyHostToDevice, 0));
+    P1CHK(hipMemsetAsync(dout, 0, npairs * 8, 0));
+    hipLaunchKernelGGL(ti_prg_kernel, dim3(512), dim3(1024), 0, 0, drk, blk0, blk1 - blk0, dks);
+    const char *ks0 = reinterpret_cast<const char *>(dks) + (byte0 - blk0 * 16);
+    unsigned gx = (unsigned)((2 * n + 1 + 255) / 256); if (gx > 128) gx = 128;
+    unsigned gy = npairs > 65535 ? 65535u : (unsigned)npairs;
+    if (wb == 8) hipLaunchKernelGGL((ti_unpack_scatter_kernel<uint64_t>), dim3(gx, gy), dim3(256), 0, 0, (const uint64_t *)ks0, npairs, n, dptr, dptr + npairs, dr);
+    else hipLaunchKernelGGL((ti_unpack_scatter_kernel<uint32_t>), dim3(gx, gy), dim3(256), 0, 0, (const uint32_t *)ks0, npairs, n, dptr, dptr + npairs, dr);
+    unsigned gd = (unsigned)((n + 255) / 256); if (gd > 64) gd = 64;
+    hipLaunchKernelGGL(p1_dot_ptr_kernel, dim3(gd, gy), dim3(256), 0, 0, dptr, dptr + npairs, npairs, n, dout);
+    P1CHK(hipGetLastError());
+    P1CHK(hipMemcpy(r, dr, npairs * 8, hipMemcpyDeviceToHost));
+    P1CHK(hipMemcpy(xy_minus_r, dout, npairs * 8, hipMemcpyDeviceToHost));
+    const uint64_t m = maskw(width);
+    for (size_t q = 0; q < npairs; q++) xy_minus_r[q] = (xy_minus_r[q] - r[q]) & m;
+    return LGC_OK;
 }

@@ -47,6 +47,61 @@ int read_values(FILE *f, size_t count, int precision, double normalizer, int w2,
     return 0;
 }
 
+/* read_matrix / read_vector for a data provider: the rest of the input file is slurped and scanned token by
+ * token; only the columns this party owns (and the target, if it owns it) are converted -- with strtod, i.e. the
+ * same correctly rounded value "%lf" gives -- and quantised, every other entry stays 0 (it is never used: a
+ * provider only ever touches its own columns).  Token counts and syntax are still checked for the whole file. */
+static int is_num_char(int ch) { return (ch >= '0' && ch <= '9') || ch == '.' || ch == '-' || ch == '+' || ch == 'e' || ch == 'E' || ch == 'i' || ch == 'n' || ch == 'f' || ch == 'a' || ch == 'I' || ch == 'N' || ch == 'F' || ch == 'A' || ch == 'x' || ch == 'X'; }
+static int read_own_columns(FILE *f, size_t n, size_t d, size_t c0, size_t c1, int own_y, int precision, double normalizer, int w2,
+                            int64_t *Xq, int64_t *yq) {
+    long at = ftell(f);
+    if (at < 0 || fseek(f, 0, SEEK_END)) return 1;
+    long end = ftell(f);
+    if (end < at || fseek(f, at, SEEK_SET)) return 1;
+    size_t len = (size_t)(end - at);
+    char *buf = malloc(len + 1);
+    if (!buf || fread(buf, 1, len, f) != len) { free(buf); return 1; }
+    buf[len] = 0;
+    char *p = buf;
+    int rc = 1;
+#define SKIP_WS() while (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f') p++
+    size_t n2 = 0, d2 = 0;
+    { char *e; SKIP_WS(); n2 = strtoull(p, &e, 10); if (e == p) goto out; p = e; SKIP_WS(); d2 = strtoull(p, &e, 10); if (e == p) goto out; p = e; }
+    if (n2 != n || d2 != d) goto out;
+    memset(Xq, 0, n * d * sizeof *Xq);
+    for (size_t k = 0; k < n; k++)
+        for (size_t j = 0; j < d; j++) {
+            SKIP_WS();
+            if (!*p) goto out;
+            if (j >= c0 && j < c1) {
+                char *e;
+                double v = strtod(p, &e);
+                if (e == p) goto out;
+                p = e;
+                Xq[k * d + j] = double_to_fixed(v / normalizer, precision, w2);
+            } else {
+                if (!is_num_char((unsigned char)*p)) goto out;       /* first character checked, the rest of the token skipped */
+                while ((unsigned char)*p > ' ') p++;
+            }
+        }
+    { char *e; SKIP_WS(); n2 = strtoull(p, &e, 10); if (e == p || n2 != n) goto out; p = e; }
+    memset(yq, 0, n * sizeof *yq);
+    for (size_t k = 0; k < n; k++) {
+        SKIP_WS();
+        if (!*p) goto out;
+        char *e;
+        double v = strtod(p, &e);
+        if (e == p) goto out;
+        p = e;
+        if (own_y) yq[k] = double_to_fixed(v / normalizer, precision, w2);
+    }
+#undef SKIP_WS
+    rc = 0;
+out:
+    free(buf);
+    return rc;
+}
+
 /* length-prefixed protobuf message (src/phase1.c:100-145) */
 int send_pmsg(node *self, int to, const uint64_t *vec, size_t n, uint64_t value) {
     size_t sz = pmsg_packed_size(vec, n, value);
@@ -1025,11 +1080,10 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
     lgc_p1 *p1 = 0;
     int rc = 1;
     double normalizer = sqrt(pow(2, precision) * (double)n);      /* src/phase1.c:473 */
-    size_t n2, d2;
-    check(fscanf(c->input, "%zu %zu", &n2, &d2) == 2 && n2 == n && d2 == d, "Input dimensions invalid");
-    check(!read_values(c->input, n * d, precision, normalizer, w2, Xq), "Could not read data");
-    check(fscanf(c->input, "%zu", &n2) == 1 && n2 == n, "Input dimensions invalid");
-    check(!read_values(c->input, n, precision, normalizer, w2, yq), "Could not read target");
+    {
+        const size_t oc0 = (size_t)c->index_owned[me], oc1 = me < last ? (size_t)c->index_owned[me + 1] : d;
+        check(!read_own_columns(c->input, n, d, oc0, oc1, me == last, precision, normalizer, w2, Xq, yq), "Could not read data (dimensions or numbers invalid)");
+    }
     if (getenv("LINREG_TIMING")) fprintf(stderr, "party %d: input parsed after %.2fs\n", c->party, wall_clock() - t_start);
     LGC(lgc_p1_create(&p1, device, n, d, w1, precision));
     LGC(lgc_p1_set_data(p1, Xq, yq));
