@@ -338,13 +338,14 @@ static int run_trusted_initializer_ring(node *self, config *c, int w1, int devic
     uint64_t *r = malloc(B * 8), *xyr = malloc(B * 8);
     uint8_t *msg = malloc(1 + B * 8);
     int rc = 1;
-    if (!xp || !xdst || !ydst || !r || !xyr || !msg || NP > 64) goto out;
+    if ((np && !xp) || !xdst || !ydst || !r || !xyr || !msg || NP > 64) goto out;
     for (int k = 2; k < NP; k++) {
         uint8_t h[64];
         if (lgc_dev_alloc(device, kTiRingSlots * slotb, &ring[k], h)) { fprintf(stderr, "%s\n", lgc_last_error()); goto out; }
         scal[k] = malloc(B * 8);
         if (!scal[k] || send_blob(self, k + 1, h, 64)) goto out;
     }
+    for (int k = 2; k < NP; k++) if (tok_expect(self, k + 1, 'O')) goto out;   /* every provider has mapped its ring */
     for (size_t q0 = 0; q0 < np; q0 += B) {
         const size_t nb = np - q0 < B ? np - q0 : B;
         int has[64] = {0};
@@ -390,10 +391,11 @@ static int run_party_ti_ring(node *self, config *c, lgc_p1 *p1, int device, uint
     uint64_t **dst = malloc(B * sizeof *dst), *scal = malloc(B * 8 + 8), *shares = malloc(B * 8 + 8);
     uint8_t *msg = malloc(1 + B * 8);
     int rc = 1;
-    if (!xp || !col || !peer || !dst || !scal || !shares || !msg || NP > 64) goto out;
+    if ((np && !xp) || !col || !peer || !dst || !scal || !shares || !msg || NP > 64) goto out;
     {
         uint8_t h[64];
         if (recv_blob(self, 1, h, 64) || lgc_dev_open(device, h, &ti)) { fprintf(stderr, "could not map the TI ring: %s\n", lgc_last_error()); goto out; }
+        if (tok_send(self, 1, 'O')) goto out;
     }
     for (size_t q = 0; q < np; q++) { if (xp[q].pa == me) shared[xp[q].pb] = 1; if (xp[q].pb == me) shared[xp[q].pa] = 1; }
     for (int k = 2; k < NP; k++) {

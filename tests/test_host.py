@@ -109,8 +109,8 @@ def _run_all(infile, P, args, timeout=300, exe_name="linreg"):
         cmd = [exe, infile, args[0], str(party)] + args[1:]
         procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     outs = [p.communicate(timeout=timeout) for p in procs]
-    for p, (o, e) in zip(procs, outs):
-        assert p.returncode == 0, e.decode()[-2000:]
+    assert all(p.returncode == 0 for p in procs), "\n".join("party %d rc %s: %s" % (k + 1, p.returncode, e.decode()[-600:])
+                                                            for k, (p, (o, e)) in enumerate(zip(procs, outs)))
     return [o.decode() for o, _ in outs]
 
 
@@ -359,3 +359,46 @@ def test_network_accounting_matches_profile_network(tmp_path):
     ref = 24215018695 / (2550 * 1e6)
     for b in (byt[0][1], byt[0][2], byt[2][2], byt[3][2]):
         assert abs(b / (pairs * n) / ref - 1) < 1e-3, (b / (pairs * n), ref)
+
+
+def _small_instance(path, n, d, starts, seed=5):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d)); X /= np.abs(X).max(axis=0)
+    y = X @ rng.random(d) + 0.05 * rng.standard_normal(n)
+    ports = _free_ports(len(starts) + 2)
+    with open(path, "w") as f:
+        f.write("%d %d %d\n127.0.0.1:%d\n127.0.0.1:%d\n" % (n, d, len(starts), ports[0], ports[1]))
+        for k, st in enumerate(starts):
+            f.write("127.0.0.1:%d %d\n" % (ports[2 + k], st))
+        f.write("%d %d\n" % (n, d))
+        np.savetxt(f, X, fmt="%.17g")
+        f.write("%d\n" % n)
+        np.savetxt(f, y[None, :], fmt="%.17g")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("starts,extra", [([0], []), ([0], ["--ti_ring"]), ([0], ["--use_ot"]),            # one provider: no cross-party pair at all
+                                          ([0, 1, 2, 6], ["--ti_ring", "--table_ring"]),                  # ragged: 1, 1, 4, 1(+y) columns
+                                          ([0, 1, 2, 6], ["--ot_ring"]), ([0, 1, 2, 6], [])],
+                         ids=["P1-ti", "P1-ti-ring", "P1-ot", "ragged-ti-ring", "ragged-ot-ring", "ragged-ti"])
+def test_edge_topologies(tmp_path, oracle, starts, extra):
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    path = str(tmp_path / "edge.in")
+    _small_instance(path, 37, 7, starts)
+    outs = _run_all(path, len(starts), ["56", "cgd", "6", "0.01"] + extra)
+    got = re.findall("-?[0-9]+\\.[0-9]+", outs[1].strip().splitlines()[-1])
+    beta = oracle.linreg_file(path, 56, -1, 64, 64, 2, 6, 0.01)
+    assert got == ["%.15f" % (int(v) / 2.0 ** 56) for v in beta]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--ti_ring"], ["--ot_ring"]], ids=["ti", "ti-ring", "ot-ring"])
+def test_phase1_in_32_bits(tmp_path, oracle, extra):
+    """--width_phase1=32 --width_phase2=32 (the reference's BIT_WIDTH_32_P1 / _P2 builds), three providers"""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    path = str(tmp_path / "w32.in")
+    _small_instance(path, 25, 5, [0, 2, 3], seed=9)
+    outs = _run_all(path, 3, ["24", "cholesky", "0", "0.01", "--width_phase1=32", "--width_phase2=32"] + extra)
+    got = re.findall("-?[0-9]+\\.[0-9]+", outs[1].strip().splitlines()[-1])
+    beta = oracle.linreg_file(path, 24, -1, 32, 32, 0, 0, 0.01)
+    assert got == ["%.15f" % (int(v) / 2.0 ** 24) for v in beta]
