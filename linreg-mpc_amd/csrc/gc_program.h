@@ -434,31 +434,30 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.new_launch();
     } else if (alg == ALG_CHOLESKY) {
         const uint32_t y = P.alloc(d), beta = P.alloc(d);
-        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d, d, 4096) + 4 * d);
-        for (size_t j = 0; j < d; j++) {             // cholesky.oc:51-65
+        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d + d, d + 1, 4096) + 4 * d + 8);
+        // cholesky.oc:51-65 (factorisation) and :68-76 (forward substitution) as ONE chain of launches: step j of
+        // the forward substitution, y_j = (b_j - sum_{k<j} L_jk y_k) / L_jj, needs row j of L (complete once
+        // column j - 1 has been scaled) and y_0..y_{j-1}, so its dot product joins the dot products of column
+        // j and its division joins the launch that scales column j.  Same operations on the same operands as
+        // the reference's three loops (results identical); d division launches and 2d narrow launches fewer
+        // on the dependent chain, which is what a small system's run time consists of.
+        for (size_t j = 0; j < d; j++) {
             if (j > 0) {
                 std::vector<Program::DotJob> jobs;
                 for (size_t i = j; i < d; i++) {
                     Program::DotJob J = {Mi(i, j), Mi(i, j), Mi(i, 0), Mi(j, 0), (uint32_t)j, true};
                     jobs.push_back(J);
                 }
+                Program::DotJob F = {bv + (uint32_t)j, bv + (uint32_t)j, Mi(j, 0), y, (uint32_t)j, true};   // :70-73
+                jobs.push_back(F);
                 P.dots(jobs, sc_dot, 4096);
             }
             P.emit(Program::mk(OP_SQRT, Mi(j, j), Mi(j, j)));
             P.new_launch();
             for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_DIV, Mi(k, j), Mi(k, j), Mi(j, j)));
+            P.emit(Program::mk(OP_DIV, y + (uint32_t)j, bv + (uint32_t)j, Mi(j, j)));                       // :75
             P.new_launch();
             for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_COPY, Mi(j, k), Mi(k, j)));
-            P.new_launch();
-        }
-        for (size_t i = 0; i < d; i++) {             // :68-76
-            if (i > 0) {
-                std::vector<Program::DotJob> jobs(1);
-                Program::DotJob J = {bv + (uint32_t)i, bv + (uint32_t)i, Mi(i, 0), y, (uint32_t)i, true};
-                jobs[0] = J;
-                P.dots(jobs, sc_dot, 64);
-            }
-            P.emit(Program::mk(OP_DIV, y + (uint32_t)i, bv + (uint32_t)i, Mi(i, i)));
             P.new_launch();
         }
         for (size_t ii = d; ii-- > 0;) {             // :79-87
