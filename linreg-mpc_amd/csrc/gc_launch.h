@@ -70,6 +70,9 @@ static constexpr int kTpbTabfill = 1024;
 // MAC launches: one workgroup per CU and every record of a launch takes the same time, so a launch runs
 // in rounds of (CUs x waves per workgroup) records and a partly filled last round costs a whole one.
 // Pick the workgroup size (waves) in [lo, hi] that wastes the least: cost = rounds x waves.
+#ifndef GC_MAC_TAIL_SPLIT
+#define GC_MAC_TAIL_SPLIT 0   /* measured on d=100 (10 000 records): 0.067 -> 0.075 s of garbler MAC time: worse */
+#endif
 #ifndef GC_MAC_ADAPT
 #define GC_MAC_ADAPT 0   /* measured: -5 % on a serialised d=100 matvec, +10 % when it overlaps the evaluator chain */
 #endif
@@ -122,6 +125,21 @@ static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words
     if (L.mac_only && L.nrec >= kNarrowMac) {
         constexpr int TPB = G ? kTpbMacG : kTpbMacE;       // upper bound (register budget of the kernel)
         const unsigned per = gc_mac_waves(L.nrec, G ? 10 : 8, TPB / 64);
+#if GC_MAC_TAIL_SPLIT
+        // One workgroup per CU, every record the same length: the launch runs in rounds of (CUs x waves) records and
+        // a partly filled last round costs a whole one.  The records beyond the last full round therefore go into a
+        // second launch of ONE workgroup per CU with just enough waves: an LDS-bound workgroup of w waves takes
+        // about w / 16 of the time of a full one, so the tail costs its share instead of a round.
+        const uint32_t round = gc_num_cus() * per, full = L.nrec / round * round, rest = L.nrec - full;
+        if (!GC_MAC_ADAPT && full && rest && rest < round - round / 8) {
+            unsigned wv = (rest + gc_num_cus() - 1) / gc_num_cus();
+            hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3(full / per), dim3(per * 64), 0, st, recs + L.first_rec, full, words,
+                               tab, L.step0, R, w, p);
+            hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((rest + wv - 1) / wv), dim3(wv * 64), 0, st, recs + L.first_rec + full, rest,
+                               words, tab, L.step0, R, w, p);
+            return hipGetLastError();
+        }
+#endif
         hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(per * 64), 0, st, recs + L.first_rec,
                            L.nrec, words, tab, L.step0, R, w, p);
     } else if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) {
