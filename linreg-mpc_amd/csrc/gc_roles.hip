@@ -169,11 +169,14 @@ static int export_labels(lgc_party *p, size_t share, const uint64_t *values, uin
     const uint32_t n = (uint32_t)(p->P.T + p->P.d);
     const size_t bits = (size_t)n * p->P.w;
     Lbl *d0 = 0, *d1 = 0; uint64_t *dv = 0;
-    RCHK(hipMalloc(&d0, bits * 16)); dev_guard.add(d0);
-    if (m1) RCHK(hipMalloc(&d1, bits * 16)); dev_guard.add(d1);
+    // both labels of every input bit pass through these two buffers (their XOR is R): cleared before they are freed
+    RCHK(hipMalloc(&d0, bits * 16)); dev_guard.add_secret(d0, bits * 16);
+    if (m1) RCHK(hipMalloc(&d1, bits * 16));
+    dev_guard.add_secret(d1, bits * 16);
     if (values) { RCHK(hipMalloc(&dv, n * 8)); dev_guard.add(dv); RCHK(hipMemcpy(dv, values, n * 8, hipMemcpyHostToDevice)); }
     hipLaunchKernelGGL(gc_export_pairs_kernel, dim3((unsigned)((bits + 255) / 256)), dim3(256), 0, 0, p->words,
                        p->P.in_base + (uint32_t)(share * n), n, p->R, p->P.w, dv, d0, d1);
+    RCHK(hipGetLastError());
     RCHK(hipMemcpy(m0, d0, bits * 16, hipMemcpyDeviceToHost));
     if (m1) RCHK(hipMemcpy(m1, d1, bits * 16, hipMemcpyDeviceToHost));
 
@@ -200,6 +203,7 @@ extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint
     RCHK(hipMemcpy(d, labels, bits * 16, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(gc_import_labels_kernel, dim3((unsigned)((n * 64u + 255) / 256)), dim3(256), 0, 0, p->words,
                        p->P.in_base + (uint32_t)(share * n), n, p->P.w, d);
+    RCHK(hipGetLastError());
     RCHK(hipDeviceSynchronize());
 
     p->labels_ready = true;

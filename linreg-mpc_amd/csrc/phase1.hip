@@ -327,6 +327,7 @@ extern "C" int lgc_p1_local(lgc_p1 *h, size_t c0, size_t c1, int with_y, uint64_
                        dC, kchunk);
     hipLaunchKernelGGL(p1_diag_kernel, dim3((own + P1_DC - 1) / P1_DC), dim3(1024), 0, 0, h->X, h->n, h->d + 1, dcols, own, h->p, h->w,
                        (double)h->d, ddiag);
+    P1CHK(hipGetLastError());
     std::vector<uint64_t> C((size_t)L * L), diag(own);
     P1CHK(hipMemcpy(C.data(), dC, C.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
     P1CHK(hipMemcpy(diag.data(), ddiag, own * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -420,6 +421,7 @@ extern "C" int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const
         for (size_t q0 = 0; q0 < npairs; q0 += 65535) {
             unsigned gy = (unsigned)(npairs - q0 < 65535 ? npairs - q0 : 65535);
             hipLaunchKernelGGL(p1_mask_kernel, dim3(gx, gy), dim3(256), 0, st, h->X, h->n, h->d + 1, dcols + q0, V + q0 * h->n, sign, out + q0 * h->n);
+            P1CHK(hipGetLastError());
         }
         P1CHK(hipGetLastError());
         P1CHK(hipStreamSynchronize(st));
@@ -431,6 +433,7 @@ extern "C" int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const
         P1CHK(hipMemcpyAsync(dV, V, bytes, hipMemcpyHostToDevice, st));
         unsigned g1 = (unsigned)((h->n + 1023) / 1024); if (g1 > 64) g1 = 64;
         hipLaunchKernelGGL(p1_mask1_kernel, dim3(g1), dim3(1024), 0, st, h->X, h->n, h->d + 1, cols[0], dV, sign, dout);
+        P1CHK(hipGetLastError());
         P1CHK(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
         P1CHK(hipStreamSynchronize(st));
         if (h->w == 32) for (size_t i = 0; i < h->n; i++) out[i] &= 0xffffffffull;
@@ -443,6 +446,7 @@ extern "C" int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const
     P1CHK(hipMemcpyAsync(dV, V, bytes, hipMemcpyHostToDevice, st));
     unsigned gx = (unsigned)((h->n + 255) / 256); if (gx > 64) gx = 64;
     hipLaunchKernelGGL(p1_mask_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, st, h->X, h->n, h->d + 1, dcols, dV, sign, dout);
+    P1CHK(hipGetLastError());
     P1CHK(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
     P1CHK(hipStreamSynchronize(st));
     const uint64_t m = maskw(h->w);
@@ -489,6 +493,7 @@ extern "C" int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const
         P1CHK(hipMemsetAsync(dout, 0, sizeof(uint64_t), st));
         unsigned g1 = (unsigned)((h->n + 1023) / 1024); if (g1 > 64) g1 = 64;
         hipLaunchKernelGGL(p1_dot1_kernel, dim3(g1), dim3(1024), 0, st, dA, dB, h->X, h->d + 1, colsB ? colsB[0] : 0u, h->n, dout);
+        P1CHK(hipGetLastError());
         P1CHK(hipMemcpyAsync(out, dout, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         P1CHK(hipStreamSynchronize(st));
         out[0] = (out[0] - (sub ? sub[0] : 0)) & maskw(h->w);
@@ -505,6 +510,7 @@ extern "C" int lgc_p1_dot(lgc_p1 *h, const uint64_t *A, const uint64_t *B, const
     P1CHK(hipMemsetAsync(dout, 0, npairs * sizeof(uint64_t), st));
     unsigned gx = (unsigned)((h->n + 255) / 256); if (gx > 64) gx = 64;
     hipLaunchKernelGGL(p1_dot_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, st, dA, dB, h->X, h->d + 1, dcols, h->n, dout);
+    P1CHK(hipGetLastError());
     P1CHK(hipMemcpyAsync(out, dout, npairs * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     P1CHK(hipStreamSynchronize(st));
     const uint64_t m = maskw(h->w);
@@ -530,6 +536,7 @@ extern "C" int lgc_p1_ti_a(lgc_p1 *h, uint32_t col, const uint64_t *y, const uin
     P1CHK(hipMemsetAsync(dout + n, 0, sizeof(uint64_t), st));
     unsigned g1 = (unsigned)((n + 1023) / 1024); if (g1 > 64) g1 = 64;
     hipLaunchKernelGGL(p1_ti_a_kernel, dim3(g1), dim3(1024), 0, st, h->X, n, h->d + 1, col, dy, din, dout);
+    P1CHK(hipGetLastError());
     P1CHK(hipMemcpyAsync(out_mask, dout, bytes, hipMemcpyDeviceToHost, st));
     uint64_t acc = 0;
     P1CHK(hipMemcpyAsync(&acc, dout + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -648,16 +655,19 @@ static int ti_generate(int device, const uint8_t seed[16], uint64_t first_pair, 
     uint4 *dks = 0;
     P1CHK(hipMalloc(&dks, (blk1 - blk0) * 16)); dev_guard.add(dks);
     hipLaunchKernelGGL(ti_prg_kernel, dim3(512), dim3(1024), 0, 0, drk, blk0, blk1 - blk0, dks);
+    P1CHK(hipGetLastError());
     const uint64_t m = maskw(width);
     uint64_t *dA = 0, *dB = 0, *dr = 0, *dout = 0;
     size_t bytes = npairs * n * 8;
     P1CHK(hipMalloc(&dA, bytes)); dev_guard.add(dA); P1CHK(hipMalloc(&dB, bytes)); dev_guard.add(dB); P1CHK(hipMalloc(&dr, npairs * 8)); dev_guard.add(dr); P1CHK(hipMalloc(&dout, npairs * 8)); dev_guard.add(dout);
     hipLaunchKernelGGL(ti_unpack_kernel, dim3(1024), dim3(256), 0, 0, (const uint8_t *)dks, (size_t)(byte0 - blk0 * 16), npairs, n,
                        (int)wb, dA, dB, dr);
+    P1CHK(hipGetLastError());
     P1CHK(hipMemset(dout, 0, npairs * 8));
     unsigned gx = (unsigned)((n + 255) / 256); if (gx > 64) gx = 64;
     hipLaunchKernelGGL(p1_dot_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, 0, dA, dB, (const int64_t *)0, (size_t)0,
                        (const uint32_t *)0, n, dout);
+    P1CHK(hipGetLastError());
     if (x_dst) {
         return lgc_fail(LGC_EINVAL, "internal: scatter requests go through ti_generate_scatter");
     } else {
@@ -704,6 +714,7 @@ extern "C" int lgc_ti_generate_scatter(int device, const uint8_t seed[16], uint6
     P1CHK(hipMemcpyAsync(dptr + npairs, y_dst, npairs * sizeof(void *), hipMemcpyHostToDevice, 0));
     P1CHK(hipMemsetAsync(dout, 0, npairs * 8, 0));
     hipLaunchKernelGGL(ti_prg_kernel, dim3(512), dim3(1024), 0, 0, drk, blk0, blk1 - blk0, dks);
+    P1CHK(hipGetLastError());
     const char *ks0 = reinterpret_cast<const char *>(dks) + (byte0 - blk0 * 16);
     unsigned gx = (unsigned)((2 * n + 1 + 255) / 256); if (gx > 128) gx = 128;
     unsigned gy = npairs > 65535 ? 65535u : (unsigned)npairs;

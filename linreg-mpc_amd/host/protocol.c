@@ -151,6 +151,84 @@ int recv_blob(node *self, int from, void *buf, uint64_t len) {
 #define TCHK(x) do { if ((x) != 0) { fprintf(stderr, "%s: %s\n", #x, lgc_last_error()); return 1; } } while (0)
 typedef struct { uint8_t handle[64]; uint64_t nslots, slot_bytes; } ring_hello;
 
+/* Two-stage pipeline between the GPU and the socket of the table stream: kTableSlots page-locked buffers of
+ * one launch each; `head` launches have been filled (garbled / received), `tail` have been drained (sent /
+ * evaluated).  The reference's Yao protocol overlaps nothing here (osend per gate, bcipher/yao), and a serial
+ * garble -> copy -> send -> next loop leaves the GPU, the PCIe link and the socket each idle two thirds of the time. */
+enum { kTableSlots = 3 };
+typedef struct {
+    node *self; int peer; lgc_party *po; size_t nl;
+    uint8_t *buf[kTableSlots]; int pinned;
+    size_t head, tail; int failed;
+    pthread_mutex_t mu; pthread_cond_t cv;
+} table_pipe;
+static void table_pipe_free(table_pipe *t) {
+    for (int k = 0; k < kTableSlots; k++) { if (t->pinned) lgc_host_free(t->buf[k]); else free(t->buf[k]); t->buf[k] = NULL; }
+    pthread_mutex_destroy(&t->mu); pthread_cond_destroy(&t->cv);
+}
+static int table_pipe_init(table_pipe *t, node *self, int peer, lgc_party *po, size_t nl, size_t chunk) {
+    memset(t, 0, sizeof *t);
+    t->self = self; t->peer = peer; t->po = po; t->nl = nl;
+    size_t biggest = 0;
+    for (size_t i = 0; i < nl; i++) { size_t b = lgc_party_table_bytes(po, i); if (b > biggest) biggest = b; }
+    if (biggest < chunk) biggest = chunk;
+    pthread_mutex_init(&t->mu, NULL); pthread_cond_init(&t->cv, NULL);
+    t->pinned = 1;
+    for (int k = 0; k < kTableSlots; k++) {
+        t->buf[k] = lgc_host_alloc(biggest + 4096);
+        if (!t->buf[k]) { fprintf(stderr, "table stream: %s\n", lgc_last_error()); table_pipe_free(t); return 1; }
+    }
+    return 0;
+}
+static void table_pipe_fail(table_pipe *t) {
+    pthread_mutex_lock(&t->mu); t->failed = 1; pthread_cond_broadcast(&t->cv); pthread_mutex_unlock(&t->mu);
+}
+static int table_pipe_failed(table_pipe *t) {
+    pthread_mutex_lock(&t->mu); int f = t->failed; pthread_mutex_unlock(&t->mu); return f;
+}
+/* producer side of buffer i % kTableSlots: wait until launch i - kTableSlots has been drained */
+static uint8_t *table_pipe_acquire(table_pipe *t, size_t i) {
+    pthread_mutex_lock(&t->mu);
+    while (!t->failed && i >= t->tail + kTableSlots) pthread_cond_wait(&t->cv, &t->mu);
+    int f = t->failed;
+    pthread_mutex_unlock(&t->mu);
+    return f ? NULL : t->buf[i % kTableSlots];
+}
+static void table_pipe_publish(table_pipe *t) {
+    pthread_mutex_lock(&t->mu); t->head++; pthread_cond_broadcast(&t->cv); pthread_mutex_unlock(&t->mu);
+}
+/* consumer side: wait until launch i has been filled */
+static uint8_t *table_pipe_take(table_pipe *t, size_t i) {
+    pthread_mutex_lock(&t->mu);
+    while (!t->failed && t->head <= i) pthread_cond_wait(&t->cv, &t->mu);
+    int f = t->failed;
+    pthread_mutex_unlock(&t->mu);
+    return f ? NULL : t->buf[i % kTableSlots];
+}
+static void table_pipe_release(table_pipe *t) {
+    pthread_mutex_lock(&t->mu); t->tail++; pthread_cond_broadcast(&t->cv); pthread_mutex_unlock(&t->mu);
+}
+static void *table_pipe_sender(void *arg) {
+    table_pipe *t = arg;
+    for (size_t i = 0; i < t->nl; i++) {
+        uint8_t *tab = table_pipe_take(t, i);
+        if (!tab) break;
+        if (send_blob(t->self, t->peer, tab, lgc_party_table_bytes(t->po, i))) { table_pipe_fail(t); break; }
+        table_pipe_release(t);
+    }
+    return NULL;
+}
+static void *table_pipe_receiver(void *arg) {
+    table_pipe *t = arg;
+    for (size_t i = 0; i < t->nl; i++) {
+        uint8_t *tab = table_pipe_acquire(t, i);
+        if (!tab) break;
+        if (recv_blob(t->self, t->peer, tab, lgc_party_table_bytes(t->po, i))) { table_pipe_fail(t); break; }
+        table_pipe_publish(t);
+    }
+    return NULL;
+}
+
 int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk) {
     const size_t nl = lgc_party_num_launches(po);
     if (ring_slots > 0) {
@@ -169,14 +247,22 @@ int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
         }
         return 0;
     }
-    uint8_t *tab = malloc(chunk + 4096);
-    if (!tab) return 1;
-    for (size_t i = 0; i < nl; i++) {
-        if (lgc_party_garble(po, i, tab) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); free(tab); return 1; }
-        if (send_blob(self, peer, tab, lgc_party_table_bytes(po, i))) { free(tab); return 1; }
+    /* socket mode: launch i + 1 is garbled and copied out while launch i is on the wire */
+    table_pipe tp;
+    if (table_pipe_init(&tp, self, peer, po, nl, chunk)) return 1;
+    pthread_t th;
+    if (pthread_create(&th, NULL, table_pipe_sender, &tp)) { table_pipe_free(&tp); return 1; }
+    for (size_t i = 0; i < nl && !table_pipe_failed(&tp); i++) {
+        uint8_t *tab = table_pipe_acquire(&tp, i);           /* waits until the sender is through with this slot */
+        if (!tab) break;
+        if (lgc_party_garble(po, i, tab) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); table_pipe_fail(&tp); break; }
+        table_pipe_publish(&tp);
     }
-    free(tab);
-    return 0;
+    if (table_pipe_failed(&tp)) pthread_cancel(th);          /* the thread may sit in send() on a dead peer */
+    pthread_join(th, NULL);
+    int rc = table_pipe_failed(&tp);
+    table_pipe_free(&tp);
+    return rc;
 }
 
 int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk,
@@ -195,15 +281,23 @@ int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
         }
         return 0;
     }
-    uint8_t *tab = malloc(chunk + 4096);
-    if (!tab) return 1;
+    /* socket mode: launch i + 1 is read from the socket while launch i is copied in and evaluated */
+    table_pipe tp;
+    if (table_pipe_init(&tp, self, peer, po, nl, chunk)) return 1;
+    pthread_t th;
+    if (pthread_create(&th, NULL, table_pipe_receiver, &tp)) { table_pipe_free(&tp); return 1; }
     for (size_t i = 0; i < nl; i++) {
-        if (recv_blob(self, peer, tab, lgc_party_table_bytes(po, i))) { free(tab); return 1; }
-        if (lgc_party_evaluate(po, i, tab) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); free(tab); return 1; }
+        const uint8_t *tab = table_pipe_take(&tp, i);        /* waits until launch i has arrived */
+        if (!tab) break;
+        if (lgc_party_evaluate(po, i, tab) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); table_pipe_fail(&tp); break; }
+        table_pipe_release(&tp);
         if (after_launch) after_launch(i, ctx);
     }
-    free(tab);
-    return 0;
+    if (table_pipe_failed(&tp)) pthread_cancel(th);          /* the thread may sit in recv() */
+    pthread_join(th, NULL);
+    int rc = table_pipe_failed(&tp);
+    table_pipe_free(&tp);
+    return rc;
 }
 
 /* ---------------------------------------------------------------- phase 1: trusted initializer */
