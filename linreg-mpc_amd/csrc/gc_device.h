@@ -176,6 +176,24 @@ __device__ __forceinline__ Lbl ld_lbl(const Lbl *p) {
 __device__ __forceinline__ void st_lbl(Lbl *p, Lbl v) {
     *reinterpret_cast<uint4 *>(p) = make_uint4(v.x, v.y, v.z, v.w);
 }
+// The same store with the address space spelled out.  Where one branch of a wave-uniform `if` stores a label to
+// the table buffer and the other one to the LDS exchange area, the compiler otherwise sinks the two stores into ONE
+// flat_store (seen in the 4-wave critical-path step): a flat store counts on lgkmcnt, so the wait in front of the
+// workgroup barrier then sat out a global-memory round trip on every gate level (15 % of a divider's time).
+typedef uint32_t gc_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_lbl_global(Lbl *p, Lbl v) {
+    gc_u32x4 d = {v.x, v.y, v.z, v.w};
+    *(__attribute__((address_space(1))) gc_u32x4 *)p = d;
+}
+__device__ __forceinline__ Lbl ld_lbl_global(const Lbl *p) {
+    gc_u32x4 v = *(const __attribute__((address_space(1))) gc_u32x4 *)p;
+    Lbl r = {v.x, v.y, v.z, v.w};
+    return r;
+}
+__device__ __forceinline__ void st_lbl_lds(Lbl *p, Lbl v) {
+    gc_u32x4 d = {v.x, v.y, v.z, v.w};
+    *(__attribute__((address_space(3))) gc_u32x4 *)p = d;
+}
 
 // MODE_MAC : one wave does all AES of its gate step, gate body inlined (MAC kernel).
 // MODE_SOLO: the same with one out-of-line gate body: generic records in WIDE launches
@@ -255,6 +273,9 @@ struct GpuBackend {
         return sel(0xffffffffull, lo, hi);
     }
     __device__ __forceinline__ W pull(W a, int from, bool ok) const {
+#ifdef GC_X_NOSHL           /* timing experiments only */
+        return a;
+#endif
         int addr = (from & 63) << 2;
         W r = {(uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)a.x), (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)a.y),
                (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)a.z), (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)a.w)};
@@ -301,10 +322,10 @@ struct GpuBackend {
             if (GARBLER) {
                 Lbl TG, TE;
                 c = garble_and(lt, c_rk, R, a, b, gid, TG, TE, c_rk24);
-                st_lbl(slot, TG);
-                st_lbl(slot + 64, TE);
+                st_lbl_global(slot, TG);
+                st_lbl_global(slot + 64, TE);
             } else {
-                Lbl TG = ld_lbl(slot), TE = ld_lbl(slot + 64);
+                Lbl TG = ld_lbl_global(slot), TE = ld_lbl_global(slot + 64);
                 c = eval_and(lt, c_rk, a, b, gid, TG, TE, c_rk24);
             }
         }
@@ -329,10 +350,12 @@ struct GpuBackend {
                     uint64_t tw = 2 * gid + (uint64_t)wave;
                     hash_n<1, TAB>(lt, c_rk, &x, &tw, &h, c_rk24);
                 }
-                xbuf[wave * 64 + lane] = h;
+                st_lbl_lds(xbuf + wave * 64 + lane, h);
             } else {
                 Lbl v = (wave == 2) ? a : b;     // the zero-labels, for gc_tabfill_kernel
-                st_lbl(slot + (wave - 2) * 64, on ? v : lzero());
+#ifndef GC_X_NOSTASH
+                st_lbl_global(slot + (wave - 2) * 64, on ? v : lzero());
+#endif
             }
             lds_barrier();
             W c = lzero();
@@ -393,8 +416,10 @@ struct GpuBackend {
                 uint64_t tw = 2 * (g2 ? gid2 : gid) + (uint64_t)(wave & 1);
                 hash_n<1, TAB>(lt, c_rk, &x, &tw, &h, c_rk24);
             }
-            xbuf[wave * 64 + lane] = h;
-            st_lbl(slot + wave * 64, on ? src : lzero());
+            st_lbl_lds(xbuf + wave * 64 + lane, h);
+#ifndef GC_X_NOSTASH
+            st_lbl_global(slot + wave * 64, on ? src : lzero());
+#endif
             lds_barrier();
             c1 = lzero();
             c2 = lzero();

@@ -7,6 +7,7 @@
 
 #include "gc_device.h"
 #include "gc_program.h"
+#include "gc_split.h"
 
 namespace gc {
 
@@ -66,6 +67,11 @@ static constexpr uint32_t kNarrowMac = 1024;
 #endif
 static constexpr uint32_t kExclusiveMac = GC_EXCLUSIVE_MAC_RECS;
 static constexpr int kTpbTabfill = 1024;
+// launches of at most one workgroup per CU run column-split on 16 waves per record (gc_split.h); the garbler side is
+// critical-path garbling by construction, so it follows GC_CRIT
+#ifndef GC_SPLIT
+#define GC_SPLIT GC_CRIT
+#endif
 
 // MAC launches: one workgroup per CU and every record of a launch takes the same time, so a launch runs
 // in rounds of (CUs x waves per workgroup) records and a partly filled last round costs a whole one.
@@ -146,6 +152,9 @@ static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words
         constexpr unsigned per = kTpbWide / 64;
         hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(kTpbWide), 0, st,
                            recs + L.first_rec, L.nrec, words, tab, dec, L.step0, R, w, p);
+    } else if (GC_SPLIT && L.nrec <= kQuadOnePerCu) {
+        hipLaunchKernelGGL((gc_split_kernel<G>), dim3(L.nrec), dim3(1024), 0, st, recs + L.first_rec, L.nrec, words, tab, dec, L.step0,
+                           R, w, p);
     } else if (L.nrec <= kQuadOnePerCu) {
         hipLaunchKernelGGL((gc_exec_kernel<G, true, 4, 256, G && GC_CRIT>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec,
                            L.nrec, words, tab, dec, L.step0, R, w, p);

@@ -1,0 +1,271 @@
+// gc_split.h -- "column-split" execution of latency-bound records (dividers, square roots, max trees: launches
+// of so few records that the chain of dependent gate levels of ONE record is the run time).
+//
+// In the 4-wave mode (gc_device.h, MODE_QUAD) a lane owns one gate and hashes whole AES blocks: 16 table lookups
+// per round, ~41 instructions per round and wave, and a wave issues them one after the other -- 2200 cycles per hash
+// on a CU that is otherwise idle (scripts/exp/lat2.hip).  Here the state of a block is spread over the four lanes of
+// a quad (lane 4j + c holds column c of block j; ShiftRows is three quad_perm DPP moves), a wave issues 4 lookups per
+// round, and one hash of the 64 gates of a step takes four waves.  A workgroup is 16 waves:
+//
+//   * waves 0..3 ("glue" waves) run the record's circuit, wave c holding COLUMN c (one dword) of every label, lane =
+//     gate: free-XOR glue is one instruction instead of four, lane moves are one ds_bpermute / v_readlane;
+//   * at a gate step they put the operand columns into LDS, and all 16 waves hash: wave 4q + r takes hash q (operand
+//     q of the step: a1, b1, a2, b2) of gates 16r .. 16r + 15 in quad layout, writes its column of the result back,
+//     and the glue waves pick the results up.  Two workgroup barriers per level.
+//
+// Measured (scripts/exp/lat4.hip): 1484 cycles per 2-hash level against 2379, 2142 per 4-hash level against 2915.
+//
+// Gate numbering, tweaks, table rows and (for the garbler) the critical-path scheme with its (a0, b0) stash are those
+// of MODE_QUAD with CRIT: a launch garbled here can be evaluated by either kernel and the other way round.
+#pragma once
+#include "gc_device.h"
+
+namespace gc {
+
+template <int CTRL> __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+
+// lane 4j + c: x = column c of label j, twc = tweak word of this column (c = 0: low, c = 1: high, else 0).
+// Returns column c of H(x_j, tweak_j) = pi(sigma(x) ^ t) ^ sigma(x) ^ t  (gc_aes.h: hash_prep / hash_n)
+__device__ __forceinline__ uint32_t hash_split(const LdsTab4 &lt, const uint32_t rkl[11], uint32_t x, uint32_t twc, int c) {
+    const uint32_t t = quad_perm<0x4E>(x);                 // lanes 0,1 <- columns 2,3 ; lanes 2,3 <- columns 0,1
+    const uint32_t k = (c < 2) ? (t ^ twc) : (x ^ t);
+    uint32_t s = k ^ rkl[0];
+#pragma unroll
+    for (int rnd = 1; rnd < 10; rnd++) {
+        const uint32_t s1 = quad_perm<0x39>(s), s2 = quad_perm<0x4E>(s), s3 = quad_perm<0x93>(s);   // columns c+1, c+2, c+3
+        const uint32_t v0 = lt.lkt(0, s, 0), v1 = lt.lkt(1, s1, 1), v2 = lt.lkt(2, s2, 2), v3 = lt.lkt(3, s3, 3);
+        s = xor3(xor3(v0, v1, rkl[rnd]), v2, v3);
+    }
+    const uint32_t s1 = quad_perm<0x39>(s), s2 = quad_perm<0x4E>(s), s3 = quad_perm<0x93>(s);
+    const uint32_t v0 = lt.lk(s, 0), v1 = lt.lk(s1, 1), v2 = lt.lk(s2, 2), v3 = lt.lk(s3, 3);
+    s = xor3(last_lo(v1, v0), last_hi(v3, v2), rkl[10]);
+    return s ^ k;
+}
+
+// LDS exchange areas (dwords).  A plane holds one column of the 64 labels of a word; planes are 72 dwords apart so
+// that both access patterns are conflict-free: glue wave c, lane g touches plane c at g (linear); hash lane 4j + c of
+// gate block r touches plane c at 16r + j (bank 8c + 16r + j mod 32: two lanes per bank, as any 64-lane access).
+enum {
+    kSplitPlane = 72,
+    kSplitWord = 4 * kSplitPlane,          // one operand / one hash result: 4 planes
+    kSplitOp = 0,                          // operands a1, b1, a2, b2
+    kSplitX = 4 * kSplitWord,              // results of hash 0..3
+    kSplitDesc = 8 * kSplitWord,           // kind, act1 (2), act2 (2), step (2)
+    kSplitWords = 8 * kSplitWord + 8
+};
+
+struct SplitDesc {
+    uint32_t kind;          // 0: record finished, 1: one gate step (hashes 0, 1), 2: two gate steps (hashes 0..3)
+    uint64_t act1, act2;    // active gates of the step(s)
+    uint64_t step;          // global index of the (first) gate step
+};
+
+// what every wave of the workgroup needs for the hash phase
+struct SplitHashCtx {
+    LdsTab4 lt;
+    uint32_t rkl[11];       // round-key column lane & 3
+    uint32_t Rq;            // column lane & 3 of the garbler's offset R (0 for the evaluator)
+    uint32_t *sx;           // LDS exchange areas
+    uint32_t *tabw;         // this launch's table buffer, as dwords
+    uint64_t launch_step0;
+    int wave, lane;
+};
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }   // unsigned: no sign extension
+__device__ __forceinline__ void st_u32_global(uint32_t *p, uint32_t v) { *(__attribute__((address_space(1))) uint32_t *)p = v; }
+__device__ __forceinline__ uint32_t ld_u32_global(const uint32_t *p) { return *(const __attribute__((address_space(1))) uint32_t *)p; }
+__device__ __forceinline__ void st_u32_lds(uint32_t *p, uint32_t v) { *(__attribute__((address_space(3))) uint32_t *)p = v; }
+__device__ __forceinline__ uint32_t ld_u32_lds(const uint32_t *p) { return *(const __attribute__((address_space(3))) uint32_t *)p; }
+
+// Hash phase of one level, between the two barriers.  Wave 4q + r: hash q of gates 16r .. 16r + 15.
+//   garbler  : x_a = H(a0 ^ pa R, 2g) ^ (pa & pb) R,  x_b = H(b0 ^ pb R, 2g + 1);  c0 = x_a ^ x_b   (gc_device.h: CRIT);
+//              rows 0 / 1 of the step receive a0 / b0 for gc_tabfill_kernel
+//   evaluator: x_a = H(a, 2g) ^ sa TG,  x_b = H(b, 2g + 1) ^ sb (TE ^ a);  c = x_a ^ x_b
+template <bool GARBLER>
+__device__ __forceinline__ void split_hash_phase(const SplitHashCtx &hc, const SplitDesc &d) {
+    const int q = hc.wave >> 2, r = hc.wave & 3;
+    if (d.kind == 1 && q >= 2) return;
+    const int c = hc.lane & 3, gate = 16 * r + (hc.lane >> 2);
+    const uint64_t act = (q < 2) ? d.act1 : d.act2;
+    if (((act >> (16 * r)) & 0xffffull) == 0) {                        // no active gate in this block (wave-uniform)
+        st_u32_lds(hc.sx + kSplitX + q * kSplitWord + c * kSplitPlane + gate, 0u);
+        if (GARBLER) {
+            const uint64_t st = d.step + (uint64_t)(q >> 1);
+            st_u32_global(hc.tabw + ((st - hc.launch_step0) * 128 + (uint64_t)((q & 1) * 64 + gate)) * 4 + c, 0u);
+        }
+        return;
+    }
+    const bool on = (act >> gate) & 1ull;
+    const uint64_t st = d.step + (uint64_t)(q >> 1);
+    const uint32_t *op = hc.sx + kSplitOp;
+    const uint32_t v = ld_u32_lds(op + q * kSplitWord + c * kSplitPlane + gate);
+    uint32_t *row = hc.tabw + ((st - hc.launch_step0) * 128 + (uint64_t)((q & 1) * 64 + gate)) * 4 + c;
+    uint32_t other = 0, tg = 0;
+    if (GARBLER) {
+        st_u32_global(row, on ? v : 0u);
+        if (!(q & 1)) other = ld_u32_lds(op + (q + 1) * kSplitWord + gate);             // column 0 of b: its colour
+    } else {
+        tg = ld_u32_global(row);                                                        // TG (hash a) / TE (hash b)
+        if (q & 1) other = ld_u32_lds(op + (q - 1) * kSplitWord + c * kSplitPlane + gate);   // column c of a
+    }
+    const uint32_t colour = quad_perm<0x00>(v) & 1u;                                   // lsb of column 0 of the own operand
+    const uint32_t x = GARBLER ? (v ^ (colour ? hc.Rq : 0u)) : v;
+    const uint32_t tlo = ((uint32_t)st << 7) | (uint32_t)(2 * gate + (q & 1)), thi = (uint32_t)(st >> 25);
+    const uint32_t twc = (c == 0) ? tlo : (c == 1) ? thi : 0u;
+    uint32_t h = hash_split(hc.lt, hc.rkl, x, twc, c);
+    if (GARBLER) {
+        if (!(q & 1)) h ^= (colour & other & 1u) ? hc.Rq : 0u;
+    } else {
+        h ^= colour ? ((q & 1) ? (tg ^ other) : tg) : 0u;
+    }
+    st_u32_lds(hc.sx + kSplitX + q * kSplitWord + c * kSplitPlane + gate, on ? h : 0u);
+}
+
+// The circuit backend of the glue waves: W is ONE column of a word's labels (wave = column, lane = gate).
+template <bool GARBLER>
+struct SplitBackend {
+    typedef uint32_t W;
+    static const bool kPairSteps = true;       // same step numbering as MODE_QUAD
+    SplitHashCtx hc;
+    uint32_t Rc;                               // column `wave` of R
+    Lbl *words;
+    uint64_t *decode;
+    uint64_t step;
+    int wave, lane;
+
+    __device__ __forceinline__ W zero() const { return 0u; }
+    __device__ __forceinline__ bool bit(uint64_t m) const { return __builtin_amdgcn_inverse_ballot_w64(m); }
+    __device__ __forceinline__ W rmask(uint64_t m) const { return bit(m) ? Rc : 0u; }
+    __device__ __forceinline__ W konst(uint64_t bits) const { return GARBLER ? rmask(bits) : 0u; }
+    __device__ __forceinline__ W XOR(W a, W b) const { return a ^ b; }
+    __device__ __forceinline__ W NOTm(W a, uint64_t m) const { return GARBLER ? (a ^ rmask(m)) : a; }
+    __device__ __forceinline__ W sel(uint64_t m, W a, W b) const { return bit(m) ? a : b; }
+    __device__ __forceinline__ W bcast(W a, int src) const { return (uint32_t)__builtin_amdgcn_readlane((int)a, src); }
+    __device__ __forceinline__ W bcast2(W a, int r) const { return sel(0xffffffffull, bcast(a, r), bcast(a, 32 + r)); }
+    __device__ __forceinline__ W pull(W a, int from, bool ok) const {
+        uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((from & 63) << 2, (int)a);
+        return ok ? v : 0u;
+    }
+    __device__ __forceinline__ W shl(W a, int k) const { return k >= 64 ? 0u : pull(a, lane - k, lane >= k); }
+    __device__ __forceinline__ W shr(W a, int k) const { return k >= 64 ? 0u : pull(a, lane + k, lane + k < 64); }
+
+    __device__ __forceinline__ const uint32_t *col(const Lbl *p) const { return reinterpret_cast<const uint32_t *>(p) + wave; }
+    __device__ __forceinline__ uint32_t *col(Lbl *p) const { return reinterpret_cast<uint32_t *>(p) + wave; }
+    __device__ __forceinline__ W load(uint32_t id) const { return ld_u32_global(col(words + (size_t)id * 64 + lane)); }
+    __device__ __forceinline__ W load2(uint32_t lo, uint32_t hi) const {
+        return ld_u32_global(col(words + (size_t)(lane < 32 ? lo : hi) * 64 + (lane & 31)));
+    }
+    __device__ __forceinline__ void store(uint32_t id, W v) { st_u32_global(col(words + (size_t)id * 64 + lane), v); }
+    __device__ __forceinline__ void store2(uint32_t lo, uint32_t hi, W v) {
+        st_u32_global(col(words + (size_t)(lane < 32 ? lo : hi) * 64 + (lane & 31)), v);
+    }
+    __device__ __forceinline__ void reveal(uint32_t slot, W v) {
+        uint64_t m = __ballot(v & 1u);                                  // colour bits live in column 0
+        if (wave == 0 && lane == 0) decode[slot] = m;
+    }
+
+    __device__ __forceinline__ void publish(int k, W v) { st_u32_lds(hc.sx + kSplitOp + k * kSplitWord + wave * kSplitPlane + lane, v); }
+    __device__ __forceinline__ W result(int q) const { return ld_u32_lds(hc.sx + kSplitX + q * kSplitWord + wave * kSplitPlane + lane); }
+    __device__ __forceinline__ void post(const SplitDesc &d) {
+        if (wave == 0 && lane == 0) {
+            uint32_t *p = hc.sx + kSplitDesc;
+            p[0] = d.kind;
+            p[1] = (uint32_t)d.act1; p[2] = (uint32_t)(d.act1 >> 32);
+            p[3] = (uint32_t)d.act2; p[4] = (uint32_t)(d.act2 >> 32);
+            p[5] = (uint32_t)d.step; p[6] = (uint32_t)(d.step >> 32);
+        }
+    }
+    __device__ __forceinline__ W AND(W a, W b, uint64_t act) {
+        SplitDesc d = {1u, act, 0ull, step};
+        step++;
+        publish(0, a);
+        publish(1, b);
+        post(d);
+        lds_barrier();
+        split_hash_phase<GARBLER>(hc, d);
+        lds_barrier();
+        return bit(act) ? (result(0) ^ result(1)) : 0u;
+    }
+    __device__ __forceinline__ void AND2(W a1, W b1, uint64_t act1, W a2, W b2, uint64_t act2, W &c1, W &c2) {
+        SplitDesc d = {2u, act1, act2, step};
+        step += 2;
+        publish(0, a1);
+        publish(1, b1);
+        publish(2, a2);
+        publish(3, b2);
+        post(d);
+        lds_barrier();
+        split_hash_phase<GARBLER>(hc, d);
+        lds_barrier();
+        c1 = bit(act1) ? (result(0) ^ result(1)) : 0u;
+        c2 = bit(act2) ? (result(2) ^ result(3)) : 0u;
+    }
+    // the record is complete: release the hash waves
+    __device__ __forceinline__ void finish() {
+        SplitDesc d = {0u, 0ull, 0ull, 0ull};
+        post(d);
+        lds_barrier();
+    }
+};
+
+// one 16-wave workgroup per record
+template <bool GARBLER>
+__global__ void __launch_bounds__(1024)
+gc_split_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *decode, uint64_t launch_step0, Lbl R, int w, int p) {
+    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    __shared__ uint32_t lds_sx[kSplitWords];
+    lds_tab4_fill(lds_te0);
+    const uint32_t wid = blockIdx.x;
+    if (wid >= nrec) return;
+    SplitHashCtx hc;
+    hc.lt = lds_tab4_make(lds_te0);
+    hc.lane = threadIdx.x & 63;
+    hc.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = hc.lane & 3;
+#pragma unroll
+    for (int k = 0; k < 11; k++) hc.rkl[k] = c_rk[4 * k + c];
+    hc.Rq = GARBLER ? (c == 0 ? R.x : c == 1 ? R.y : c == 2 ? R.z : R.w) : 0u;
+    hc.sx = lds_sx;
+    hc.tabw = reinterpret_cast<uint32_t *>(tab);
+    hc.launch_step0 = launch_step0;
+    if (hc.wave >= 4) {
+        // hash waves: serve the levels the glue waves post
+        for (;;) {
+            lds_barrier();
+            const uint32_t *dp = lds_sx + kSplitDesc;
+            SplitDesc d;
+            d.kind = rfl(ld_u32_lds(dp));
+            if (d.kind == 0u) return;
+            d.act1 = ((uint64_t)rfl(ld_u32_lds(dp + 2)) << 32) | rfl(ld_u32_lds(dp + 1));
+            d.act2 = ((uint64_t)rfl(ld_u32_lds(dp + 4)) << 32) | rfl(ld_u32_lds(dp + 3));
+            d.step = ((uint64_t)rfl(ld_u32_lds(dp + 6)) << 32) | rfl(ld_u32_lds(dp + 5));
+            split_hash_phase<GARBLER>(hc, d);
+            lds_barrier();
+        }
+    }
+    SplitBackend<GARBLER> be;
+    be.hc = hc;
+    be.wave = hc.wave;
+    be.lane = hc.lane;
+    be.Rc = GARBLER ? (hc.wave == 0 ? R.x : hc.wave == 1 ? R.y : hc.wave == 2 ? R.z : R.w) : 0u;
+    be.words = words;
+    be.decode = decode;
+    Rec r = recs[wid];
+    r.op = __builtin_amdgcn_readfirstlane(r.op);
+    r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);
+    r.dst = __builtin_amdgcn_readfirstlane(r.dst);
+    r.a = __builtin_amdgcn_readfirstlane(r.a);
+    r.b = __builtin_amdgcn_readfirstlane(r.b);
+    r.c = __builtin_amdgcn_readfirstlane(r.c);
+    r.sa = __builtin_amdgcn_readfirstlane(r.sa);
+    r.sb = __builtin_amdgcn_readfirstlane(r.sb);
+    uint32_t s_lo = __builtin_amdgcn_readfirstlane((uint32_t)r.step0);
+    uint32_t s_hi = __builtin_amdgcn_readfirstlane((uint32_t)(r.step0 >> 32));
+    be.step = ((uint64_t)s_hi << 32) | s_lo;
+    exec_record(be, r, w, p);
+    be.finish();
+}
+
+}  // namespace gc
