@@ -319,10 +319,6 @@ int lgc_ot_labels_recv_start(lgc_ot_receiver *r, const uint8_t *choice, size_t m
 int lgc_ot_labels_send(lgc_ot_sender *s, const uint8_t *msg0, const uint8_t *msg1, size_t m, const uint8_t *u_in, uint8_t *e_out);
 int lgc_ot_labels_recv_finish(lgc_ot_receiver *r, const uint8_t *e_in, uint8_t *out);
 
-/* ------------------------------------------------------- micro-benchmarks */
-/* Stand-alone LDS T-table AES throughput (the "AES roofline" of the north
- * star): blocks_per_lane AES-128 encryptions in every lane of `waves` waves.
- * Returns blocks/second in *rate; *check gets an XOR checksum. */
 /* Page-locked host memory for buffers that are handed to the entry points above (tables, OT
  * messages, phase-1 vectors): the copies to and from the GPU then run as DMA at PCIe speed instead
  * of through a pageable staging copy.  Optional -- every entry point accepts ordinary memory.
@@ -330,6 +326,16 @@ int lgc_ot_labels_recv_finish(lgc_ot_receiver *r, const uint8_t *e_in, uint8_t *
 void *lgc_host_alloc(size_t bytes);
 void lgc_host_free(void *p);
 
+/* Kernel choice for latency-bound launches (at most one record per CU), per role: non-zero (the
+ * default) runs them column-split on 16 waves per record, zero on 4 waves per record.  Both produce
+ * and consume the same garbled tables, so garbler and evaluator may differ; process-wide, takes
+ * effect at the next launch.  Exists for A/B timing and for the interchangeability test. */
+void lgc_set_split_kernels(int garbler, int evaluator);
+
+/* ------------------------------------------------------- micro-benchmarks */
+/* Stand-alone LDS T-table AES throughput (the "AES roofline" of the north
+ * star): blocks_per_lane AES-128 encryptions in every lane of `waves` waves.
+ * Returns blocks/second in *rate; *check gets an XOR checksum. */
 int lgc_aes_bench(int device, int waves, int blocks_per_lane, double *rate, uint32_t *check);
 /* AES-128 of `n` 16-byte blocks with the fixed key on the device (known-answer tests). */
 int lgc_aes_encrypt(int device, const uint8_t *in, uint8_t *out, size_t n);

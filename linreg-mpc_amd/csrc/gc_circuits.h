@@ -45,7 +45,15 @@ struct Circ {
     // ---- Kogge-Stone adder over lanes [0, n): returns x + y + cin (mod 2^n).
     // cinw: word whose lane 0 holds the carry-in (other lanes zero) or zero().
     // cout (optional): carry out of lane n-1, broadcast to every lane.
-    static GC_HD W add(B &be, W x, W y, int n, W cinw, W *cout) {
+    static GC_HD W add(B &be, W x, W y, int n, W cinw, W *cout) { return add_pick(be, x, y, n, cinw, cout, 0); }
+    // a backend may run the whole addition itself (same gate steps in the same order): gc_split.h
+    template <class BB>
+    static GC_HD auto add_pick(BB &be, W x, W y, int n, W cinw, W *cout, int) -> decltype(be.add_native(x, y, n, cinw, cout)) {
+        return be.add_native(x, y, n, cinw, cout);
+    }
+    template <class BB>
+    static GC_HD W add_pick(BB &be, W x, W y, int n, W cinw, W *cout, long) { return add_generic(be, x, y, n, cinw, cout); }
+    static GC_HD W add_generic(B &be, W x, W y, int n, W cinw, W *cout) {
         const uint64_t act = lanes(n);
         W P = be.XOR(x, y);
         // lane 0: maj(x0, y0, cin) = ((x0^c)&(y0^c))^c ; other lanes: x&y

@@ -703,6 +703,11 @@ extern "C" void *lgc_host_alloc(size_t bytes) {
 }
 extern "C" void lgc_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+extern "C" void lgc_set_split_kernels(int garbler, int evaluator) {
+    gc_split_enabled(true) = garbler != 0;
+    gc_split_enabled(false) = evaluator != 0;
+}
+
 // --------------------------------------------------------- micro-benchmarks
 extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double *rate, uint32_t *check) {
     DevFree dev_guard;   // temporary device buffers are released on every return path

@@ -72,6 +72,11 @@ static constexpr int kTpbTabfill = 1024;
 #ifndef GC_SPLIT
 #define GC_SPLIT GC_CRIT
 #endif
+// ... switchable per role at run time (lgc_set_split_kernels): the two kernels are interchangeable
+inline int &gc_split_enabled(bool garbler) {
+    static int on[2] = {1, 1};
+    return on[garbler ? 0 : 1];
+}
 
 // MAC launches: one workgroup per CU and every record of a launch takes the same time, so a launch runs
 // in rounds of (CUs x waves per workgroup) records and a partly filled last round costs a whole one.
@@ -152,7 +157,7 @@ static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words
         constexpr unsigned per = kTpbWide / 64;
         hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(kTpbWide), 0, st,
                            recs + L.first_rec, L.nrec, words, tab, dec, L.step0, R, w, p);
-    } else if (GC_SPLIT && L.nrec <= kQuadOnePerCu) {
+    } else if (GC_SPLIT && gc_split_enabled(G) && L.nrec <= kQuadOnePerCu) {
         hipLaunchKernelGGL((gc_split_kernel<G>), dim3(L.nrec), dim3(1024), 0, st, recs + L.first_rec, L.nrec, words, tab, dec, L.step0,
                            R, w, p);
     } else if (L.nrec <= kQuadOnePerCu) {

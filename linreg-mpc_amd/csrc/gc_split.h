@@ -32,6 +32,9 @@ __device__ __forceinline__ uint32_t hash_split(const LdsTab4 &lt, const uint32_t
     const uint32_t t = quad_perm<0x4E>(x);                 // lanes 0,1 <- columns 2,3 ; lanes 2,3 <- columns 0,1
     const uint32_t k = (c < 2) ? (t ^ twc) : (x ^ t);
     uint32_t s = k ^ rkl[0];
+#ifdef GC_X_NOHASH          /* timing experiments only (scripts/exp): results are wrong with it */
+    return s;
+#endif
 #pragma unroll
     for (int rnd = 1; rnd < 10; rnd++) {
         const uint32_t s1 = quad_perm<0x39>(s), s2 = quad_perm<0x4E>(s), s3 = quad_perm<0x93>(s);   // columns c+1, c+2, c+3
@@ -50,14 +53,17 @@ __device__ __forceinline__ uint32_t hash_split(const LdsTab4 &lt, const uint32_t
 enum {
     kSplitPlane = 72,
     kSplitWord = 4 * kSplitPlane,          // one operand / one hash result: 4 planes
-    kSplitOp = 0,                          // operands a1, b1, a2, b2
-    kSplitX = 4 * kSplitWord,              // results of hash 0..3
-    kSplitDesc = 8 * kSplitWord,           // kind, act1 (2), act2 (2), step (2)
-    kSplitWords = 8 * kSplitWord + 8
+    kSplitOp = 0,                          // operands a1, b1, a2, b2 (adder: x, y, carry-in)
+    kSplitX = 4 * kSplitWord,              // results of hash 0..3 (adder: sum, final generate word)
+    kSplitKs = 8 * kSplitWord,             // adder levels: two buffers of four hash results (level parity)
+    kSplitGs = 16 * kSplitWord,            // adder levels: two snapshots of the generate word
+    kSplitDesc = 18 * kSplitWord,          // kind, act1 (2), act2 (2), step (2), width
+    kSplitWords = 18 * kSplitWord + 8
 };
 
 struct SplitDesc {
-    uint32_t kind;          // 0: record finished, 1: one gate step (hashes 0, 1), 2: two gate steps (hashes 0..3)
+    uint32_t kind;          // 0: record finished, 1: one gate step (hashes 0, 1), 2: two gate steps (hashes 0..3),
+                            // 3: a whole Kogge-Stone addition over act1 = lanes(n) (split_ks_add)
     uint64_t act1, act2;    // active gates of the step(s)
     uint64_t step;          // global index of the (first) gate step
 };
@@ -79,48 +85,125 @@ __device__ __forceinline__ uint32_t ld_u32_global(const uint32_t *p) { return *(
 __device__ __forceinline__ void st_u32_lds(uint32_t *p, uint32_t v) { *(__attribute__((address_space(3))) uint32_t *)p = v; }
 __device__ __forceinline__ uint32_t ld_u32_lds(const uint32_t *p) { return *(const __attribute__((address_space(3))) uint32_t *)p; }
 
-// Hash phase of one level, between the two barriers.  Wave 4q + r: hash q of gates 16r .. 16r + 15.
+// One hash of one gate step: wave 4q + r hashes operand (q & 1) of gates 16r .. 16r + 15 of step `st`; a_op / b_op are
+// column c of the step's two operands for this lane's gate.  The result column goes to xdst (one word: 4 planes).
 //   garbler  : x_a = H(a0 ^ pa R, 2g) ^ (pa & pb) R,  x_b = H(b0 ^ pb R, 2g + 1);  c0 = x_a ^ x_b   (gc_device.h: CRIT);
 //              rows 0 / 1 of the step receive a0 / b0 for gc_tabfill_kernel
 //   evaluator: x_a = H(a, 2g) ^ sa TG,  x_b = H(b, 2g + 1) ^ sb (TE ^ a);  c = x_a ^ x_b
+// All 64 lanes of the wave are active here (the quad_perm moves read neighbouring lanes).
 template <bool GARBLER>
-__device__ __forceinline__ void split_hash_phase(const SplitHashCtx &hc, const SplitDesc &d) {
-    const int q = hc.wave >> 2, r = hc.wave & 3;
-    if (d.kind == 1 && q >= 2) return;
-    const int c = hc.lane & 3, gate = 16 * r + (hc.lane >> 2);
-    const uint64_t act = (q < 2) ? d.act1 : d.act2;
+__device__ __forceinline__ void split_hash_core(const SplitHashCtx &hc, int q, uint64_t act, uint64_t st, uint32_t a_op, uint32_t b_op,
+                                                uint32_t *xdst) {
+    const int r = hc.wave & 3, c = hc.lane & 3, gate = 16 * r + (hc.lane >> 2);
+    uint32_t *row = hc.tabw + ((st - hc.launch_step0) * 128 + (uint64_t)((q & 1) * 64 + gate)) * 4 + c;
+    uint32_t *xo = xdst + c * kSplitPlane + gate;
     if (((act >> (16 * r)) & 0xffffull) == 0) {                        // no active gate in this block (wave-uniform)
-        st_u32_lds(hc.sx + kSplitX + q * kSplitWord + c * kSplitPlane + gate, 0u);
-        if (GARBLER) {
-            const uint64_t st = d.step + (uint64_t)(q >> 1);
-            st_u32_global(hc.tabw + ((st - hc.launch_step0) * 128 + (uint64_t)((q & 1) * 64 + gate)) * 4 + c, 0u);
-        }
+        st_u32_lds(xo, 0u);
+        if (GARBLER) st_u32_global(row, 0u);
         return;
     }
     const bool on = (act >> gate) & 1ull;
-    const uint64_t st = d.step + (uint64_t)(q >> 1);
-    const uint32_t *op = hc.sx + kSplitOp;
-    const uint32_t v = ld_u32_lds(op + q * kSplitWord + c * kSplitPlane + gate);
-    uint32_t *row = hc.tabw + ((st - hc.launch_step0) * 128 + (uint64_t)((q & 1) * 64 + gate)) * 4 + c;
-    uint32_t other = 0, tg = 0;
-    if (GARBLER) {
-        st_u32_global(row, on ? v : 0u);
-        if (!(q & 1)) other = ld_u32_lds(op + (q + 1) * kSplitWord + gate);             // column 0 of b: its colour
-    } else {
-        tg = ld_u32_global(row);                                                        // TG (hash a) / TE (hash b)
-        if (q & 1) other = ld_u32_lds(op + (q - 1) * kSplitWord + c * kSplitPlane + gate);   // column c of a
-    }
+    const uint32_t v = (q & 1) ? b_op : a_op;
+    uint32_t tg = 0;
+    if (GARBLER) st_u32_global(row, on ? v : 0u);
+    else tg = ld_u32_global(row);                                                       // TG (hash a) / TE (hash b): in flight during the hash
     const uint32_t colour = quad_perm<0x00>(v) & 1u;                                   // lsb of column 0 of the own operand
     const uint32_t x = GARBLER ? (v ^ (colour ? hc.Rq : 0u)) : v;
     const uint32_t tlo = ((uint32_t)st << 7) | (uint32_t)(2 * gate + (q & 1)), thi = (uint32_t)(st >> 25);
     const uint32_t twc = (c == 0) ? tlo : (c == 1) ? thi : 0u;
     uint32_t h = hash_split(hc.lt, hc.rkl, x, twc, c);
     if (GARBLER) {
-        if (!(q & 1)) h ^= (colour & other & 1u) ? hc.Rq : 0u;
+        if (!(q & 1)) h ^= (colour & quad_perm<0x00>(b_op) & 1u) ? hc.Rq : 0u;
     } else {
-        h ^= colour ? ((q & 1) ? (tg ^ other) : tg) : 0u;
+        h ^= colour ? ((q & 1) ? (tg ^ a_op) : tg) : 0u;
     }
-    st_u32_lds(hc.sx + kSplitX + q * kSplitWord + c * kSplitPlane + gate, on ? h : 0u);
+    st_u32_lds(xo, on ? h : 0u);
+}
+
+// Hash phase of a posted gate step (kind 1 / 2), between the two barriers: operands come from the LDS operand area.
+template <bool GARBLER>
+__device__ __forceinline__ void split_hash_phase(const SplitHashCtx &hc, const SplitDesc &d) {
+    const int q = hc.wave >> 2, r = hc.wave & 3;
+    if (d.kind == 1 && q >= 2) return;
+    const int c = hc.lane & 3, gate = 16 * r + (hc.lane >> 2);
+    const uint32_t *op = hc.sx + kSplitOp + c * kSplitPlane + gate;
+    const uint32_t a_op = ld_u32_lds(op + (q & ~1) * kSplitWord), b_op = ld_u32_lds(op + (q | 1) * kSplitWord);
+    split_hash_core<GARBLER>(hc, q, (q < 2) ? d.act1 : d.act2, d.step + (uint64_t)(q >> 1), a_op, b_op, hc.sx + kSplitX + q * kSplitWord);
+}
+
+// A whole Kogge-Stone addition (gc_circuits.h: Circ::add) run by the 16 waves in quad layout with ONE barrier per level.
+// Posted by the glue waves with x, y and the carry-in word in operand words 0..2; sum and final generate word come back
+// in result words 0 and 1.  The gate steps, their order and their activity masks are exactly those of Circ::add
+// (first AND; per distance a dual step (Pg & shl(G), Pg & shl(Pg)), the last distance a single step).
+//
+// Why one barrier is enough: the operands of level L at gate g are (G, Pg)_{L-1} at g and at g - dist.  Pg_{L-1} at any
+// gate is the XOR of two hash results of level L-1, which lie in LDS for all 64 gates after that level's barrier; G_{L-1}
+// at any gate is G_{L-2} there -- published by its owner during level L-1, before that barrier -- XOR two hash results
+// of level L-1.  So a lane rebuilds the shifted operands itself from what the last barrier made visible; nothing has to
+// be shifted and re-published in between.  Hash results and generate snapshots alternate between two buffers.
+template <bool GARBLER>
+__device__ __forceinline__ void split_ks_add(const SplitHashCtx &hc, const SplitDesc &d) {
+    const int q = hc.wave >> 2, r = hc.wave & 3, c = hc.lane & 3, gate = 16 * r + (hc.lane >> 2);
+    const int pl = c * kSplitPlane;
+    const uint64_t act = d.act1;
+    const int n = 64 - __builtin_clzll(act);                                    // act = lanes(n)
+    const uint32_t *opx = hc.sx + kSplitOp + pl, *opy = opx + kSplitWord, *opc = opx + 2 * kSplitWord;
+    const uint32_t xg = ld_u32_lds(opx + gate), yg = ld_u32_lds(opy + gate), cg = ld_u32_lds(opc + gate);
+    const uint32_t P = xg ^ yg;
+    uint64_t st = d.step;
+    int par = 0;                                                                 // buffer of the level being written
+    // level 0: G = ((x ^ cin) & (y ^ cin)) ^ cin
+    if (q < 2) split_hash_core<GARBLER>(hc, q, act, st, xg ^ cg, yg ^ cg, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord);
+    st += 1;
+    lds_barrier();
+    uint32_t Gown = cg, Pown = P;                                                // (G, Pg) of the own gate, one level behind the hashes
+    bool prev_first = true, prev_dual = false;
+    for (int dist = 1; dist < n; dist <<= 1) {
+        const uint32_t *X = hc.sx + kSplitKs + par * 4 * kSplitWord + pl;        // results of the previous level
+        const uint32_t *Gs = hc.sx + kSplitGs + (par ^ 1) * kSplitWord + pl;     // G two levels back (written during the previous level)
+        const int gs = gate - dist;
+        const bool sv = gs >= 0;
+        const int gsc = sv ? gs : 0;
+        // own gate
+        Gown ^= ld_u32_lds(X + gate) ^ ld_u32_lds(X + kSplitWord + gate);
+        if (prev_dual) Pown = ld_u32_lds(X + 2 * kSplitWord + gate) ^ ld_u32_lds(X + 3 * kSplitWord + gate);
+        // shifted gate
+        uint32_t Gsh = ld_u32_lds(X + gsc) ^ ld_u32_lds(X + kSplitWord + gsc);
+        uint32_t Psh;
+        if (prev_first) {
+            Gsh ^= ld_u32_lds(opc + gsc);
+            Psh = ld_u32_lds(opx + gsc) ^ ld_u32_lds(opy + gsc);
+        } else {
+            Gsh ^= ld_u32_lds(Gs + gsc);
+            Psh = ld_u32_lds(X + 2 * kSplitWord + gsc) ^ ld_u32_lds(X + 3 * kSplitWord + gsc);
+        }
+        if (!sv) { Gsh = 0u; Psh = 0u; }
+        if (q == 0) st_u32_lds(hc.sx + kSplitGs + par * kSplitWord + pl + gate, Gown);      // snapshot for the level after this one
+        par ^= 1;
+        const uint64_t hi = act & ~((dist >= 64) ? ~0ull : ((1ull << dist) - 1ull));
+        const bool dual = (dist << 1) < n;
+        if (q < 2) split_hash_core<GARBLER>(hc, q, hi, st, Pown, Gsh, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord);
+        else if (dual) split_hash_core<GARBLER>(hc, q, hi, st + 1, Pown, Psh, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord);
+        st += dual ? 2 : 1;
+        prev_first = false;
+        prev_dual = dual;
+        lds_barrier();
+    }
+    // carries = shl(G, 1) ^ cin on the active lanes; sum = P ^ carries; final G for the carry out
+    {
+        const uint32_t *X = hc.sx + kSplitKs + par * 4 * kSplitWord + pl;
+        const uint32_t *Gs = hc.sx + kSplitGs + (par ^ 1) * kSplitWord + pl;
+        Gown ^= ld_u32_lds(X + gate) ^ ld_u32_lds(X + kSplitWord + gate);
+        const int gs = gate - 1;
+        const int gsc = gs >= 0 ? gs : 0;
+        uint32_t Gsh = ld_u32_lds(X + gsc) ^ ld_u32_lds(X + kSplitWord + gsc);
+        Gsh ^= prev_first ? ld_u32_lds(opc + gsc) : ld_u32_lds(Gs + gsc);
+        if (gs < 0 || !((act >> gate) & 1ull)) Gsh = 0u;
+        if (q == 0) {
+            st_u32_lds(hc.sx + kSplitX + pl + gate, P ^ Gsh ^ cg);
+            st_u32_lds(hc.sx + kSplitX + kSplitWord + pl + gate, Gown);
+        }
+    }
 }
 
 // The circuit backend of the glue waves: W is ONE column of a word's labels (wave = column, lane = gate).
@@ -202,6 +285,23 @@ struct SplitBackend {
         c1 = bit(act1) ? (result(0) ^ result(1)) : 0u;
         c2 = bit(act2) ? (result(2) ^ result(3)) : 0u;
     }
+    // x + y + carry-in over lanes [0, n) as one posted job (Circ::add picks this up): same gate steps as the generic
+    // Kogge-Stone code, two barriers around the whole addition plus one per level instead of two per level
+    __device__ __forceinline__ W add_native(W x, W y, int n, W cinw, W *cout) {
+        const uint64_t act = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+        SplitDesc d = {3u, act, 0ull, step};
+        step += 1;
+        for (int dist = 1; dist < n; dist <<= 1) step += ((dist << 1) < n) ? 2 : 1;
+        publish(0, x);
+        publish(1, y);
+        publish(2, cinw);
+        post(d);
+        lds_barrier();
+        split_ks_add<GARBLER>(hc, d);
+        lds_barrier();
+        if (cout) *cout = bcast(result(1), n - 1);
+        return result(0);
+    }
     // the record is complete: release the hash waves
     __device__ __forceinline__ void finish() {
         SplitDesc d = {0u, 0ull, 0ull, 0ull};
@@ -241,7 +341,8 @@ gc_split_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *
             d.act1 = ((uint64_t)rfl(ld_u32_lds(dp + 2)) << 32) | rfl(ld_u32_lds(dp + 1));
             d.act2 = ((uint64_t)rfl(ld_u32_lds(dp + 4)) << 32) | rfl(ld_u32_lds(dp + 3));
             d.step = ((uint64_t)rfl(ld_u32_lds(dp + 6)) << 32) | rfl(ld_u32_lds(dp + 5));
-            split_hash_phase<GARBLER>(hc, d);
+            if (d.kind == 3u) split_ks_add<GARBLER>(hc, d);
+            else split_hash_phase<GARBLER>(hc, d);
             lds_barrier();
         }
     }

@@ -111,6 +111,7 @@ def lib():
         ]:
             fn = getattr(L, name)
             fn.restype, fn.argtypes = ci, args
+        L.lgc_set_split_kernels.argtypes = [ci, ci]; L.lgc_set_split_kernels.restype = None
         L.lgc_solver_destroy.argtypes = [vp]; L.lgc_solver_destroy.restype = None
         L.lgc_solver_prefix_bytes.argtypes = [vp]; L.lgc_solver_prefix_bytes.restype = sz
         L.lgc_program_destroy.argtypes = [vp]; L.lgc_program_destroy.restype = None
@@ -530,6 +531,11 @@ class OtReceiver:
             self.close()
         except Exception:
             pass
+
+
+def set_split_kernels(garbler=True, evaluator=True):
+    """which kernel runs the latency-bound launches of each role (16-wave column-split or 4-wave); interchangeable"""
+    lib().lgc_set_split_kernels(int(bool(garbler)), int(bool(evaluator)))
 
 
 def aes_bench(waves=8192, blocks_per_lane=256, device=0):

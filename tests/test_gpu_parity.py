@@ -106,3 +106,26 @@ def test_gpu_medium_dimension_chunked(lgc, oracle):
         exp, _, _ = oracle_solve(oracle, A, b, d, w, p, alg, iters, 0.0, 0)
         assert s.beta().tolist() == exp.tolist()
         s.close()
+
+
+@pytest.mark.parametrize("w,p,alg", [(64, 56, "cholesky"), (64, 56, "cgd"), (32, 30, "ldlt")])
+def test_split_and_four_wave_kernels_are_interchangeable(lgc, oracle, w, p, alg):
+    """The latency-bound launches run column-split on 16 waves or on 4 waves per record (gc_split.h / gc_device.h):
+    same gate numbering, tweaks and table rows, so any garbler kernel pairs with any evaluator kernel."""
+    rng = np.random.default_rng(99)
+    d, n = 7, 50
+    A, b = synth_system(oracle, rng, n, d, w, p)
+    shares = split_shares(rng, A, b, 2, w)
+    sysm = lgc.make_system(d, w, p, alg, 4, 0.0, 2, 0, reveal_inputs=1, trace=1)
+    exp, _, _ = oracle_solve(oracle, A, b, d, w, p, alg, 4, 0.0, 0, trace=(alg == "cgd"))
+    beta = exp[0] if alg == "cgd" else exp
+    try:
+        for g, e in [(1, 0), (0, 1), (0, 0), (1, 1)]:
+            lgc.set_split_kernels(g, e)
+            s = _solve(lgc, sysm, shares)
+            assert s.beta().tolist() == beta.tolist(), (g, e)
+            if alg == "cgd":
+                assert s.trace().tolist() == exp[1].tolist(), (g, e)
+            s.close()
+    finally:
+        lgc.set_split_kernels(1, 1)
