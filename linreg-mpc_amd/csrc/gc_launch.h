@@ -72,6 +72,13 @@ static constexpr int kTpbTabfill = 1024;
 #ifndef GC_SPLIT
 #define GC_SPLIT GC_CRIT
 #endif
+// ... up to this many records (one workgroup per CU).  512, i.e. two rounds, measured on the 500-divider launches of
+// d=500 CGD: 3.8 ms against 2.9 ms for the 4-wave kernel at two workgroups per CU -- with the whole chip busy the
+// table pass of critical-path garbling is no longer free
+#ifndef GC_SPLIT_MAX_RECS
+#define GC_SPLIT_MAX_RECS 256
+#endif
+static constexpr uint32_t kSplitMaxRecs = GC_SPLIT_MAX_RECS;
 // ... switchable per role at run time (lgc_set_split_kernels): the two kernels are interchangeable
 inline int &gc_split_enabled(bool garbler) {
     static int on[2] = {1, 1};
@@ -111,11 +118,19 @@ static inline unsigned gc_mac_waves(uint32_t nrec, unsigned lo, unsigned hi) {
     return best;
 }
 
+// the launch runs in the 16-wave column-split kernel (role G: garbler, else evaluator)
+static inline bool gc_launch_is_split(const Launch &L, bool garbler) {
+    const bool mac = L.mac_only && L.nrec >= kNarrowMac;
+    const bool wide = L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps;
+    return GC_SPLIT && gc_split_enabled(garbler) && !mac && !wide && L.nrec > 0 && L.nrec <= kSplitMaxRecs;
+}
 // true when the garbler of this launch runs the critical path only and needs gc_launch_tabfill afterwards
 static inline bool gc_launch_is_crit(const Launch &L) {
     const bool mac = L.mac_only && L.nrec >= kNarrowMac;
     const bool wide = L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps;
-    return GC_CRIT && !mac && !wide && L.nrec > 0 && L.nrec <= kCritMaxRecs && L.steps > 0;
+    if (L.steps == 0) return false;
+    if (gc_launch_is_split(L, true)) return true;
+    return GC_CRIT && !mac && !wide && L.nrec > 0 && L.nrec <= kCritMaxRecs;
 }
 // the table pass of a critical-path launch; it only has to finish before the launch is EVALUATED, so the
 // co-located solver runs it on a side stream while the garbler chain moves on to the next launch
@@ -157,7 +172,7 @@ static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words
         constexpr unsigned per = kTpbWide / 64;
         hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(kTpbWide), 0, st,
                            recs + L.first_rec, L.nrec, words, tab, dec, L.step0, R, w, p);
-    } else if (GC_SPLIT && gc_split_enabled(G) && L.nrec <= kQuadOnePerCu) {
+    } else if (gc_launch_is_split(L, G)) {
         hipLaunchKernelGGL((gc_split_kernel<G>), dim3(L.nrec), dim3(1024), 0, st, recs + L.first_rec, L.nrec, words, tab, dec, L.step0,
                            R, w, p);
     } else if (L.nrec <= kQuadOnePerCu) {

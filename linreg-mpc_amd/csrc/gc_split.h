@@ -37,9 +37,10 @@ __device__ __forceinline__ uint32_t hash_split(const LdsTab4 &lt, const uint32_t
 #endif
 #pragma unroll
     for (int rnd = 1; rnd < 10; rnd++) {
-        const uint32_t s1 = quad_perm<0x39>(s), s2 = quad_perm<0x4E>(s), s3 = quad_perm<0x93>(s);   // columns c+1, c+2, c+3
-        const uint32_t v0 = lt.lkt(0, s, 0), v1 = lt.lkt(1, s1, 1), v2 = lt.lkt(2, s2, 2), v3 = lt.lkt(3, s3, 3);
-        s = xor3(xor3(v0, v1, rkl[rnd]), v2, v3);
+        // look up with the OWN column, then route: column c of the new state is Te0[s_c.b0] ^ Te1[s_{c+1}.b1] ^
+        // Te2[s_{c+2}.b2] ^ Te3[s_{c+3}.b3], and the three foreign terms arrive as DPP operands of the XORs (no moves)
+        const uint32_t u0 = lt.lkt(0, s, 0), u1 = lt.lkt(1, s, 1), u2 = lt.lkt(2, s, 2), u3 = lt.lkt(3, s, 3);
+        s = (u0 ^ rkl[rnd]) ^ quad_perm<0x39>(u1) ^ quad_perm<0x4E>(u2) ^ quad_perm<0x93>(u3);
     }
     const uint32_t s1 = quad_perm<0x39>(s), s2 = quad_perm<0x4E>(s), s3 = quad_perm<0x93>(s);
     const uint32_t v0 = lt.lk(s, 0), v1 = lt.lk(s1, 1), v2 = lt.lk(s2, 2), v3 = lt.lk(s3, 3);
@@ -91,22 +92,26 @@ __device__ __forceinline__ uint32_t ld_u32_lds(const uint32_t *p) { return *(con
 //              rows 0 / 1 of the step receive a0 / b0 for gc_tabfill_kernel
 //   evaluator: x_a = H(a, 2g) ^ sa TG,  x_b = H(b, 2g + 1) ^ sb (TE ^ a);  c = x_a ^ x_b
 // All 64 lanes of the wave are active here (the quad_perm moves read neighbouring lanes).
+__device__ __forceinline__ uint32_t *split_row(const SplitHashCtx &hc, int q, uint64_t st) {
+    const int gate = 16 * (hc.wave & 3) + (hc.lane >> 2);
+    return hc.tabw + ((st - hc.launch_step0) * 128 + (uint64_t)((q & 1) * 64 + gate)) * 4 + (hc.lane & 3);
+}
+// tg (evaluator): this lane's dword of the step's TG (q even) / TE (q odd) row, loaded by the caller
 template <bool GARBLER>
 __device__ __forceinline__ void split_hash_core(const SplitHashCtx &hc, int q, uint64_t act, uint64_t st, uint32_t a_op, uint32_t b_op,
-                                                uint32_t *xdst) {
+                                                uint32_t *xdst, uint32_t tg) {
     const int r = hc.wave & 3, c = hc.lane & 3, gate = 16 * r + (hc.lane >> 2);
-    uint32_t *row = hc.tabw + ((st - hc.launch_step0) * 128 + (uint64_t)((q & 1) * 64 + gate)) * 4 + c;
+    uint32_t *row = split_row(hc, q, st);
     uint32_t *xo = xdst + c * kSplitPlane + gate;
-    if (((act >> (16 * r)) & 0xffffull) == 0) {                        // no active gate in this block (wave-uniform)
+    const uint32_t act16 = (uint32_t)(act >> (16 * r)) & 0xffffu;     // this block's gates (wave-uniform)
+    if (act16 == 0) {
         st_u32_lds(xo, 0u);
         if (GARBLER) st_u32_global(row, 0u);
         return;
     }
-    const bool on = (act >> gate) & 1ull;
+    const bool on = (act16 >> (hc.lane >> 2)) & 1u;
     const uint32_t v = (q & 1) ? b_op : a_op;
-    uint32_t tg = 0;
     if (GARBLER) st_u32_global(row, on ? v : 0u);
-    else tg = ld_u32_global(row);                                                       // TG (hash a) / TE (hash b): in flight during the hash
     const uint32_t colour = quad_perm<0x00>(v) & 1u;                                   // lsb of column 0 of the own operand
     const uint32_t x = GARBLER ? (v ^ (colour ? hc.Rq : 0u)) : v;
     const uint32_t tlo = ((uint32_t)st << 7) | (uint32_t)(2 * gate + (q & 1)), thi = (uint32_t)(st >> 25);
@@ -128,7 +133,9 @@ __device__ __forceinline__ void split_hash_phase(const SplitHashCtx &hc, const S
     const int c = hc.lane & 3, gate = 16 * r + (hc.lane >> 2);
     const uint32_t *op = hc.sx + kSplitOp + c * kSplitPlane + gate;
     const uint32_t a_op = ld_u32_lds(op + (q & ~1) * kSplitWord), b_op = ld_u32_lds(op + (q | 1) * kSplitWord);
-    split_hash_core<GARBLER>(hc, q, (q < 2) ? d.act1 : d.act2, d.step + (uint64_t)(q >> 1), a_op, b_op, hc.sx + kSplitX + q * kSplitWord);
+    const uint64_t st = d.step + (uint64_t)(q >> 1);
+    const uint32_t tg = GARBLER ? 0u : ld_u32_global(split_row(hc, q, st));            // in flight during the hash
+    split_hash_core<GARBLER>(hc, q, (q < 2) ? d.act1 : d.act2, st, a_op, b_op, hc.sx + kSplitX + q * kSplitWord, tg);
 }
 
 // A whole Kogge-Stone addition (gc_circuits.h: Circ::add) run by the 16 waves in quad layout with ONE barrier per level.
@@ -152,8 +159,17 @@ __device__ __forceinline__ void split_ks_add(const SplitHashCtx &hc, const Split
     const uint32_t P = xg ^ yg;
     uint64_t st = d.step;
     int par = 0;                                                                 // buffer of the level being written
+    // evaluator: the ciphertext rows of a level are fetched one level ahead (every step index of the addition is known)
+    uint32_t tg = 0, tgn = 0;
+    if (!GARBLER) {
+        if (q < 2) tg = ld_u32_global(split_row(hc, q, st));
+        if (n > 1) {
+            if (q < 2) tgn = ld_u32_global(split_row(hc, q, st + 1));
+            else if (2 < n) tgn = ld_u32_global(split_row(hc, q, st + 2));
+        }
+    }
     // level 0: G = ((x ^ cin) & (y ^ cin)) ^ cin
-    if (q < 2) split_hash_core<GARBLER>(hc, q, act, st, xg ^ cg, yg ^ cg, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord);
+    if (q < 2) split_hash_core<GARBLER>(hc, q, act, st, xg ^ cg, yg ^ cg, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord, tg);
     st += 1;
     lds_barrier();
     uint32_t Gown = cg, Pown = P;                                                // (G, Pg) of the own gate, one level behind the hashes
@@ -182,8 +198,14 @@ __device__ __forceinline__ void split_ks_add(const SplitHashCtx &hc, const Split
         par ^= 1;
         const uint64_t hi = act & ~((dist >= 64) ? ~0ull : ((1ull << dist) - 1ull));
         const bool dual = (dist << 1) < n;
-        if (q < 2) split_hash_core<GARBLER>(hc, q, hi, st, Pown, Gsh, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord);
-        else if (dual) split_hash_core<GARBLER>(hc, q, hi, st + 1, Pown, Psh, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord);
+        tg = tgn;
+        if (!GARBLER && (dist << 1) < n) {                                        // rows of the next level
+            const uint64_t sn = st + (dual ? 2 : 1);
+            if (q < 2) tgn = ld_u32_global(split_row(hc, q, sn));
+            else if ((dist << 2) < n) tgn = ld_u32_global(split_row(hc, q, sn + 1));
+        }
+        if (q < 2) split_hash_core<GARBLER>(hc, q, hi, st, Pown, Gsh, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord, tg);
+        else if (dual) split_hash_core<GARBLER>(hc, q, hi, st + 1, Pown, Psh, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord, tg);
         st += dual ? 2 : 1;
         prev_first = false;
         prev_dual = dual;
@@ -253,11 +275,11 @@ struct SplitBackend {
     __device__ __forceinline__ W result(int q) const { return ld_u32_lds(hc.sx + kSplitX + q * kSplitWord + wave * kSplitPlane + lane); }
     __device__ __forceinline__ void post(const SplitDesc &d) {
         if (wave == 0 && lane == 0) {
-            uint32_t *p = hc.sx + kSplitDesc;
-            p[0] = d.kind;
-            p[1] = (uint32_t)d.act1; p[2] = (uint32_t)(d.act1 >> 32);
-            p[3] = (uint32_t)d.act2; p[4] = (uint32_t)(d.act2 >> 32);
-            p[5] = (uint32_t)d.step; p[6] = (uint32_t)(d.step >> 32);
+            typedef __attribute__((address_space(3))) gc_u32x4 *lds4;
+            gc_u32x4 lo = {d.kind, (uint32_t)d.act1, (uint32_t)(d.act1 >> 32), (uint32_t)d.act2};
+            gc_u32x4 hi = {(uint32_t)(d.act2 >> 32), (uint32_t)d.step, (uint32_t)(d.step >> 32), 0u};
+            ((lds4)(hc.sx + kSplitDesc))[0] = lo;
+            ((lds4)(hc.sx + kSplitDesc))[1] = hi;
         }
     }
     __device__ __forceinline__ W AND(W a, W b, uint64_t act) {
@@ -315,7 +337,7 @@ template <bool GARBLER>
 __global__ void __launch_bounds__(1024)
 gc_split_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *decode, uint64_t launch_step0, Lbl R, int w, int p) {
     __shared__ uint32_t lds_te0[2 * kLdsTabWords];
-    __shared__ uint32_t lds_sx[kSplitWords];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_sx[kSplitWords];
     lds_tab4_fill(lds_te0);
     const uint32_t wid = blockIdx.x;
     if (wid >= nrec) return;
@@ -334,13 +356,15 @@ gc_split_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *
         // hash waves: serve the levels the glue waves post
         for (;;) {
             lds_barrier();
-            const uint32_t *dp = lds_sx + kSplitDesc;
+            typedef const __attribute__((address_space(3))) gc_u32x4 *lds4;
+            const gc_u32x4 lo = ((lds4)(lds_sx + kSplitDesc))[0];
             SplitDesc d;
-            d.kind = rfl(ld_u32_lds(dp));
+            d.kind = rfl(lo.x);
             if (d.kind == 0u) return;
-            d.act1 = ((uint64_t)rfl(ld_u32_lds(dp + 2)) << 32) | rfl(ld_u32_lds(dp + 1));
-            d.act2 = ((uint64_t)rfl(ld_u32_lds(dp + 4)) << 32) | rfl(ld_u32_lds(dp + 3));
-            d.step = ((uint64_t)rfl(ld_u32_lds(dp + 6)) << 32) | rfl(ld_u32_lds(dp + 5));
+            const gc_u32x4 hi = ((lds4)(lds_sx + kSplitDesc))[1];
+            d.act1 = ((uint64_t)rfl(lo.z) << 32) | rfl(lo.y);
+            d.act2 = ((uint64_t)rfl(hi.x) << 32) | rfl(lo.w);
+            d.step = ((uint64_t)rfl(hi.z) << 32) | rfl(hi.y);
             if (d.kind == 3u) split_ks_add<GARBLER>(hc, d);
             else split_hash_phase<GARBLER>(hc, d);
             lds_barrier();

@@ -17,9 +17,8 @@ __device__ __forceinline__ uint32_t hash_split(const LdsTab4 &lt, const uint32_t
   uint32_t s = k ^ rkl[0];
 #pragma unroll
   for (int rnd = 1; rnd < 10; rnd++) {
-    uint32_t s1 = qp<0x39>(s), s2 = qp<0x4E>(s), s3 = qp<0x93>(s);
-    uint32_t v0 = lt.lkt(0, s, 0), v1 = lt.lkt(1, s1, 1), v2 = lt.lkt(2, s2, 2), v3 = lt.lkt(3, s3, 3);
-    s = xor3(xor3(v0, v1, rkl[rnd]), v2, v3);
+    uint32_t u0 = lt.lkt(0, s, 0), u1 = lt.lkt(1, s, 1), u2 = lt.lkt(2, s, 2), u3 = lt.lkt(3, s, 3);
+    s = (u0 ^ rkl[rnd]) ^ qp<0x39>(u1) ^ qp<0x4E>(u2) ^ qp<0x93>(u3);
   }
   uint32_t s1 = qp<0x39>(s), s2 = qp<0x4E>(s), s3 = qp<0x93>(s);
   uint32_t v0 = lt.lk(s, 0), v1 = lt.lk(s1, 1), v2 = lt.lk(s2, 2), v3 = lt.lk(s3, 3);
