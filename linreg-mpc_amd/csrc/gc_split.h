@@ -37,10 +37,11 @@ __device__ __forceinline__ uint32_t hash_split(const LdsTab4 &lt, const uint32_t
 #endif
 #pragma unroll
     for (int rnd = 1; rnd < 10; rnd++) {
-        // look up with the OWN column, then route: column c of the new state is Te0[s_c.b0] ^ Te1[s_{c+1}.b1] ^
-        // Te2[s_{c+2}.b2] ^ Te3[s_{c+3}.b3], and the three foreign terms arrive as DPP operands of the XORs (no moves)
-        const uint32_t u0 = lt.lkt(0, s, 0), u1 = lt.lkt(1, s, 1), u2 = lt.lkt(2, s, 2), u3 = lt.lkt(3, s, 3);
-        s = (u0 ^ rkl[rnd]) ^ quad_perm<0x39>(u1) ^ quad_perm<0x4E>(u2) ^ quad_perm<0x93>(u3);
+        // (looking up with the own column and routing the results as DPP operands of the XORs saves the three moves but
+        // measured no faster: scripts/exp/lat4.hip 2 118 against 2 142 cycles, the divider 2 % slower)
+        const uint32_t s1 = quad_perm<0x39>(s), s2 = quad_perm<0x4E>(s), s3 = quad_perm<0x93>(s);   // columns c+1, c+2, c+3
+        const uint32_t v0 = lt.lkt(0, s, 0), v1 = lt.lkt(1, s1, 1), v2 = lt.lkt(2, s2, 2), v3 = lt.lkt(3, s3, 3);
+        s = xor3(xor3(v0, v1, rkl[rnd]), v2, v3);
     }
     const uint32_t s1 = quad_perm<0x39>(s), s2 = quad_perm<0x4E>(s), s3 = quad_perm<0x93>(s);
     const uint32_t v0 = lt.lk(s, 0), v1 = lt.lk(s1, 1), v2 = lt.lk(s2, 2), v3 = lt.lk(s3, 3);
