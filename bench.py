@@ -224,7 +224,9 @@ def main():
     torch.cuda.set_device(device_index)
     dist = None
     backend = os.environ.get("LGC_BENCH_BACKEND", "nccl")   # "gloo" only to dry-run N > 1 on one GPU
-    if world > 1:
+    # LGC_BENCH_FORCE_DIST=1: build the process group even for one rank, so that a one-GPU box can put every collective of
+    # the N > 1 path (barrier, broadcasts, all_gather, all_reduce on device tensors) through RCCL (tests/test_gpu_multirank.py)
+    if world > 1 or os.environ.get("LGC_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if backend == "nccl":
             # no per-rank fallback: a rank that silently switched to gloo while the others stay in the RCCL
@@ -445,7 +447,7 @@ def main():
             "metric": "AND-gates/sec (garble+eval) d=500 CGD-15; phase1+2 wall-clock",
             "value": value, "unit": "AND-gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "barrier_backend": (backend if world > 1 else None),
+            "barrier_backend": (backend if dist is not None else None),
             "vs_baseline": value / REF_RATE if (d == 500 and iters == 15 and w == 64) else None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "phase-2 CGD solve, d=%d, %d iterations, %d-bit fixed point, precision %d, "

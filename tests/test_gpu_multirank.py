@@ -47,6 +47,29 @@ def test_bench_two_ranks_share_one_gpu(tmp_path, oracle):
         assert [int(v) for v in exp] == d0["beta"][k], (k, lam)
 
 
+def test_bench_collectives_through_rccl_one_rank(tmp_path, oracle):
+    """The box has one GPU, so the RCCL group has one rank -- but every collective of the N > 1 path (barrier, broadcast
+    of the seed and of the exported prefix in device memory, all_gather, all_reduce of the timings) goes through RCCL on
+    device tensors here, which the two-rank gloo run above cannot show."""
+    env = dict(os.environ, LGC_BENCH_FORCE_DIST="1", LGC_BENCH_DUMP=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("LGC_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+           "--dimension", "24", "--iters", "2", "--sweep-d", "6", "--sweep-iters", "3", "--sweep-lambdas", "5",
+           "--no-cpu-baseline", "--no-traffic", "--no-e2e"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["barrier_backend"] == "nccl"
+    d0 = json.load(open(os.path.join(str(tmp_path), "sweep_rank0.json")))
+    d, w, p, iters = d0["d"], d0["width"], d0["precision"], d0["iters"]
+    tot = np.array(d0["shares"], dtype=np.uint64).sum(axis=0, dtype=np.uint64)
+    T = d * (d + 1) // 2
+    for k, lam in enumerate(d0["lambdas"]):
+        exp, _, _ = oracle_solve(oracle, tot[:T], tot[T:], d, w, p, "cgd", iters, lam, 1)
+        assert [int(v) for v in exp] == d0["beta"][k], (k, lam)
+
+
 def test_table_ring_across_two_gpus(tmp_path, oracle, lgc):
     """CSP on GPU 0, Evaluator on GPU 1, garbled tables through the hipIpc ring (xGMI peer access)"""
     if lgc.device_count() < 2:
