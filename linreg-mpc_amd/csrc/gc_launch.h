@@ -166,8 +166,12 @@ static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words
             return hipGetLastError();
         }
 #endif
-        hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(per * 64), 0, st, recs + L.first_rec,
-                           L.nrec, words, tab, L.step0, R, w, p);
+        unsigned wgs = (L.nrec + per - 1) / per;
+#if GC_MAC_PERSIST      /* one workgroup per CU: the waves walk the records themselves (gc_device.h; measured, off) */
+        if (wgs > gc_num_cus()) wgs = gc_num_cus();
+#endif
+        hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3(wgs), dim3(per * 64), 0, st, recs + L.first_rec, L.nrec, words, tab,
+                           L.step0, R, w, p);
     } else if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) {
         constexpr unsigned per = kTpbWide / 64;
         hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(kTpbWide), 0, st,
