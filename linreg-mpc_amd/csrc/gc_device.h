@@ -538,12 +538,14 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
 #endif
     typedef Circ<B> C;
     // GC_MAC_PERSIST: a grid of one workgroup per CU whose waves walk the records round-robin with the WORKGROUP index
-    // running fastest, so that a partly filled last round is spread over all CUs.  Measured: the MAC launches of d=100
-    // (2.44 rounds) 14 % faster when garbler and evaluator run one after the other, but the co-located solver, whose
-    // evaluator kernels slip in between the garbler's workgroups, gets slower (d=100 0.153 -> 0.159 s, d=500 +4 %): off.
+    // running fastest, so that a partly filled last round is spread over all CUs.  Measured: the garbler's MAC launches
+    // of d=100 (2.44 rounds) 12-14 % faster, serialised or not -- but the co-located solve gets SLOWER (0.154 -> 0.160 s
+    // with the garbler alone persistent, d=500 +2..4 %): the evaluator's kernels no longer slip in between the garbler's
+    // workgroups and its chain, pushed into the gaps, ends later.  Off; worth another look for roles on separate GPUs.
     const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-    const uint32_t first = GC_MAC_PERSIST ? wave * gridDim.x + blockIdx.x : blockIdx.x * waves + wave;
-    const uint32_t stride = GC_MAC_PERSIST ? waves * gridDim.x : (nrec ? nrec : 1u);
+    const bool persist = GC_MAC_PERSIST && gridDim.x * waves < nrec;          // fewer slots than records: walk
+    const uint32_t first = persist ? wave * gridDim.x + blockIdx.x : blockIdx.x * waves + wave;
+    const uint32_t stride = persist ? waves * gridDim.x : (nrec ? nrec : 1u);
     for (uint32_t wid = first; wid < nrec; wid += stride) {
         Rec r = recs[wid];
         r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);

@@ -91,6 +91,9 @@ inline int &gc_split_enabled(bool garbler) {
 #ifndef GC_MAC_TAIL_SPLIT
 #define GC_MAC_TAIL_SPLIT 0   /* measured on d=100 (10 000 records): 0.067 -> 0.075 s of garbler MAC time: worse */
 #endif
+#ifndef GC_MAC_PERSIST_MAX_ROUNDS
+#define GC_MAC_PERSIST_MAX_ROUNDS 8
+#endif
 #ifndef GC_MAC_ADAPT
 #define GC_MAC_ADAPT 0   /* measured: -5 % on a serialised d=100 matvec, +10 % when it overlaps the evaluator chain */
 #endif
@@ -167,8 +170,8 @@ static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words
         }
 #endif
         unsigned wgs = (L.nrec + per - 1) / per;
-#if GC_MAC_PERSIST      /* one workgroup per CU: the waves walk the records themselves (gc_device.h; measured, off) */
-        if (wgs > gc_num_cus()) wgs = gc_num_cus();
+#if GC_MAC_PERSIST      /* one workgroup per CU: the waves walk the records themselves (gc_device.h) */
+        if (G && wgs > gc_num_cus() && wgs <= GC_MAC_PERSIST_MAX_ROUNDS * gc_num_cus()) wgs = gc_num_cus();
 #endif
         hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3(wgs), dim3(per * 64), 0, st, recs + L.first_rec, L.nrec, words, tab,
                            L.step0, R, w, p);
