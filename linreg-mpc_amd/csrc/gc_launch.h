@@ -94,6 +94,12 @@ inline int &gc_split_enabled(bool garbler) {
 #ifndef GC_MAC_PERSIST_MAX_ROUNDS
 #define GC_MAC_PERSIST_MAX_ROUNDS 8
 #endif
+#ifndef GC_MAC_ADAPT_LO_G
+#define GC_MAC_ADAPT_LO_G 10
+#endif
+#ifndef GC_MAC_ADAPT_LO_E
+#define GC_MAC_ADAPT_LO_E 8
+#endif
 #ifndef GC_MAC_ADAPT
 #define GC_MAC_ADAPT 0   /* measured: -5 % on a serialised d=100 matvec, +10 % when it overlaps the evaluator chain */
 #endif
@@ -112,6 +118,8 @@ static inline unsigned gc_num_cus() {
 static inline unsigned gc_mac_waves(uint32_t nrec, unsigned lo, unsigned hi) {
     if (!GC_MAC_ADAPT) return hi;
     const uint64_t cus = gc_num_cus();
+    if (((uint64_t)nrec + hi - 1) / hi > 8 * cus) return hi;     // many rounds: the last one hardly matters, and the
+                                                                 // cost model below (time of a round ~ waves) is only rough
     unsigned best = hi;
     uint64_t best_cost = ~0ull;
     for (unsigned wv = hi; wv >= lo; wv--) {
@@ -153,7 +161,7 @@ static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words
     if (L.nrec == 0) return hipSuccess;
     if (L.mac_only && L.nrec >= kNarrowMac) {
         constexpr int TPB = G ? kTpbMacG : kTpbMacE;       // upper bound (register budget of the kernel)
-        const unsigned per = gc_mac_waves(L.nrec, G ? 10 : 8, TPB / 64);
+        const unsigned per = gc_mac_waves(L.nrec, G ? GC_MAC_ADAPT_LO_G : GC_MAC_ADAPT_LO_E, TPB / 64);
 #if GC_MAC_TAIL_SPLIT
         // One workgroup per CU, every record the same length: the launch runs in rounds of (CUs x waves) records and
         // a partly filled last round costs a whole one.  The records beyond the last full round therefore go into a
