@@ -325,6 +325,10 @@ int lgc_ot_labels_recv_finish(lgc_ot_receiver *r, const uint8_t *e_in, uint8_t *
  * Returns NULL (and sets lgc_last_error) on failure. */
 void *lgc_host_alloc(size_t bytes);
 void lgc_host_free(void *p);
+/* A destroyed lgc_solver leaves its table ring (its one large device allocation) parked for the next
+ * solver on that device: allocating tens of GB right after freeing as much costs more than a solve.
+ * This call frees what is parked (all devices). */
+void lgc_release_cached_memory(void);
 
 /* Kernel choice for latency-bound launches (at most one record per CU), per role: non-zero (the
  * default) runs them column-split on 16 waves per record, zero on 4 waves per record.  Both produce

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -301,6 +302,7 @@ struct lgc_solver {
     // overwriting, the garbler waits for the evaluation of launch tab_wait[i] (the newest earlier
     // launch whose region overlaps; the evaluator chain is in order, so older ones are done too)
     size_t ring_bytes;
+    size_t tab_alloc_bytes;              // size of the allocation behind `tab` (>= ring_bytes when it came from the cache)
     std::vector<size_t> tab_off;
     std::vector<int64_t> tab_wait;
     std::vector<hipEvent_t> evG, evE;     // per launch: tables written / tables consumed
@@ -313,16 +315,70 @@ struct lgc_solver {
     bool have_shares, ran;
     bool prefix_ready;    // sweep: input labels and prefix tables are in place (garbled here or imported)
     lgc_stats st;
-    lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), streamE(0), streamT(0), ev0(0), ev1(0), ev_in(0), ring_bytes(0),
+    lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), streamE(0), streamT(0), ev0(0), ev1(0), ev_in(0), ring_bytes(0), tab_alloc_bytes(0),
                    have_shares(false), ran(false), prefix_ready(false) { memset(&st, 0, sizeof(st)); }
 };
+
+// The table ring is by far the largest allocation of a solver (twice its largest launch: 18 GiB at d=500, 42 GB for a
+// block of eight d=100 circuits), and a hipMalloc of that size that follows the hipFree of another one was measured at
+// 1.46 s (the solve it belongs to: 1.07 s).  A destroyed solver therefore parks its ring here -- one per device, the
+// larger one wins -- and the next solver on that device takes it if it is big enough.  Garbled tables are what the
+// evaluator is given anyway: nothing secret stays in the parked buffer.  lgc_release_cached_memory() frees it.
+namespace {
+struct RingCache {
+    std::mutex mu;
+    struct Slot { int device; void *ptr; size_t bytes; };
+    std::vector<Slot> slots;
+    void *take(int device, size_t need, size_t *bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < slots.size(); i++)
+            if (slots[i].device == device && slots[i].bytes >= need) {
+                void *p = slots[i].ptr;
+                *bytes = slots[i].bytes;
+                slots.erase(slots.begin() + (long)i);
+                return p;
+            }
+        return 0;
+    }
+    void park(int device, void *ptr, size_t bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < slots.size(); i++)
+            if (slots[i].device == device) {
+                if (slots[i].bytes >= bytes) { (void)hipFree(ptr); return; }
+                (void)hipFree(slots[i].ptr);
+                slots[i].ptr = ptr; slots[i].bytes = bytes;
+                return;
+            }
+        Slot n = {device, ptr, bytes};
+        slots.push_back(n);
+    }
+    void release(int device) {      // device < 0: all
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < slots.size();) {
+            if (device < 0 || slots[i].device == device) {
+                (void)hipSetDevice(slots[i].device);
+                (void)hipFree(slots[i].ptr);
+                slots.erase(slots.begin() + (long)i);
+            } else {
+                i++;
+            }
+        }
+    }
+};
+RingCache &ring_cache() { static RingCache c; return c; }
+}  // namespace
+
+extern "C" void lgc_release_cached_memory(void) { ring_cache().release(-1); }
 
 extern "C" void lgc_solver_destroy(lgc_solver *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->wordsG) (void)hipFree(s->wordsG);
     if (s->wordsE) (void)hipFree(s->wordsE);
-    if (s->tab) (void)hipFree(s->tab);
+    if (s->tab) {
+        (void)hipDeviceSynchronize();                    // nothing of this solver may still write into the ring
+        ring_cache().park(s->device, s->tab, s->tab_alloc_bytes);
+    }
     if (s->decG) (void)hipFree(s->decG);
     if (s->decE) (void)hipFree(s->decE);
     if (s->vals) (void)hipFree(s->vals);
@@ -400,7 +456,17 @@ static int solver_create(lgc_solver **out, int device, const lgc_system *sys, co
     s->ring_bytes = plan_table_ring(P, 0, s->tab_off, s->tab_wait);
     TRY(hipMalloc(&s->wordsG, wbytes));
     TRY(hipMalloc(&s->wordsE, wbytes));
-    TRY(hipMalloc(&s->tab, s->ring_bytes));
+    s->tab = reinterpret_cast<Lbl *>(ring_cache().take(s->device, s->ring_bytes, &s->tab_alloc_bytes));   // parked by a destroyed solver
+    if (!s->tab) {
+        hipError_t em = hipMalloc(&s->tab, s->ring_bytes);
+        if (em == hipErrorOutOfMemory) {                                                  // a smaller parked ring may be in the way
+            (void)hipGetLastError();
+            ring_cache().release(s->device);
+            em = hipMalloc(&s->tab, s->ring_bytes);
+        }
+        TRY(em);
+        s->tab_alloc_bytes = s->ring_bytes;
+    }
     TRY(hipMalloc(&s->decG, (P.n_reveal + 1) * sizeof(uint64_t)));
     TRY(hipMalloc(&s->decE, (P.n_reveal + 1) * sizeof(uint64_t)));
     TRY(hipMalloc(&s->vals, nin * sizeof(uint64_t)));

@@ -112,6 +112,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = ci, args
         L.lgc_set_split_kernels.argtypes = [ci, ci]; L.lgc_set_split_kernels.restype = None
+        L.lgc_release_cached_memory.argtypes = []; L.lgc_release_cached_memory.restype = None
         L.lgc_solver_destroy.argtypes = [vp]; L.lgc_solver_destroy.restype = None
         L.lgc_solver_prefix_bytes.argtypes = [vp]; L.lgc_solver_prefix_bytes.restype = sz
         L.lgc_program_destroy.argtypes = [vp]; L.lgc_program_destroy.restype = None
@@ -531,6 +532,11 @@ class OtReceiver:
             self.close()
         except Exception:
             pass
+
+
+def release_cached_memory():
+    """free the table ring a closed Solver left parked for the next one"""
+    lib().lgc_release_cached_memory()
 
 
 def set_split_kernels(garbler=True, evaluator=True):
