@@ -98,31 +98,22 @@ int main(int argc, char **argv) {
     check(party >= 1 && party <= c->num_parties, "Party must be in 1..%d", c->num_parties);
 
     double time = wall_clock();
+    /* LINREG_TRACE=1: wall-clock marks on stderr (where an end-to-end run of a small configuration spends its time) */
+    const int tracing = getenv("LINREG_TRACE") != NULL;
+#define TRACE(what) do { if (tracing) fprintf(stderr, "[party %d] %8.3f ms  %s\n", party, (wall_clock() - time) * 1e3, what); } while (0)
     if (party == 2) printf("{\"n\":\"%zd\", \"d\":\"%zd\" \"p\":\"%d\"}\n", c->n, c->d, c->num_parties - 1);
 
     status = node_new(&self, party, c->num_parties, c->endpoint);
     check(!status, "Could not create node");
+    TRACE("connected");
 
-    if (party == 1) {
-        if (!use_ot) {
-            status = run_trusted_initializer(self, c, w1, device);
-            check(!status, "Error while running trusted initializer");
-        }
-    } else if (party > 2) {
-        status = run_party(self, c, precision, precision_phase2 != -1 ? precision_phase2 : precision, w1, w2, use_ot, device,
-                           &share_A, &share_b);
-        check(!status, "Error while running party %d", party);
-    }
-    check(!net_barrier(self), "Error while waiting for other peers to finish");
-    printf("Party %d finished phase 1\n", party);
-
-    /* ---------------------------------------------------------------------------- phase 2 */
-    if (precision_phase2 != -1) precision = precision_phase2;
+    /* the phase-2 system: known from the configuration before any protocol message */
+    const int precision2 = precision_phase2 != -1 ? precision_phase2 : precision;
     const size_t d = c->d, T = d * (d + 1) / 2;
     const int P = c->num_parties - 2;
     lgc_system sys;
     memset(&sys, 0, sizeof sys);
-    sys.d = d; sys.width = w2; sys.precision = precision;
+    sys.d = d; sys.width = w2; sys.precision = precision2;
     sys.algorithm = !strcmp(algorithm, "cholesky") ? LGC_ALG_CHOLESKY : (!strcmp(algorithm, "ldlt") ? LGC_ALG_LDLT : LGC_ALG_CGD);
     sys.num_iterations = num_iterations; sys.lambda = lambda; sys.nshares = (size_t)P;
     sys.normalize = 1; sys.reveal_inputs = 1; sys.trace = 1;
@@ -131,11 +122,43 @@ int main(int argc, char **argv) {
      * in HBM (CSP and Evaluator on one node), so launches can be as large as the fused solver's */
     const size_t kTableChunk = ring_slots > 0 ? (size_t)1 << 30 : (size_t)64 << 20;
 
+    if (party == 1) {
+        if (!use_ot) {
+            status = run_trusted_initializer(self, c, w1, device);
+            check(!status, "Error while running trusted initializer");
+        } else {                                                     /* OT mode: the CSP is idle in phase 1 as well */
+            uint8_t seed[16];
+            check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
+            if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk, n_lambdas, lambdas));
+            else LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk));
+            TRACE("garbler created");
+        }
+    } else if (party > 2) {
+        status = run_party(self, c, precision, precision_phase2 != -1 ? precision_phase2 : precision, w1, w2, use_ot, device,
+                           &share_A, &share_b);
+        check(!status, "Error while running party %d", party);
+    } else {
+        /* The Evaluator has no part in phase 1: it brings up its GPU context, program and buffers while the data
+         * providers work, instead of after the barrier with the CSP waiting for it (0.3 s of a 0.9 s config-3 run). */
+        if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, LGC_ROLE_EVALUATOR, NULL, kTableChunk, n_lambdas, lambdas));
+        else LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_EVALUATOR, NULL, kTableChunk));
+        TRACE("evaluator created");
+    }
+    TRACE("phase 1 done");
+    check(!net_barrier(self), "Error while waiting for other peers to finish");
+    TRACE("barrier");
+    printf("Party %d finished phase 1\n", party);
+
+    /* ---------------------------------------------------------------------------- phase 2 */
+    if (precision_phase2 != -1) precision = precision_phase2;
     if (party == 1) {                                                /* CSP: garbler */
-        uint8_t seed[16];
-        check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
-        if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk, n_lambdas, lambdas));
-        else LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk));
+        if (!party_obj) {                                            /* TI mode: this process was the initializer until now */
+            uint8_t seed[16];
+            check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
+            if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk, n_lambdas, lambdas));
+            else LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk));
+            TRACE("garbler created");
+        }
         size_t bits = lgc_party_input_bits(party_obj);
         uint8_t *m0 = lgc_host_alloc(bits * 16), *m1 = lgc_host_alloc(bits * 16), *u = lgc_host_alloc(lgc_ot_u_bytes(bits)),
                 *e = lgc_host_alloc(bits * 32);
@@ -152,7 +175,9 @@ int main(int argc, char **argv) {
             lgc_ot_sender_destroy(S);
         }
         lgc_host_free(m0); lgc_host_free(m1); lgc_host_free(u); lgc_host_free(e);
+        TRACE("input labels sent");
         check(!tables_send(self, 2, party_obj, ring_slots, kTableChunk), "could not stream the garbled tables");
+        TRACE("tables sent");
         size_t nr = lgc_party_num_reveal(party_obj);
         uint64_t *dec = malloc((nr + 1) * 8);
         LGC(lgc_party_decode_bits(party_obj, dec));
@@ -161,8 +186,6 @@ int main(int argc, char **argv) {
     } else if (party == 2) {                                         /* Evaluator */
         double time_start = wall_clock();
         printf("\nAlgorithm: %s\n", algorithm);
-        if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, LGC_ROLE_EVALUATOR, NULL, kTableChunk, n_lambdas, lambdas));
-        else LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_EVALUATOR, NULL, kTableChunk));
         size_t bits = lgc_party_input_bits(party_obj);
         uint8_t *labels = malloc(bits * 16);
         printf("party %d listening for %d inputs", party, P);
@@ -172,6 +195,7 @@ int main(int argc, char **argv) {
             printf("Evaluator received A from party %d\nEvaluator received b from party %d\n", k, k);
         }
         free(labels);
+        TRACE("input labels received");
         double t_ot = wall_clock() - time_start;
         /* where cgd.oc:190-194 prints yaoGateCount() and the running time: after the launch that
          * completes each iteration */
@@ -182,6 +206,7 @@ int main(int argc, char **argv) {
         if (n_marks) LGC(lgc_party_iteration_marks(party_obj, mark_launch, mark_gates, n_marks));
         iter_marks marks = {n_marks, 0, mark_launch, mark_time, time_start};
         check(!tables_recv(self, 1, party_obj, ring_slots, kTableChunk, note_launch, &marks), "could not receive garbled tables");
+        TRACE("tables evaluated");
         size_t nr = lgc_party_num_reveal(party_obj);
         uint64_t *dec = malloc((nr + 1) * 8);
         check(!recv_blob(self, 1, dec, nr * 8), "could not receive decode bits");
