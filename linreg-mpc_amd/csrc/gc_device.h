@@ -23,7 +23,8 @@ __constant__ uint32_t c_rk24[44];
 // c_rk24: rotl24 of the round keys (two-table AES rounds)
 
 #ifndef GC_SOLO_INLINE
-#define GC_SOLO_INLINE 0   /* wide generic kernel: 1 = gate bodies inlined at every AND site (experiment) */
+#define GC_SOLO_INLINE 1   /* wide generic kernel: gate bodies inlined at every AND site (0: one out-of-line body; the call ABI
+                              spills around every gate step, as it did in the 4-wave kernels) */
 #endif
 #ifndef GC_AES_TAB4
 #define GC_AES_TAB4 1   /* MAC kernels and the AES micro-benchmark: four rotated tables, 32 replicas each */

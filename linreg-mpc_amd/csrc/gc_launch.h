@@ -30,10 +30,12 @@ static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
 #define GC_WIDE_LAUNCH 2048
 #endif
 static constexpr uint32_t kWideLaunch = GC_WIDE_LAUNCH;
-// ... and only for short records (sums, merges): long dependent records (dividers, square roots) run
-// faster in the 4-wave mode even when there are thousands of them (measured on the merged lambda sweep)
+// ... whatever the length of the records.  With an out-of-line gate body, long dependent records (dividers by the
+// thousand in a merged lambda sweep) ran 5 % faster in the 4-wave mode and this was a bound on steps per record (256);
+// with the gate bodies inlined (GC_SOLO_INLINE, gc_device.h) the one-wave-per-record kernel wins: 64-lambda sweep
+// 8.39 -> 7.87 s.  The macro stays for A/B runs.
 #ifndef GC_WIDE_MAX_STEPS
-#define GC_WIDE_MAX_STEPS 256
+#define GC_WIDE_MAX_STEPS 100000000
 #endif
 static constexpr uint64_t kWideMaxSteps = GC_WIDE_MAX_STEPS;
 // wide launches: 12 records (waves) per workgroup share one 128 KiB four-table image
