@@ -586,7 +586,7 @@ gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *d
     __shared__ uint32_t lds_te0[TS::kWords];
     __shared__ Lbl lds_xch[QUAD ? 2 * 512 : 1];   // 16 KiB exchange area of the 4-wave steps
     TS::fill(lds_te0);
-    const uint32_t wid = QUAD ? blockIdx.x : blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    const uint32_t wid = QUAD ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // wide: blockDim <= TPB
     if (wid >= nrec) return;
     typedef GpuBackend<GARBLER, QUAD ? MODE_QUAD : MODE_SOLO, typename TS::T, CRIT && GARBLER && QUAD> B;
     B be;

@@ -29,6 +29,9 @@ static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
 #ifndef GC_WIDE_LAUNCH
 #define GC_WIDE_LAUNCH 2048
 #endif
+#ifndef GC_WIDE_ADAPT
+#define GC_WIDE_ADAPT 1
+#endif
 static constexpr uint32_t kWideLaunch = GC_WIDE_LAUNCH;
 // ... whatever the length of the records.  With an out-of-line gate body, long dependent records (dividers by the
 // thousand in a merged lambda sweep) ran 5 % faster in the 4-wave mode and this was a bound on steps per record (256);
@@ -186,8 +189,12 @@ static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words
         hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3(wgs), dim3(per * 64), 0, st, recs + L.first_rec, L.nrec, words, tab,
                            L.step0, R, w, p);
     } else if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) {
-        constexpr unsigned per = kTpbWide / 64;
-        hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(kTpbWide), 0, st,
+        // records (waves) per workgroup: as few as keep the launch within one workgroup per CU, at most TPB / 64 --
+        // a launch of 800 dividers runs as 200 workgroups of 4 waves, one round, instead of 67 CUs with 12 waves each
+        unsigned per = (L.nrec + gc_num_cus() - 1) / gc_num_cus();
+        if (per > (unsigned)kTpbWide / 64) per = kTpbWide / 64;
+        if (!GC_WIDE_ADAPT) per = kTpbWide / 64;
+        hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(per * 64), 0, st,
                            recs + L.first_rec, L.nrec, words, tab, dec, L.step0, R, w, p);
     } else if (gc_launch_is_split(L, G)) {
         hipLaunchKernelGGL((gc_split_kernel<G>), dim3(L.nrec), dim3(1024), 0, st, recs + L.first_rec, L.nrec, words, tab, dec, L.step0,
