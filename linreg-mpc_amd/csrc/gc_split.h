@@ -11,7 +11,9 @@
 //     gate: free-XOR glue is one instruction instead of four, lane moves are one ds_bpermute / v_readlane;
 //   * at a gate step they put the operand columns into LDS, and all 16 waves hash: wave 4q + r takes hash q (operand
 //     q of the step: a1, b1, a2, b2) of gates 16r .. 16r + 15 in quad layout, writes its column of the result back,
-//     and the glue waves pick the results up.  Two workgroup barriers per level.
+//     and the glue waves pick the results up: two workgroup barriers per posted gate step;
+//   * whole additions -- nearly all levels of a divider or square root -- are posted as ONE job and walked by the hash
+//     waves themselves with one barrier per Kogge-Stone level (split_ks_add).
 //
 // Measured (scripts/exp/lat4.hip): 1484 cycles per 2-hash level against 2379, 2142 per 4-hash level against 2915.
 //
@@ -59,7 +61,7 @@ enum {
     kSplitX = 4 * kSplitWord,              // results of hash 0..3 (adder: sum, final generate word)
     kSplitKs = 8 * kSplitWord,             // adder levels: two buffers of four hash results (level parity)
     kSplitGs = 16 * kSplitWord,            // adder levels: two snapshots of the generate word
-    kSplitDesc = 18 * kSplitWord,          // kind, act1 (2), act2 (2), step (2), width
+    kSplitDesc = 18 * kSplitWord,          // kind, act1 (2), act2 (2), step (2): two 16-byte stores
     kSplitWords = 18 * kSplitWord + 8
 };
 
