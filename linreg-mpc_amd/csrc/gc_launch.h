@@ -77,6 +77,9 @@ static constexpr int kTpbTabfill = 1024;
 #ifndef GC_SPLIT
 #define GC_SPLIT GC_CRIT
 #endif
+#ifndef GC_QUAD4
+#define GC_QUAD4 0
+#endif
 // ... up to this many records (one workgroup per CU).  512, i.e. two rounds, measured on the 500-divider launches of
 // d=500 CGD: 3.8 ms against 2.9 ms for the 4-wave kernel at two workgroups per CU -- with the whole chip busy the
 // table pass of critical-path garbling is no longer free
@@ -146,7 +149,7 @@ static inline bool gc_launch_is_crit(const Launch &L) {
     const bool wide = L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps;
     if (L.steps == 0) return false;
     if (gc_launch_is_split(L, true)) return true;
-    return GC_CRIT && !mac && !wide && L.nrec > 0 && L.nrec <= kCritMaxRecs;
+    return GC_CRIT && GC_QUAD4 && !mac && !wide && L.nrec > 0 && L.nrec <= kCritMaxRecs;
 }
 // the table pass of a critical-path launch; it only has to finish before the launch is EVALUATED, so the
 // co-located solver runs it on a side stream while the garbler chain moves on to the next launch
@@ -199,12 +202,18 @@ static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words
     } else if (gc_launch_is_split(L, G)) {
         hipLaunchKernelGGL((gc_split_kernel<G>), dim3(L.nrec), dim3(1024), 0, st, recs + L.first_rec, L.nrec, words, tab, dec, L.step0,
                            R, w, p);
+#if GC_QUAD4          /* the 4-wave kernels with the four-table image (garbler: critical-path garbling): what ran these launches
+                         before the column-split kernel; with 0 (default, 45 s less to compile) a role whose split kernel is
+                         switched off runs them in the two-table 4-wave kernel below */
     } else if (L.nrec <= kQuadOnePerCu) {
         hipLaunchKernelGGL((gc_exec_kernel<G, true, 4, 256, G && GC_CRIT>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec,
                            L.nrec, words, tab, dec, L.step0, R, w, p);
+#endif
+#if GC_CRIT_MAX_RECS > GC_QUAD_ONE_PER_CU     /* critical-path garbling at two workgroups per CU: measured, no gain; not instantiated */
     } else if (L.nrec <= kCritMaxRecs) {
         hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256, G && GC_CRIT>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec,
                            L.nrec, words, tab, dec, L.step0, R, w, p);
+#endif
     } else {
         hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec, L.nrec, words,
                            tab, dec, L.step0, R, w, p);

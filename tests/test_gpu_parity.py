@@ -110,8 +110,9 @@ def test_gpu_medium_dimension_chunked(lgc, oracle):
 
 @pytest.mark.parametrize("w,p,alg", [(64, 56, "cholesky"), (64, 56, "cgd"), (32, 30, "ldlt")])
 def test_split_and_four_wave_kernels_are_interchangeable(lgc, oracle, w, p, alg):
-    """The latency-bound launches run column-split on 16 waves or on 4 waves per record (gc_split.h / gc_device.h):
-    same gate numbering, tweaks and table rows, so any garbler kernel pairs with any evaluator kernel."""
+    """The latency-bound launches run column-split on 16 waves (garbler: critical-path garbling + table pass) or on
+    4 waves per record (one-pass garbler, two-table AES; gc_split.h / gc_device.h): same gate numbering, tweaks and
+    table rows, so any garbler kernel pairs with any evaluator kernel."""
     rng = np.random.default_rng(99)
     d, n = 7, 50
     A, b = synth_system(oracle, rng, n, d, w, p)
