@@ -39,6 +39,7 @@ int main(int argc, char **argv) {
           "         --prec_phase2=<Precision phase 2>: Use different precision for phase 2 of the protocol\n"
           "         --width_phase1=<32|64>, --width_phase2=<32|64>: bit widths (default 64)\n"
           "         --table_ring[=slots]: parties 1 and 2 share one node; garbled tables stay in HBM\n"
+          "         --table_lanes=<K>: garbled tables through the network over K extra TCP connections\n"
           "         --ti_ring: (TI mode) all parties on this node: the vectors of the multiplication protocol stay in HBM\n"
           "         --ot_ring: --use_ot with all data providers on this node: the OT extension's messages stay in HBM\n"
           "         --lambdas=l1,l2,...: regularisation sweep -- one circuit per value on the same shares (the data\n"
@@ -58,7 +59,7 @@ int main(int argc, char **argv) {
     check(!errno, "strtod: %s", strerror(errno));
     check(!*end, "lambda must be a number");
 
-    int use_ot = 0, precision_phase2 = -1, w1 = 64, w2 = 64, ring_slots = 0;
+    int use_ot = 0, precision_phase2 = -1, w1 = 64, w2 = 64, ring_slots = 0, table_lanes = 0;
     double *lambdas = NULL;                     /* --lambdas: the per-lambda sweep (lambda enters at linear.oc:52-57) */
     size_t n_lambdas = 0;
     for (int i = 7; i < argc; i++) {
@@ -79,6 +80,7 @@ int main(int argc, char **argv) {
         }
         else if (!strcmp(argv[i], "--table_ring")) ring_slots = 8;
         else if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) {}
+        else if (sscanf(argv[i], "--table_lanes=%i", &table_lanes) == 1) protocol_set_table_lanes(table_lanes);
         else if (sscanf(argv[i], "--width_phase1=%i", &w1) == 1) {}
         else if (sscanf(argv[i], "--width_phase2=%i", &w2) == 1) {}
         else if (sscanf(argv[i], "--prec_phase2=%i", &precision_phase2) != 1) precision_phase2 = -1;

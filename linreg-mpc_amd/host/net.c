@@ -29,6 +29,8 @@ static int io_all(int fd, void *buf, size_t len, int wr) {
     return 0;
 }
 
+int net_io_all(int fd, void *buf, size_t len, int wr) { return io_all(fd, buf, len, wr); }
+
 int net_send(node *n, int to, const void *buf, size_t len) {
     if (to < 1 || to > n->num_parties || n->fd[to - 1] < 0) return -1;
     n->sent[to - 1] += len;
@@ -164,6 +166,65 @@ void node_destroy(node **nn) {
     if (n->fd) for (int i = 0; i < n->num_parties; i++) if (n->fd[i] >= 0) close(n->fd[i]);
     free(n->fd); free(n->sent); free(n->nsend); free(n->wait_ns); free(n->pending); free(n->nflush); free(n);
     *nn = 0;
+}
+
+typedef struct { uint32_t k, port; } lane_offer;
+int net_lanes_offer(node *n, int peer, int k, int *fds) {
+    if (peer < 1 || peer > n->num_parties || n->fd[peer - 1] < 0 || k < 0) return -1;
+    if (k == 0) {                                        /* "no lanes": the peer still expects the offer */
+        lane_offer none = {0, 0};
+        return net_send(n, peer, &none, sizeof none) ? -1 : 0;
+    }
+    int ls = socket(AF_INET, SOCK_STREAM, 0);
+    if (ls < 0) return -1;
+    struct sockaddr_in sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sin_family = AF_INET; sa.sin_port = 0; sa.sin_addr.s_addr = INADDR_ANY;
+    socklen_t sl = sizeof sa;
+    if (bind(ls, (struct sockaddr *)&sa, sizeof sa) < 0 || listen(ls, k) < 0 || getsockname(ls, (struct sockaddr *)&sa, &sl) < 0) {
+        close(ls);
+        return -1;
+    }
+    lane_offer o = {(uint32_t)k, (uint32_t)ntohs(sa.sin_port)};
+    if (net_send(n, peer, &o, sizeof o)) { close(ls); return -1; }
+    for (int i = 0; i < k; i++) fds[i] = -1;
+    for (int i = 0; i < k; i++) {
+        int s = accept(ls, 0, 0);
+        uint32_t lane = 0;
+        if (s < 0 || io_all(s, &lane, sizeof lane, 0) || lane >= (uint32_t)k || fds[lane] >= 0) {
+            if (s >= 0) close(s);
+            for (int j = 0; j < k; j++) if (fds[j] >= 0) close(fds[j]);
+            close(ls);
+            return -1;
+        }
+        tune_socket(s);
+        fds[lane] = s;
+    }
+    close(ls);
+    return 0;
+}
+int net_lanes_accept_offer(node *n, int peer, int max_k, int *k, int *fds) {
+    if (peer < 1 || peer > n->num_parties || n->fd[peer - 1] < 0) return -1;
+    lane_offer o;
+    if (net_recv(n, peer, &o, sizeof o)) return -1;
+    if (o.k == 0) { *k = 0; return 0; }
+    if ((int)o.k > max_k || o.port == 0 || o.port > 65535) return -1;
+    struct sockaddr_in sa;
+    socklen_t sl = sizeof sa;
+    if (getpeername(n->fd[peer - 1], (struct sockaddr *)&sa, &sl) < 0 || sa.sin_family != AF_INET) return -1;
+    sa.sin_port = htons((uint16_t)o.port);
+    for (uint32_t i = 0; i < o.k; i++) {
+        int s = socket(AF_INET, SOCK_STREAM, 0);
+        if (s < 0 || connect(s, (struct sockaddr *)&sa, sizeof sa) < 0 || io_all(s, &i, sizeof i, 1)) {
+            if (s >= 0) close(s);
+            for (uint32_t j = 0; j < i; j++) close(fds[j]);
+            return -1;
+        }
+        tune_socket(s);
+        fds[i] = s;
+    }
+    *k = (int)o.k;
+    return 0;
 }
 
 int net_barrier(node *n) {

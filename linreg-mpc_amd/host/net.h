@@ -29,6 +29,13 @@ int net_recv(node *n, int from_party, void *buf, size_t len);
 void net_flush(node *n, int to_party);               /* explicit flush point */
 int net_send_flush(node *n, int to_party, const void *buf, size_t len);   /* send followed by an explicit flush */
 uint64_t net_flush_count(const node *n, int party);  /* as "Total flush done" would report it at cleanup */
+/* Extra TCP connections to one peer (bulk data striped over several streams: one stream is one core's worth of
+ * copying on either side).  The side that calls net_lanes_offer listens on an ephemeral port, tells the peer over the
+ * main connection and accepts k connections; the peer calls net_lanes_accept_offer and connects to the address the
+ * main connection comes from.  fds[i] is lane i on both sides.  Returns 0 on success. */
+int net_lanes_offer(node *n, int peer, int k, int *fds);
+int net_lanes_accept_offer(node *n, int peer, int max_k, int *k, int *fds);
+int net_io_all(int fd, void *buf, size_t len, int wr);   /* full-length send (wr = 1) / recv on a raw descriptor */
 int net_barrier(node *n);    /* chain barrier of src/cmd/linreg.c:19-41 */
 double wall_clock(void);
 #endif

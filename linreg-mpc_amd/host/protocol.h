@@ -33,6 +33,7 @@ void protocol_set_ti_ring(int on);        /* TI mode with all parties on one nod
  * launch travel over the socket.  ring_slots > 0: both processes are on one node; the tables stay
  * in a device-resident ring shared through hipIpc and only one-byte ready/ack tokens travel.
  * after_launch (may be NULL) is called once launch i has been evaluated. */
+void protocol_set_table_lanes(int k);   /* --table_lanes=K: socket-mode table stream striped over K extra connections */
 int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk);
 int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk,
                 void (*after_launch)(size_t launch, void *ctx), void *ctx);

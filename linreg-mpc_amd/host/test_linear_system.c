@@ -41,6 +41,7 @@ int main(int argc, char **argv) {
         if (sscanf(argv[i], "--width=%i", &w) == 1) continue;
         if (!strcmp(argv[i], "--table_ring")) { ring_slots = 8; continue; }
         if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) continue;
+        { int lanes = 0; if (sscanf(argv[i], "--table_lanes=%i", &lanes) == 1) { protocol_set_table_lanes(lanes); continue; } }
         if (!strncmp(argv[i], "--host=", 7)) host = argv[i] + 7;
     }
     int num_iterations = !strcmp(algorithm, "cgd") ? atoi(argv[5]) : 0;

@@ -118,8 +118,9 @@ README_RESULT = ["0.984331027786964", "0.792399824970372", "0.754117840176144", 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--use_ot"], ["--table_ring"], ["--ot_ring", "--table_ring"], ["--ti_ring", "--table_ring"]],
-                         ids=["ti", "ot", "table-ring", "ot-ring", "ti-ring"])
+@pytest.mark.parametrize("extra", [[], ["--use_ot"], ["--table_ring"], ["--ot_ring", "--table_ring"], ["--ti_ring", "--table_ring"],
+                                   ["--table_lanes=4"]],
+                         ids=["ti", "ot", "table-ring", "ot-ring", "ti-ring", "table-lanes"])
 def test_five_process_readme_example(tmp_path, golden_dir, extra):
     """bin/linreg examples/readme_example.in 56 $party cgd 10 0.001 (README.md:81) -> README.md:87"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
@@ -176,10 +177,11 @@ def test_secure_multiplication_binary(tmp_path, golden_dir, extra):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("alg,w,p,ring", [("cgd", 64, 56, 0), ("cholesky", 64, 54, 0), ("ldlt", 32, 28, 0),
-                                          ("cgd", 64, 56, 2), ("cholesky", 32, 28, 1)])
+                                          ("cgd", 64, 56, 2), ("cholesky", 32, 28, 1), ("cgd", 64, 56, -3), ("ldlt", 64, 56, -1)])
 def test_test_linear_system_binary(tmp_path, oracle, alg, w, p, ring):
     """two-party phase-2 benchmark (src/cmd/test/test_linear_system.c) vs the oracle on the same file;
-    ring > 0: the garbled tables stay in a device-resident ring shared between the two processes"""
+    ring > 0: the garbled tables stay in a device-resident ring shared between the two processes;
+    ring < 0: they cross the network striped over -ring extra connections (--table_lanes)"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     rng = np.random.default_rng(17)
     d, iters = 4, 5
@@ -196,7 +198,7 @@ def test_test_linear_system_binary(tmp_path, oracle, alg, w, p, ring):
         f.write("%d\n" % d + " ".join(repr(float(v)) for v in sol) + " ")
     port = _free_ports(1)[0]
     exe = os.path.join(HOST, "bin", "test_linear_system")
-    opt = ["--width=%d" % w, "--host=127.0.0.1"] + (["--table_ring=%d" % ring] if ring else [])
+    opt = ["--width=%d" % w, "--host=127.0.0.1"] + (["--table_ring=%d" % ring] if ring > 0 else []) + (["--table_lanes=%d" % -ring] if ring < 0 else [])
     procs = [subprocess.Popen([exe, str(port), str(k), path, alg, str(iters), str(p)] + opt,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE) for k in (1, 2)]
     outs = [q.communicate(timeout=300) for q in procs]

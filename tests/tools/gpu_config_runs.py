@@ -92,6 +92,8 @@ subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
 if "c2" in which: run("c2", 1000, 20, [0, 10], "cholesky", 0, 0.001, [])
 if "c3ti" in which: run("c3ti", 10000, 100, [0, 50], "cgd", 15, 0.001, [])
 if "c3" in which: run("c3", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--use_ot"])
+if "c3l" in which: run("c3ti-lanes4", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--table_lanes=4"])
+if "c3l8" in which: run("c3ti-lanes8", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--table_lanes=8"])
 if "c3or" in which: run("c3-otring", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--ot_ring", "--table_ring"])
 if "c4" in which: run("c4", 50000, 500, [0, 100, 200, 300, 400], "cgd", 20, 0.001, ["--width_phase2=32", "--prec_phase2=30"], w2=32)
 # --table_ring: CSP and Evaluator processes share the garbled tables in HBM (hipIpc) instead of the socket
