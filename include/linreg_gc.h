@@ -224,13 +224,6 @@ int lgc_party_ring_create(lgc_party *p, int nslots, uint8_t handle_out[64], size
 int lgc_party_ring_open(lgc_party *p, const uint8_t handle[64], int nslots, size_t slot_bytes);
 int lgc_party_garble_ring(lgc_party *p, size_t launch);
 int lgc_party_evaluate_ring(lgc_party *p, size_t launch);
-/* The same without blocking: *_begin enqueues launch k; lgc_party_ring_wait(p, k) returns when its tables
- * (garbler) / output words (evaluator) are complete.  At most four launches may be in flight; the ordering
- * rules above apply to the moment lgc_party_ring_wait(k) has returned.  tables_send / tables_recv begin
- * launch k + 1 before they wait for k and pass its token on. */
-int lgc_party_garble_ring_begin(lgc_party *p, size_t launch);
-int lgc_party_evaluate_ring_begin(lgc_party *p, size_t launch);
-int lgc_party_ring_wait(lgc_party *p, size_t launch);
 /* evaluator: the labels a data provider forwarded (dcsSendIntArray -> orecv, input.c:46, 84-92) */
 int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint8_t *labels);
 int lgc_party_garble(lgc_party *p, size_t launch, uint8_t *tables_out);

@@ -43,11 +43,6 @@ struct lgc_party {
     int ring_slots;
     size_t ring_slot_bytes;
     bool ring_imported;
-    // asynchronous ring launches: record kernels on sA, the table pass of critical-path launches on sT, one completion
-    // event per launch in flight
-    hipStream_t sA, sT;
-    hipEvent_t evA, done[4];
-    bool async_ready;
 };
 
 // (m0, m1) = (zero label, zero label ^ R) per input bit of one share: yaoKeyNewPair (input.c:94-101)
@@ -81,10 +76,6 @@ extern "C" void lgc_party_destroy(lgc_party *p) {
     if (p->dec) (void)hipFree(p->dec);
     if (p->recs) (void)hipFree(p->recs);
     if (p->ring) { if (p->ring_imported) (void)hipIpcCloseMemHandle(p->ring); else (void)hipFree(p->ring); }
-    if (p->async_ready) {
-        (void)hipStreamDestroy(p->sA); (void)hipStreamDestroy(p->sT); (void)hipEventDestroy(p->evA);
-        for (int i = 0; i < 4; i++) (void)hipEventDestroy(p->done[i]);
-    }
     delete p;
 }
 
@@ -116,7 +107,6 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
     p->sys = *sys; p->device = device; p->role = role;
     p->words = 0; p->tab = 0; p->dec = 0; p->recs = 0; p->labels_ready = false;
     p->ring = 0; p->ring_slots = 0; p->ring_slot_bytes = 0; p->ring_imported = false;
-    p->async_ready = false;
     if (!max_launch_table_bytes) max_launch_table_bytes = (size_t)256 << 20;
     const uint64_t cap = max_launch_table_bytes / 2048 ? max_launch_table_bytes / 2048 : 1;
     if (lambdas) {
@@ -314,60 +304,6 @@ extern "C" int lgc_party_evaluate_ring(lgc_party *p, size_t launch) {
     RCHK(hipSetDevice(p->device));
     RCHK(party_launch<false>(p, p->P.launches[launch], ring_slot(p, launch)));
     RCHK(hipDeviceSynchronize());
-    return LGC_OK;
-}
-
-// ---- the same two steps without blocking: *_begin enqueues launch k, lgc_party_ring_wait(k) returns once its tables
-// (garbler) / its output words (evaluator) are complete.  The host loop begins launch k + 1 before it waits for k, so the
-// token round trip and -- on the garbler -- the table pass of a critical-path launch run beside the next record kernel.
-static int ring_async_setup(lgc_party *p) {
-    if (p->async_ready) return LGC_OK;
-    RCHK(hipStreamCreate(&p->sA));
-    RCHK(hipStreamCreate(&p->sT));
-    RCHK(hipEventCreateWithFlags(&p->evA, hipEventDisableTiming));
-    for (int i = 0; i < 4; i++) RCHK(hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming));
-    p->async_ready = true;
-    return LGC_OK;
-}
-extern "C" int lgc_party_garble_ring_begin(lgc_party *p, size_t launch) {
-    if (!p) return lgc_fail(LGC_EINVAL, "null party");
-    if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "not the garbler");
-    if (!p->ring) return lgc_fail(LGC_ESTATE, "lgc_party_ring_create has not been called");
-    if (launch >= p->P.launches.size()) return lgc_fail(LGC_EINVAL, "launch out of range");
-    RCHK(hipSetDevice(p->device));
-    int rc = ring_async_setup(p);
-    if (rc) return rc;
-    const Launch &L = p->P.launches[launch];
-    Lbl *slot = ring_slot(p, launch);
-    RCHK(gc_launch_records<true>(p->recs, L, p->words, p->dec, slot, p->R, p->P.w, p->P.p, p->sA));
-    if (gc_launch_is_crit(L)) {
-        RCHK(hipEventRecord(p->evA, p->sA));
-        RCHK(hipStreamWaitEvent(p->sT, p->evA, 0));
-        RCHK(gc_launch_tabfill(L, slot, p->R, p->sT));
-        RCHK(hipEventRecord(p->done[launch & 3], p->sT));
-    } else {
-        RCHK(hipEventRecord(p->done[launch & 3], p->sA));
-    }
-    return LGC_OK;
-}
-extern "C" int lgc_party_evaluate_ring_begin(lgc_party *p, size_t launch) {
-    if (!p) return lgc_fail(LGC_EINVAL, "null party");
-    if (p->role != LGC_ROLE_EVALUATOR) return lgc_fail(LGC_ESTATE, "not the evaluator");
-    if (!p->ring) return lgc_fail(LGC_ESTATE, "lgc_party_ring_open has not been called");
-    if (!p->labels_ready) return lgc_fail(LGC_ESTATE, "input labels have not been set");
-    if (launch >= p->P.launches.size()) return lgc_fail(LGC_EINVAL, "launch out of range");
-    RCHK(hipSetDevice(p->device));
-    int rc = ring_async_setup(p);
-    if (rc) return rc;
-    RCHK(gc_launch_records<false>(p->recs, p->P.launches[launch], p->words, p->dec, ring_slot(p, launch), p->R, p->P.w, p->P.p, p->sA));
-    RCHK(hipEventRecord(p->done[launch & 3], p->sA));
-    return LGC_OK;
-}
-extern "C" int lgc_party_ring_wait(lgc_party *p, size_t launch) {
-    if (!p) return lgc_fail(LGC_EINVAL, "null party");
-    if (!p->async_ready) return lgc_fail(LGC_ESTATE, "no asynchronous ring launch has been started");
-    RCHK(hipSetDevice(p->device));
-    RCHK(hipEventSynchronize(p->done[launch & 3]));
     return LGC_OK;
 }
 

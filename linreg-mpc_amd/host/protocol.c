@@ -310,26 +310,6 @@ int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
         h.nslots = (uint64_t)ring_slots; h.slot_bytes = sb;
         if (send_blob(self, peer, &h, sizeof h)) return 1;
         uint8_t tok = 0;
-        if (ring_slots >= 2) {
-            /* launch i is enqueued before the host waits for launch i - 1 and passes its token on: the token round
-             * trip and the table pass of a critical-path launch run beside the next record kernel.  (With two slots or
-             * more the free-slot token of launch i - slots is always one the evaluator could already send.) */
-            for (size_t i = 0; i < nl; i++) {
-                if (i >= (size_t)ring_slots && recv_blob(self, peer, &tok, 1)) return 1;   /* slot is free again */
-                TCHK(lgc_party_garble_ring_begin(po, i));
-                if (i > 0) {
-                    TCHK(lgc_party_ring_wait(po, i - 1));
-                    tok = 1;
-                    if (send_blob(self, peer, &tok, 1)) return 1;
-                }
-            }
-            if (nl) {
-                TCHK(lgc_party_ring_wait(po, nl - 1));
-                tok = 1;
-                if (send_blob(self, peer, &tok, 1)) return 1;
-            }
-            return 0;
-        }
         for (size_t i = 0; i < nl; i++) {
             if (i >= (size_t)ring_slots && recv_blob(self, peer, &tok, 1)) return 1;   /* slot is free again */
             TCHK(lgc_party_garble_ring(po, i));

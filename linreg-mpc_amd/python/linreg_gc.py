@@ -98,7 +98,6 @@ def lib():
             ("lgc_party_input_pairs", [vp, sz, vp, vp]), ("lgc_party_encode_inputs", [vp, sz, vp, vp]),
             ("lgc_party_set_input_labels", [vp, sz, vp]), ("lgc_party_garble", [vp, sz, vp]),
             ("lgc_party_evaluate", [vp, sz, vp]), ("lgc_party_decode_bits", [vp, vp]),
-            ("lgc_party_garble_ring_begin", [vp, sz]), ("lgc_party_evaluate_ring_begin", [vp, sz]), ("lgc_party_ring_wait", [vp, sz]),
             ("lgc_party_finish", [vp, vp, vp, vp, vp]),
             ("lgc_ot_sender_create", [C.POINTER(vp), ci, C.c_char_p, vp]),
             ("lgc_ot_receiver_create", [C.POINTER(vp), ci, vp, vp]),
