@@ -126,36 +126,19 @@ ot_gilboa_send_kernel(const uint4 *rows, uint4 delta, const uint64_t *bvals, uin
     const int lw = w == 32 ? 5 : 6;
     for (uint64_t q = blockIdx.y; q < npairs; q += gridDim.y) {
         uint64_t acc = 0;
-        // two OTs per thread and trip: four independent AES blocks in flight per lane (two hid the LDS latency of a
-        // round only partly: these kernels ran at a third of the MAC kernels' AES rate)
-        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-        for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m_per_pair; t += 2 * stride) {
-            const uint64_t t1 = t + stride;
-            const bool two = t1 < m_per_pair;
-            const uint64_t i = q * m_per_pair + t, i1 = q * m_per_pair + (two ? t1 : t);
-            const Lbl r0 = u4_lbl(rows[i]), r1 = u4_lbl(rows[i1]);
-            Lbl x[4] = {r0, lxor(r0, u4_lbl(delta)), r1, lxor(r1, u4_lbl(delta))};
-            uint64_t tw[4] = {tweak0 + i, tweak0 + i, tweak0 + i1, tweak0 + i1};
-            Lbl h[4];
-            hash_n<4, LdsTab4>(lt, c_rk, x, tw, h, c_rk24);
-            {
-                const uint64_t k = t >> lw;             // w is 32 or 64: no 64-bit division in the inner loop
-                const int bit = (int)(t & (uint64_t)(w - 1));
-                uint64_t x0 = ((uint64_t)h[0].x | ((uint64_t)h[0].y << 32)) & mask;
-                uint64_t h1 = ((uint64_t)h[1].x | ((uint64_t)h[1].y << 32)) & mask;
-                uint64_t d = (bvals[q * n + k] << bit) & mask;
-                y[i] = (x0 + d - h1) & mask;
-                acc -= x0;
-            }
-            if (two) {
-                const uint64_t k = t1 >> lw;
-                const int bit = (int)(t1 & (uint64_t)(w - 1));
-                uint64_t x0 = ((uint64_t)h[2].x | ((uint64_t)h[2].y << 32)) & mask;
-                uint64_t h1 = ((uint64_t)h[3].x | ((uint64_t)h[3].y << 32)) & mask;
-                uint64_t d = (bvals[q * n + k] << bit) & mask;
-                y[i1] = (x0 + d - h1) & mask;
-                acc -= x0;
-            }
+        for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m_per_pair; t += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t i = q * m_per_pair + t;
+            const uint64_t k = t >> lw;                 // w is 32 or 64: no 64-bit division in the inner loop
+            const int bit = (int)(t & (uint64_t)(w - 1));
+            Lbl x[2] = {u4_lbl(rows[i]), lxor(u4_lbl(rows[i]), u4_lbl(delta))};
+            uint64_t tw[2] = {tweak0 + i, tweak0 + i};
+            Lbl h[2];
+            hash_n<2, LdsTab4>(lt, c_rk, x, tw, h, c_rk24);
+            uint64_t x0 = ((uint64_t)h[0].x | ((uint64_t)h[0].y << 32)) & mask;
+            uint64_t h1 = ((uint64_t)h[1].x | ((uint64_t)h[1].y << 32)) & mask;
+            uint64_t d = (bvals[q * n + k] << bit) & mask;
+            y[i] = (x0 + d - h1) & mask;
+            acc -= x0;
         }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
         if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&shares[q], (unsigned long long)acc);
@@ -172,29 +155,17 @@ ot_gilboa_recv_kernel(const uint4 *rows, const uint64_t *avals, uint64_t n, int 
     const int lw = w == 32 ? 5 : 6;
     for (uint64_t q = blockIdx.y; q < npairs; q += gridDim.y) {
         uint64_t acc = 0;
-        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-        for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m_per_pair; t += 2 * stride) {   // two OTs per trip
-            const uint64_t t1 = t + stride;
-            const bool two = t1 < m_per_pair;
-            const uint64_t i = q * m_per_pair + t, i1 = q * m_per_pair + (two ? t1 : t);
-            Lbl x[2] = {u4_lbl(rows[i]), u4_lbl(rows[i1])};
-            uint64_t tw[2] = {tweak0 + i, tweak0 + i1};
-            Lbl h[2];
-            hash_n<2, LdsTab4>(lt, c_rk, x, tw, h, c_rk24);
-            {
-                const uint64_t k = t >> lw;             // w is 32 or 64: no 64-bit division in the inner loop
-                const int bit = (int)(t & (uint64_t)(w - 1));
-                uint64_t v = ((uint64_t)h[0].x | ((uint64_t)h[0].y << 32)) & mask;
-                if ((avals[q * n + k] >> bit) & 1ull) v += y[i];
-                acc += v;
-            }
-            if (two) {
-                const uint64_t k = t1 >> lw;
-                const int bit = (int)(t1 & (uint64_t)(w - 1));
-                uint64_t v = ((uint64_t)h[1].x | ((uint64_t)h[1].y << 32)) & mask;
-                if ((avals[q * n + k] >> bit) & 1ull) v += y[i1];
-                acc += v;
-            }
+        for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m_per_pair; t += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t i = q * m_per_pair + t;
+            const uint64_t k = t >> lw;                 // w is 32 or 64: no 64-bit division in the inner loop
+            const int bit = (int)(t & (uint64_t)(w - 1));
+            Lbl x = u4_lbl(rows[i]);
+            uint64_t tw = tweak0 + i;
+            Lbl h;
+            hash_n<1, LdsTab4>(lt, c_rk, &x, &tw, &h, c_rk24);
+            uint64_t v = ((uint64_t)h.x | ((uint64_t)h.y << 32)) & mask;
+            if ((avals[q * n + k] >> bit) & 1ull) v += y[i];
+            acc += v;
         }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
         if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&shares[q], (unsigned long long)acc);
