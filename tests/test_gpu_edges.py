@@ -86,6 +86,19 @@ def test_extreme_operand_values(lgc, oracle):
             _check(lgc, oracle, A, b, d, w, p, "cgd", 2, 2, 0, 0.0, rng)
 
 
+def test_parked_table_ring_is_reused_and_released(lgc, oracle):
+    """a closed solver parks its table ring for the next one (gc_engine.hip: RingCache): a larger system after a smaller
+    one, a smaller one after a larger one and a solve after lgc_release_cached_memory() all give the oracle's result"""
+    rng = np.random.default_rng(41)
+    for d in (6, 12, 4):
+        A, b = synth_system(oracle, rng, 40, d, 64, 56)
+        _check(lgc, oracle, A, b, d, 64, 56, "cholesky", 0, 2, 0, 0.0, rng)
+    lgc.release_cached_memory()
+    lgc.release_cached_memory()                      # nothing parked: a no-op
+    A, b = synth_system(oracle, rng, 40, 5, 64, 56)
+    _check(lgc, oracle, A, b, 5, 64, 56, "cgd", 3, 2, 0, 0.0, rng)
+
+
 def test_rejects_unsupported_parameters(lgc):
     with pytest.raises(lgc.LgcError):
         lgc.Solver(lgc.make_system(3, width=64, precision=64))      # p < width (src/cmd/linreg.c:85-88)
