@@ -13,6 +13,7 @@
 #include <errno.h>
 #include <math.h>
 #include <openssl/rand.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,6 +26,13 @@ typedef struct { size_t n, next; const uint32_t *launch; double *time; double t0
 static void note_launch(size_t i, void *ctx) {
     iter_marks *m = ctx;
     while (m->next < m->n && m->launch[m->next] == i) m->time[m->next++] = wall_clock() - m->t0;
+}
+
+typedef struct { node *self; int peer, rc; uint8_t delta[16], seeds[128][16]; pthread_t th; } base_ot_job;
+static void *base_ot_main(void *arg) {
+    base_ot_job *j = arg;
+    j->rc = baseot_ext_sender(j->self, j->peer, j->delta, j->seeds);
+    return NULL;
 }
 
 int main(int argc, char **argv) {
@@ -165,11 +173,22 @@ int main(int argc, char **argv) {
         uint8_t *m0 = lgc_host_alloc(bits * 16), *m1 = lgc_host_alloc(bits * 16), *u = lgc_host_alloc(lgc_ot_u_bytes(bits)),
                 *e = lgc_host_alloc(bits * 32);
         check(m0 && m1 && u && e, "%s", lgc_last_error());
+        /* the base OTs (128 P-256 transfers per data provider, host work on both sides) run for all providers at once: each
+         * uses its own connection and its own OpenSSL objects */
+        base_ot_job *jobs = calloc((size_t)P, sizeof *jobs);
+        check(jobs != NULL, "out of memory");
+        for (int k = 3; k <= c->num_parties; k++) {
+            jobs[k - 3].self = self; jobs[k - 3].peer = k;
+            check(!pthread_create(&jobs[k - 3].th, NULL, base_ot_main, &jobs[k - 3]), "could not start a base-OT thread");
+        }
+        for (int k = 3; k <= c->num_parties; k++) {
+            pthread_join(jobs[k - 3].th, NULL);
+            check(!jobs[k - 3].rc, "base OT with party %d failed", k);
+        }
+        TRACE("base OTs done");
         for (int k = 3; k <= c->num_parties; k++) {                  /* data providers in order (linear.oc:31) */
-            uint8_t delta[16], seeds[128][16];
-            check(!baseot_ext_sender(self, k, delta, seeds), "base OT with party %d failed", k);
             lgc_ot_sender *S = 0;
-            LGC(lgc_ot_sender_create(&S, device, delta, seeds));
+            LGC(lgc_ot_sender_create(&S, device, jobs[k - 3].delta, jobs[k - 3].seeds));
             LGC(lgc_party_input_pairs(party_obj, (size_t)(k - 3), m0, m1));
             check(!recv_blob(self, k, u, lgc_ot_u_bytes(bits)), "OT: could not receive u from party %d", k);
             LGC(lgc_ot_labels_send(S, m0, m1, bits, u, e));
@@ -177,6 +196,7 @@ int main(int argc, char **argv) {
             lgc_ot_sender_destroy(S);
         }
         lgc_host_free(m0); lgc_host_free(m1); lgc_host_free(u); lgc_host_free(e);
+        free(jobs);
         TRACE("input labels sent");
         check(!tables_send(self, 2, party_obj, ring_slots, kTableChunk), "could not stream the garbled tables");
         TRACE("tables sent");
