@@ -232,6 +232,46 @@ struct Program {
             emit(recs_best[i]);
         }
         new_launch();
+        // Merging the partial sums of a job is a chain of carry-save steps as long as the job has parts (two words per
+        // piece).  Where few jobs run at once the chain IS the run time of the merge launch (Cholesky at d = 100: 198
+        // merge launches of up to 198 + 14 dependent steps, 8 % of the solve), so long merges go in two levels: groups of
+        // about sqrt(parts) words are resolved side by side, then the group sums are merged (sums mod 2^w: any grouping
+        // gives the same word).  Many jobs at once (a merged lambda sweep) are throughput-bound and keep the single
+        // level: the extra additions would cost more than the shorter chain saves.
+        size_t maxparts = 0;
+        for (size_t i = 0; i < jobs.size(); i++) if (jobs[i].len && parts[i].second > maxparts) maxparts = parts[i].second;
+        if (jobs.size() <= kSumTreeMaxJobs && maxparts >= kSumTreeMinParts) {
+            std::vector<uint32_t> gsz(jobs.size(), 0), gcnt(jobs.size(), 0);
+            size_t need = 0;
+            for (size_t i = 0; i < jobs.size(); i++) {
+                if (jobs[i].len == 0) continue;
+                uint32_t cnt = parts[i].second, m = 1;
+                while ((uint64_t)m * m < cnt) m++;
+                gsz[i] = m; gcnt[i] = (cnt + m - 1) / m;
+                need += gcnt[i];
+            }
+            if (need > sum_tree_cap) { sum_tree_cap = need + need / 2 + 16; sum_tree_base = alloc(sum_tree_cap); }
+            uint32_t off = 0;
+            std::vector<uint32_t> first(jobs.size(), 0);
+            for (size_t i = 0; i < jobs.size(); i++) {
+                if (jobs[i].len == 0) continue;
+                first[i] = sum_tree_base + off;
+                for (uint32_t g = 0; g < gcnt[i]; g++) {
+                    uint32_t lo = g * gsz[i], n = parts[i].second - lo < gsz[i] ? parts[i].second - lo : gsz[i];
+                    emit(mk(OP_SUM, first[i] + g, parts[i].first + lo, 0, 0, n));
+                }
+                off += gcnt[i];
+            }
+            new_launch();
+            for (size_t i = 0; i < jobs.size(); i++) {
+                const DotJob &J = jobs[i];
+                if (J.len == 0) continue;
+                if (J.has_base) emit(mk(OP_SUBSUM, J.dst, first[i], 0, J.base, gcnt[i]));
+                else emit(mk(OP_SUM, J.dst, first[i], 0, 0, gcnt[i]));
+            }
+            new_launch();
+            return;
+        }
         for (size_t i = 0; i < jobs.size(); i++) {
             const DotJob &J = jobs[i];
             if (J.len == 0) continue;
@@ -240,6 +280,9 @@ struct Program {
         }
         new_launch();
     }
+    static constexpr size_t kSumTreeMaxJobs = 1024, kSumTreeMinParts = 32;
+    uint32_t sum_tree_base = 0;          // scratch words of the first merge level (grow-only, shared by all dots() calls)
+    size_t sum_tree_cap = 0;
     // products per OP_MAC record: enough records to fill the chip (target_waves), and
     // short enough that one table slot (cap_steps gate steps) still holds >= kMinRecsPerLaunch
     // records -- a launch with fewer waves than the GPU has wave slots idles most CUs
