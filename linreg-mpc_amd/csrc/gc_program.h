@@ -519,7 +519,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.new_launch();
     } else {  // ALG_LDLT
         const uint32_t tv = P.alloc(d);
-        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d, d, 4096) + 4 * d);
+        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d + d, d + 1, 4096) + 4 * d + 8);
         for (size_t j = 0; j < d; j++) {             // ldlt.oc:50-64
             if (j > 0) {
                 for (size_t k = 0; k < j; k++) P.emit(Program::mk(OP_MUL, tv + (uint32_t)k, Mi(j, k), Mi(k, k)));
@@ -529,18 +529,17 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
                     Program::DotJob J = {Mi(i, j), Mi(i, j), Mi(i, 0), tv, (uint32_t)j, true};
                     jobs.push_back(J);
                 }
+                // step j of the forward substitution (:67-73), b_j -= sum_{k<j} L_jk b_k, needs row j of L (complete once
+                // column j - 1 has been scaled) and b_0 .. b_{j-1}: it joins the dot products of column j instead of
+                // forming a chain of d - 1 launch pairs of its own after the factorisation (as in the Cholesky lowering)
+                Program::DotJob F = {bv + (uint32_t)j, bv + (uint32_t)j, Mi(j, 0), bv, (uint32_t)j, true};
+                jobs.push_back(F);
                 P.dots(jobs, sc_dot, 4096);
             }
             for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_DIV, Mi(k, j), Mi(k, j), Mi(j, j)));
             P.new_launch();
             for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_COPY, Mi(j, k), Mi(k, j)));
             P.new_launch();
-        }
-        for (size_t i = 1; i < d; i++) {             // :67-73
-            std::vector<Program::DotJob> jobs(1);
-            Program::DotJob J = {bv + (uint32_t)i, bv + (uint32_t)i, Mi(i, 0), bv, (uint32_t)i, true};
-            jobs[0] = J;
-            P.dots(jobs, sc_dot, 64);
         }
         for (size_t i = 0; i < d; i++)               // :76-79
             P.emit(Program::mk(OP_DIV, bv + (uint32_t)i, bv + (uint32_t)i, Mi(i, i)));
