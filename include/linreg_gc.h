@@ -219,7 +219,11 @@ int lgc_party_encode_inputs(lgc_party *p, size_t share, const uint64_t *values, 
  * slot k % nslots.  The host keeps the ordering: the garbler may call lgc_party_garble_ring(k)
  * only after the evaluator has finished launch k - nslots; the evaluator may call
  * lgc_party_evaluate_ring(k) only after lgc_party_garble_ring(k) has returned.  Both calls block
- * until their kernel has completed. */
+ * until their kernel has completed.
+ * What the ring ever holds is what the socket would carry: garbled tables (and zeros).  The garbler's
+ * intermediate state of critical-path launches -- zero-labels, from which R follows -- stays in a buffer
+ * private to its process (src/input.c:94-108: label pairs never leave the CSP); a failed call leaves the
+ * slot with its previous contents. */
 int lgc_party_ring_create(lgc_party *p, int nslots, uint8_t handle_out[64], size_t *slot_bytes);
 int lgc_party_ring_open(lgc_party *p, const uint8_t handle[64], int nslots, size_t slot_bytes);
 int lgc_party_garble_ring(lgc_party *p, size_t launch);
@@ -335,6 +339,14 @@ void lgc_release_cached_memory(void);
  * and consume the same garbled tables, so garbler and evaluator may differ; process-wide, takes
  * effect at the next launch.  Exists for A/B timing and for the interchangeability test. */
 void lgc_set_split_kernels(int garbler, int evaluator);
+
+/* Test hooks (tests/test_gpu_roles.py; not part of the drop-in surface).  lgc_test_party_garble_ring_stage
+ * issues launch k as lgc_party_garble_ring does, in halves: stage 1 = the record kernel (stops before the table
+ * pass of a critical-path launch; *is_critical_path tells whether the launch has one), stage 2 = the table pass.
+ * lgc_test_party_ring_read copies `bytes` of the ring slot of launch k to the host -- what the mapped peer could
+ * read at that moment. */
+int lgc_test_party_garble_ring_stage(lgc_party *p, size_t launch, int stage, int *is_critical_path);
+int lgc_test_party_ring_read(lgc_party *p, size_t launch, uint8_t *out, size_t bytes);
 
 /* ------------------------------------------------------- micro-benchmarks */
 /* Stand-alone LDS T-table AES throughput (the "AES roofline" of the north

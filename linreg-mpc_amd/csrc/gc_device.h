@@ -17,10 +17,19 @@
 
 namespace gc {
 
-__constant__ uint32_t c_rk[44];
-__constant__ uint32_t c_te0[256];
-__constant__ uint32_t c_rk24[44];
+// Device constants of the fixed-key AES.  `static`: every translation unit of the library (the garbler kernels, the
+// evaluator kernels, the engine, phase 1, OT -- compiled in parallel, csrc/Makefile) has its own copy, which its
+// gc_tu_upload() fills; lgc_upload_constants() (gc_engine.hip) calls them all for the current device.
+static __constant__ uint32_t c_rk[44];
+static __constant__ uint32_t c_te0[256];
+static __constant__ uint32_t c_rk24[44];
 // c_rk24: rotl24 of the round keys (two-table AES rounds)
+static inline hipError_t gc_tu_upload(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_rk), rk, 44 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_te0), te0, 256 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_rk24), rk24, 44 * sizeof(uint32_t));
+    return e;
+}
 
 #ifndef GC_SOLO_INLINE
 #define GC_SOLO_INLINE 1   /* wide generic kernel: gate bodies inlined at every AND site (0: one out-of-line body; the call ABI
@@ -615,12 +624,13 @@ gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *d
     exec_record(be, r, w, p);
 }
 
-// second pass of critical-path garbling: every gate step of the launch holds (a0, b0) in its two table
-// rows; one wavefront per step turns them into the half-gates ciphertexts (TG, TE) in place.  All four
-// hashes are recomputed here, in throughput mode (16 waves per CU, four-table AES).
+// second pass of critical-path garbling: the stash holds (a0, b0) of every gate step of the launch (two rows
+// per step); one wavefront per step turns them into the half-gates ciphertexts (TG, TE) of the launch's table
+// (stash == tab: in place).  All four hashes are recomputed here, in throughput mode (16 waves per CU,
+// four-table AES).
 template <int TPB>
 __global__ void __launch_bounds__(TPB)
-gc_tabfill_kernel(Lbl *tab, uint32_t nsteps, uint64_t launch_step0, Lbl R) {
+gc_tabfill_kernel(const Lbl *stash, Lbl *tab, uint32_t nsteps, uint64_t launch_step0, Lbl R) {
     __shared__ uint32_t lds_te0[2 * kLdsTabWords];
     lds_tab4_fill(lds_te0);
     const LdsTab4 lt = lds_tab4_make(lds_te0);
@@ -628,7 +638,8 @@ gc_tabfill_kernel(Lbl *tab, uint32_t nsteps, uint64_t launch_step0, Lbl R) {
     const uint32_t per = TPB / 64;
     for (uint32_t row = blockIdx.x * per + (threadIdx.x >> 6); row < nsteps; row += gridDim.x * per) {
         Lbl *slot = tab + (size_t)row * 128 + lane;
-        const Lbl a0 = ld_lbl(slot), b0 = ld_lbl(slot + 64);
+        const Lbl *src = stash + (size_t)row * 128 + lane;
+        const Lbl a0 = ld_lbl(src), b0 = ld_lbl(src + 64);
         Lbl TG = lzero(), TE = lzero();
         if ((a0.x | a0.y | a0.z | a0.w | b0.x | b0.y | b0.z | b0.w) != 0u) {
             const uint64_t gid = (launch_step0 + row) * 64 + (uint64_t)lane;

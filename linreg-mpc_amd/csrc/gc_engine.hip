@@ -54,16 +54,22 @@ int lgc_need_device(int device) {
 static AesTables g_tabs;
 static bool g_tabs_built = false;
 static const AesTables &tables() {
-    if (!g_tabs_built) { aes_build_tables(g_tabs, kFixedKey); g_tabs_built = true; }
+    static std::once_flag once;
+    std::call_once(once, [] { aes_build_tables(g_tabs, kFixedKey); g_tabs_built = true; });
     return g_tabs;
 }
+// every translation unit with device code has its own copy of the AES constants (gc_device.h): fill them all, on the
+// CURRENT device (callers have just selected it: lgc_need_device)
+hipError_t p1_tu_upload(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24);
+hipError_t ot_tu_upload(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24);
 int lgc_upload_constants() {
     const AesTables &t = tables();
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rk), t.rk, sizeof(t.rk)));
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_te0), t.te0, sizeof(t.te0)));
     uint32_t rk24[44];
     for (int i = 0; i < 44; i++) rk24[i] = (t.rk[i] << 24) | (t.rk[i] >> 8);
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rk24), rk24, sizeof(rk24)));
+    HIPCHK(gc_tu_upload(t.rk, t.te0, rk24));
+    HIPCHK(gc_kern_upload_all(t.rk, t.te0, rk24));
+    HIPCHK(p1_tu_upload(t.rk, t.te0, rk24));
+    HIPCHK(ot_tu_upload(t.rk, t.te0, rk24));
     return LGC_OK;
 }
 
@@ -554,20 +560,23 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
             HIPCHK(hipStreamWaitEvent(sG, s->evE[i - 1], 0));
 #endif
         if (timed) HIPCHK(hipEventRecord(s->evs[3 * i], sG));
+        const LaunchMode modeG = gc_launch_mode(L, true);      // read once: record kernel and table pass agree
         if (pre && i < P.prefix_launches) {          // tables already in the ring
             if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
             if (!profile) HIPCHK(hipEventRecord(s->evG[i], sG));
-        } else if (profile || !gc_launch_is_crit(L)) {
-            HIPCHK(gc_launch<true>(s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
+        } else if (profile || !gc_mode_is_crit(modeG, L)) {
+            HIPCHK(gc_launch_records<true>(modeG, s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
+            if (gc_mode_is_crit(modeG, L)) HIPCHK(gc_launch_tabfill(L, tab, tab, s->R, sG));
             if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
             if (!profile) HIPCHK(hipEventRecord(s->evG[i], sG));
         } else {
-            // critical path on the garbler chain, table pass on the side stream: only the evaluation waits for it
-            HIPCHK(gc_launch_records<true>(s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
+            // critical path on the garbler chain, table pass on the side stream: only the evaluation waits for it.
+            // The stash is the launch's own ring region (in place): this ring is private to the process
+            HIPCHK(gc_launch_records<true>(modeG, s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
             if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
             HIPCHK(hipEventRecord(s->evC[i], sG));
             HIPCHK(hipStreamWaitEvent(s->streamT, s->evC[i], 0));
-            HIPCHK(gc_launch_tabfill(L, tab, s->R, s->streamT));
+            HIPCHK(gc_launch_tabfill(L, tab, tab, s->R, s->streamT));
             HIPCHK(hipEventRecord(s->evG[i], s->streamT));
         }
         if (!profile) HIPCHK(hipStreamWaitEvent(sE, s->evG[i], 0));
@@ -770,8 +779,8 @@ extern "C" void *lgc_host_alloc(size_t bytes) {
 extern "C" void lgc_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 extern "C" void lgc_set_split_kernels(int garbler, int evaluator) {
-    gc_split_enabled(true) = garbler != 0;
-    gc_split_enabled(false) = evaluator != 0;
+    gc_split_enabled(true).store(garbler != 0);
+    gc_split_enabled(false).store(evaluator != 0);
 }
 
 // --------------------------------------------------------- micro-benchmarks

@@ -1,0 +1,27 @@
+// gc_kern.hip -- one translation unit per (role, kernel family): compiled with -DGC_KERN_G=0|1 (evaluator | garbler)
+// and -DGC_KERN_PART=0|1|2|3 (MAC | generic, one wave per record | column-split | generic, 4 waves per record; the garbler's
+// part 2 also holds the table pass of critical-path garbling).  Eight units build in parallel instead of one that takes minutes.
+#include "gc_kernels.h"
+
+#define GC_CAT3_(a, b, c) a##b##_##c
+#define GC_CAT3(a, b, c) GC_CAT3_(a, b, c)
+#if GC_KERN_G
+#define GC_ROLE_TAG g
+#else
+#define GC_ROLE_TAG e
+#endif
+
+namespace gc {
+hipError_t GC_CAT3(gc_launch_records_, GC_ROLE_TAG, GC_KERN_PART)(LaunchMode m, const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec,
+                                                                   Lbl *tab, Lbl R, int w, int p, hipStream_t st) {
+    return gc_launch_records_impl<GC_KERN_G != 0, GC_KERN_PART>(m, recs, L, words, dec, tab, R, w, p, st);
+}
+hipError_t GC_CAT3(gc_kern_upload_, GC_ROLE_TAG, GC_KERN_PART)(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24) {
+    return gc_tu_upload(rk, te0, rk24);
+}
+#if GC_KERN_G && GC_KERN_PART == 2
+hipError_t gc_launch_tabfill(const Launch &L, const Lbl *stash, Lbl *tab, Lbl R, hipStream_t st) {
+    return gc_launch_tabfill_impl(L, stash, tab, R, st);
+}
+#endif
+}  // namespace gc

@@ -5,9 +5,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "gc_device.h"
+#include <atomic>
+
+#include "gc_aes.h"
 #include "gc_program.h"
-#include "gc_split.h"
 
 namespace gc {
 
@@ -87,9 +88,10 @@ static constexpr int kTpbTabfill = 1024;
 #define GC_SPLIT_MAX_RECS 256
 #endif
 static constexpr uint32_t kSplitMaxRecs = GC_SPLIT_MAX_RECS;
-// ... switchable per role at run time (lgc_set_split_kernels): the two kernels are interchangeable
-inline int &gc_split_enabled(bool garbler) {
-    static int on[2] = {1, 1};
+// ... switchable per role at run time (lgc_set_split_kernels): the two kernels are interchangeable.  A launch reads the
+// flag ONCE (gc_launch_mode) and passes the decision down: record kernel and table pass can never disagree
+inline std::atomic<int> &gc_split_enabled(bool garbler) {
+    static std::atomic<int> on[2] = {{1}, {1}};
     return on[garbler ? 0 : 1];
 }
 
@@ -137,95 +139,79 @@ static inline unsigned gc_mac_waves(uint32_t nrec, unsigned lo, unsigned hi) {
     return best;
 }
 
-// the launch runs in the 16-wave column-split kernel (role G: garbler, else evaluator)
-static inline bool gc_launch_is_split(const Launch &L, bool garbler) {
-    const bool mac = L.mac_only && L.nrec >= kNarrowMac;
-    const bool wide = L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps;
-    return GC_SPLIT && gc_split_enabled(garbler) && !mac && !wide && L.nrec > 0 && L.nrec <= kSplitMaxRecs;
+// which kernel runs a launch for one role
+enum LaunchMode {
+    LM_NONE = 0,     // no records
+    LM_MAC,          // gc_mac_kernel: one wave per record, throughput
+    LM_WIDE,         // gc_exec_kernel<.., false, 4, ..>: one wave per generic record
+    LM_SPLIT,        // gc_split_kernel: 16 waves per record, column-split (garbler: critical path + table pass)
+    LM_QUAD4,        // GC_QUAD4 builds only: 4 waves per record on the four-table image (garbler: critical path + table pass)
+    LM_QUAD2         // 4 waves per record on the two-table image, two workgroups per CU
+};
+static inline LaunchMode gc_launch_mode(const Launch &L, bool garbler) {
+    if (L.nrec == 0) return LM_NONE;
+    if (L.mac_only && L.nrec >= kNarrowMac) return LM_MAC;
+    if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) return LM_WIDE;
+    if (GC_SPLIT && L.nrec <= kSplitMaxRecs && gc_split_enabled(garbler).load(std::memory_order_relaxed)) return LM_SPLIT;
+    if (GC_QUAD4 && L.nrec <= kQuadOnePerCu) return LM_QUAD4;
+    return LM_QUAD2;
 }
-// true when the garbler of this launch runs the critical path only and needs gc_launch_tabfill afterwards
-static inline bool gc_launch_is_crit(const Launch &L) {
-    const bool mac = L.mac_only && L.nrec >= kNarrowMac;
-    const bool wide = L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps;
-    if (L.steps == 0) return false;
-    if (gc_launch_is_split(L, true)) return true;
-    return GC_CRIT && GC_QUAD4 && !mac && !wide && L.nrec > 0 && L.nrec <= kCritMaxRecs;
+// true when the garbler's record kernel of this mode computes the critical path only: it leaves the zero-labels
+// (a0, b0) of every gate in a STASH (two rows per gate step, the layout of the launch's table) and gc_launch_tabfill
+// turns the stash into the ciphertexts
+static inline bool gc_mode_is_crit(LaunchMode m, const Launch &L) {
+    return L.steps != 0 && (m == LM_SPLIT || (m == LM_QUAD4 && GC_CRIT));
 }
-// the table pass of a critical-path launch; it only has to finish before the launch is EVALUATED, so the
-// co-located solver runs it on a side stream while the garbler chain moves on to the next launch
-static hipError_t gc_launch_tabfill(const Launch &L, Lbl *tab, Lbl R, hipStream_t st) {
-    const uint64_t per = kTpbTabfill / 64;
-    uint64_t blocks = (L.steps + per - 1) / per;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL((gc_tabfill_kernel<kTpbTabfill>), dim3((unsigned)blocks), dim3(kTpbTabfill), 0, st, tab,
-                       (uint32_t)L.steps, L.step0, R);
-    return hipGetLastError();
+// The kernels live in translation units of their own -- gc_kern.hip compiled per (role, kernel family), gc_kernels.h
+// holds the dispatch -- so that the library builds in parallel.
+// The table pass of a critical-path launch: stash -> tab (in place when they are the same buffer).  It only has to
+// finish before the launch is EVALUATED, so the co-located solver runs it on a side stream while the garbler chain
+// moves on to the next launch.  With the roles in different processes `tab` is memory the evaluator maps (hipIpc
+// table ring) and `stash` is private to the garbler: nothing but finished ciphertexts is ever stored to `tab`.
+hipError_t gc_launch_tabfill(const Launch &L, const Lbl *stash, Lbl *tab, Lbl R, hipStream_t st);
+#define GC_KERN_DECL(tag)                                                                                                              \
+    hipError_t gc_launch_records_##tag(LaunchMode m, const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R, int w, \
+                                       int p, hipStream_t st);                                                                         \
+    hipError_t gc_kern_upload_##tag(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24);
+GC_KERN_DECL(g_0) GC_KERN_DECL(g_1) GC_KERN_DECL(g_2) GC_KERN_DECL(g_3) GC_KERN_DECL(e_0) GC_KERN_DECL(e_1) GC_KERN_DECL(e_2) GC_KERN_DECL(e_3)
+#undef GC_KERN_DECL
+static inline hipError_t gc_kern_upload_all(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24) {
+    hipError_t e = gc_kern_upload_g_0(rk, te0, rk24);
+    if (e == hipSuccess) e = gc_kern_upload_g_1(rk, te0, rk24);
+    if (e == hipSuccess) e = gc_kern_upload_g_2(rk, te0, rk24);
+    if (e == hipSuccess) e = gc_kern_upload_e_0(rk, te0, rk24);
+    if (e == hipSuccess) e = gc_kern_upload_e_1(rk, te0, rk24);
+    if (e == hipSuccess) e = gc_kern_upload_e_2(rk, te0, rk24);
+    if (e == hipSuccess) e = gc_kern_upload_g_3(rk, te0, rk24);
+    if (e == hipSuccess) e = gc_kern_upload_e_3(rk, te0, rk24);
+    return e;
 }
-
-// the record kernel of a launch (garbler: without the table pass)
+// the record kernel of a launch in mode `m` (garbler in a critical-path mode: `tab` is the stash)
 template <bool G>
-static hipError_t gc_launch_records(const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R, int w, int p,
-                                    hipStream_t st) {
-    if (L.nrec == 0) return hipSuccess;
-    if (L.mac_only && L.nrec >= kNarrowMac) {
-        constexpr int TPB = G ? kTpbMacG : kTpbMacE;       // upper bound (register budget of the kernel)
-        const unsigned per = gc_mac_waves(L.nrec, G ? GC_MAC_ADAPT_LO_G : GC_MAC_ADAPT_LO_E, TPB / 64);
-#if GC_MAC_TAIL_SPLIT
-        // One workgroup per CU, every record the same length: the launch runs in rounds of (CUs x waves) records and
-        // a partly filled last round costs a whole one.  The records beyond the last full round therefore go into a
-        // second launch of ONE workgroup per CU with just enough waves: an LDS-bound workgroup of w waves takes
-        // about w / 16 of the time of a full one, so the tail costs its share instead of a round.
-        const uint32_t round = gc_num_cus() * per, full = L.nrec / round * round, rest = L.nrec - full;
-        if (!GC_MAC_ADAPT && full && rest && rest < round - round / 8) {
-            unsigned wv = (rest + gc_num_cus() - 1) / gc_num_cus();
-            hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3(full / per), dim3(per * 64), 0, st, recs + L.first_rec, full, words,
-                               tab, L.step0, R, w, p);
-            hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((rest + wv - 1) / wv), dim3(wv * 64), 0, st, recs + L.first_rec + full, rest,
-                               words, tab, L.step0, R, w, p);
-            return hipGetLastError();
-        }
-#endif
-        unsigned wgs = (L.nrec + per - 1) / per;
-#if GC_MAC_PERSIST      /* one workgroup per CU: the waves walk the records themselves (gc_device.h) */
-        if (G && wgs > gc_num_cus() && wgs <= GC_MAC_PERSIST_MAX_ROUNDS * gc_num_cus()) wgs = gc_num_cus();
-#endif
-        hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3(wgs), dim3(per * 64), 0, st, recs + L.first_rec, L.nrec, words, tab,
-                           L.step0, R, w, p);
-    } else if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) {
-        // records (waves) per workgroup: as few as keep the launch within one workgroup per CU, at most TPB / 64 --
-        // a launch of 800 dividers runs as 200 workgroups of 4 waves, one round, instead of 67 CUs with 12 waves each
-        unsigned per = (L.nrec + gc_num_cus() - 1) / gc_num_cus();
-        if (per > (unsigned)kTpbWide / 64) per = kTpbWide / 64;
-        if (!GC_WIDE_ADAPT) per = kTpbWide / 64;
-        hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(per * 64), 0, st,
-                           recs + L.first_rec, L.nrec, words, tab, dec, L.step0, R, w, p);
-    } else if (gc_launch_is_split(L, G)) {
-        hipLaunchKernelGGL((gc_split_kernel<G>), dim3(L.nrec), dim3(1024), 0, st, recs + L.first_rec, L.nrec, words, tab, dec, L.step0,
-                           R, w, p);
-#if GC_QUAD4          /* the 4-wave kernels with the four-table image (garbler: critical-path garbling): what ran these launches
-                         before the column-split kernel; with 0 (default, 45 s less to compile) a role whose split kernel is
-                         switched off runs them in the two-table 4-wave kernel below */
-    } else if (L.nrec <= kQuadOnePerCu) {
-        hipLaunchKernelGGL((gc_exec_kernel<G, true, 4, 256, G && GC_CRIT>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec,
-                           L.nrec, words, tab, dec, L.step0, R, w, p);
-#endif
-#if GC_CRIT_MAX_RECS > GC_QUAD_ONE_PER_CU     /* critical-path garbling at two workgroups per CU: measured, no gain; not instantiated */
-    } else if (L.nrec <= kCritMaxRecs) {
-        hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256, G && GC_CRIT>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec,
-                           L.nrec, words, tab, dec, L.step0, R, w, p);
-#endif
-    } else {
-        hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec, L.nrec, words,
-                           tab, dec, L.step0, R, w, p);
+static inline hipError_t gc_launch_records(LaunchMode m, const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R,
+                                          int w, int p, hipStream_t st) {
+    switch (m) {
+    case LM_NONE: return hipSuccess;
+    case LM_MAC: return G ? gc_launch_records_g_0(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_0(m, recs, L, words, dec, tab, R, w, p, st);
+    case LM_SPLIT: return G ? gc_launch_records_g_2(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_2(m, recs, L, words, dec, tab, R, w, p, st);
+    case LM_WIDE: return G ? gc_launch_records_g_1(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_1(m, recs, L, words, dec, tab, R, w, p, st);
+    default: return G ? gc_launch_records_g_3(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_3(m, recs, L, words, dec, tab, R, w, p, st);
     }
-    return hipGetLastError();
 }
 
+// A whole launch of one role.  stash: garbler only -- where a critical-path record kernel leaves the zero-labels for the
+// table pass; 0 = in the launch's own table rows (the co-located solver, whose ring no other process maps).
+// stages (test hook only): 1 = record kernel, 2 = table pass, 3 = both; *was_crit reports whether the launch has a table pass.
 template <bool G>
 static hipError_t gc_launch(const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R, int w, int p,
-                            hipStream_t st) {
-    hipError_t e = gc_launch_records<G>(recs, L, words, dec, tab, R, w, p, st);
-    if (e == hipSuccess && G && gc_launch_is_crit(L)) e = gc_launch_tabfill(L, tab, R, st);
+                            hipStream_t st, Lbl *stash = 0, int stages = 3, bool *was_crit = 0) {
+    const LaunchMode m = gc_launch_mode(L, G);
+    const bool crit = G && gc_mode_is_crit(m, L);
+    if (was_crit) *was_crit = crit;
+    Lbl *rec_tab = (crit && stash) ? stash : tab;
+    hipError_t e = hipSuccess;
+    if (stages & 1) e = gc_launch_records<G>(m, recs, L, words, dec, rec_tab, R, w, p, st);
+    if (e == hipSuccess && crit && (stages & 2)) e = gc_launch_tabfill(L, rec_tab, tab, R, st);
     return e;
 }
 

@@ -210,9 +210,14 @@ extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint
     return LGC_OK;
 }
 
+// tab: where the launch's garbled tables go / come from (0: the party's private buffer).  A garbler that writes into
+// memory the evaluator process maps (the hipIpc ring) keeps the zero-label stash of critical-path launches in its
+// PRIVATE buffer p->tab: only finished ciphertexts are ever stored to the shared slot (src/input.c:94-108 -- label
+// pairs never leave the CSP)
 template <bool G>
-static hipError_t party_launch(lgc_party *p, const Launch &L, Lbl *tab = 0) {
-    return gc_launch<G>(p->recs, L, p->words, p->dec, tab ? tab : p->tab, p->R, p->P.w, p->P.p, 0);
+static hipError_t party_launch(lgc_party *p, const Launch &L, Lbl *tab = 0, int stages = 3, bool *was_crit = 0) {
+    return gc_launch<G>(p->recs, L, p->words, p->dec, tab ? tab : p->tab, p->R, p->P.w, p->P.p, 0, (G && tab) ? p->tab : (Lbl *)0,
+                        stages, was_crit);
 }
 
 extern "C" int lgc_party_garble(lgc_party *p, size_t launch, uint8_t *tables_out) {
@@ -293,6 +298,25 @@ extern "C" int lgc_party_garble_ring(lgc_party *p, size_t launch) {
     RCHK(hipSetDevice(p->device));
     RCHK(party_launch<true>(p, p->P.launches[launch], ring_slot(p, launch)));
     RCHK(hipDeviceSynchronize());      // kernel end = release: the tables are visible to the peer process
+    return LGC_OK;
+}
+// ---- test hooks (tests/test_gpu_roles.py): what the peer-mapped ring holds at a given moment
+// `launch` exactly as lgc_party_garble_ring issues it, in two halves: stage 1 = the record kernel (stops BEFORE the table
+// pass of a critical-path launch), stage 2 = the table pass
+extern "C" int lgc_test_party_garble_ring_stage(lgc_party *p, size_t launch, int stage, int *is_critical_path) {
+    if (!p || !p->ring || p->role != LGC_ROLE_GARBLER || launch >= p->P.launches.size() || (stage != 1 && stage != 2))
+        return lgc_fail(LGC_EINVAL, "bad argument");
+    RCHK(hipSetDevice(p->device));
+    bool crit = false;
+    RCHK(party_launch<true>(p, p->P.launches[launch], ring_slot(p, launch), stage, &crit));
+    RCHK(hipDeviceSynchronize());
+    if (is_critical_path) *is_critical_path = crit ? 1 : 0;
+    return LGC_OK;
+}
+extern "C" int lgc_test_party_ring_read(lgc_party *p, size_t launch, uint8_t *out, size_t bytes) {
+    if (!p || !p->ring || !out || bytes > p->ring_slot_bytes) return lgc_fail(LGC_EINVAL, "bad argument");
+    RCHK(hipSetDevice(p->device));
+    RCHK(hipMemcpy(out, ring_slot(p, launch), bytes, hipMemcpyDeviceToHost));
     return LGC_OK;
 }
 extern "C" int lgc_party_evaluate_ring(lgc_party *p, size_t launch) {

@@ -1,6 +1,4 @@
-// liblinreg_gc.hip -- single translation unit of the product library (the device
-// constants c_rk / c_te0 of gc_device.h must exist once).
+// liblinreg_gc.hip -- host engine + C ABI translation unit (solver, separate roles).  The heavy kernels are in
+// gc_kern_g.hip / gc_kern_e.hip, phase 1 and OT in their own units: csrc/Makefile builds them in parallel.
 #include "gc_engine.hip"
-#include "phase1.hip"
-#include "ot.hip"
 #include "gc_roles.hip"

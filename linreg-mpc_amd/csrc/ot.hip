@@ -31,6 +31,7 @@ using namespace gc;
 int lgc_fail(int code, const char *fmt, ...);
 int lgc_need_device(int device);
 int lgc_upload_constants();
+hipError_t ot_tu_upload(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24) { return gc_tu_upload(rk, te0, rk24); }
 
 #define OTCHK(x)                                                                             \
     do {                                                                                     \

@@ -24,6 +24,7 @@ using namespace gc;
 int lgc_fail(int code, const char *fmt, ...);
 int lgc_need_device(int device);
 int lgc_upload_constants();
+hipError_t p1_tu_upload(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24) { return gc_tu_upload(rk, te0, rk24); }
 
 #define P1CHK(x)                                                                             \
     do {                                                                                     \
@@ -141,13 +142,15 @@ p1_diag_kernel(const int64_t *X, size_t n, size_t ld, const uint32_t *cols, uint
 }
 
 // ---- batched masking: out[q][k] = X[k][col[q]] + sign * V[q][k]   (mod 2^64)
+// m = 2^w - 1: the message is truncated to the protocol width HERE, so that a buffer another party maps (--ti_ring)
+// never holds bits 32..63 of X +- v at w = 32 (X is stored sign-extended)
 __global__ void p1_mask_kernel(const int64_t *X, size_t n, size_t ld, const uint32_t *cols, const uint64_t *V,
-                               int sign, uint64_t *out) {
+                               int sign, uint64_t *out, uint64_t m) {
     const uint32_t q = blockIdx.y;
     const uint32_t c = cols[q];
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
         uint64_t x = (uint64_t)X[k * ld + c], v = V[(size_t)q * n + k];
-        out[(size_t)q * n + k] = sign > 0 ? x + v : x - v;
+        out[(size_t)q * n + k] = (sign > 0 ? x + v : x - v) & m;
     }
 }
 
@@ -165,10 +168,10 @@ __device__ __forceinline__ uint64_t p1_block_sum(uint64_t acc) {
 }
 // out[k] = X[k][col] + sign * V[k]
 __global__ void __launch_bounds__(1024)
-p1_mask1_kernel(const int64_t *X, size_t n, size_t ld, uint32_t col, const uint64_t *V, int sign, uint64_t *out) {
+p1_mask1_kernel(const int64_t *X, size_t n, size_t ld, uint32_t col, const uint64_t *V, int sign, uint64_t *out, uint64_t m) {
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
         uint64_t x = (uint64_t)X[k * ld + col], v = V[k];
-        out[k] = sign > 0 ? x + v : x - v;
+        out[k] = (sign > 0 ? x + v : x - v) & m;
     }
 }
 // out[0] = sum_k A[k] * (Bv ? Bv[k] : X[k][col])
@@ -183,11 +186,11 @@ p1_dot1_kernel(const uint64_t *A, const uint64_t *Bv, const int64_t *X, size_t l
 // party a of inner_product_ti in one pass (phase1.c:186-196): out[k] = a[k] - y[k] for k < n, and
 // out[n] = sum_k in[k] * y[k]   (in = b + x from party b, y from the TI)
 __global__ void __launch_bounds__(1024)
-p1_ti_a_kernel(const int64_t *X, size_t n, size_t ld, uint32_t col, const uint64_t *y, const uint64_t *in, uint64_t *out) {
+p1_ti_a_kernel(const int64_t *X, size_t n, size_t ld, uint32_t col, const uint64_t *y, const uint64_t *in, uint64_t *out, uint64_t m) {
     uint64_t acc = 0;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
         uint64_t yk = y[k];
-        out[k] = (uint64_t)X[k * ld + col] - yk;
+        out[k] = ((uint64_t)X[k * ld + col] - yk) & m;
         acc += in[k] * yk;
     }
     uint64_t t = p1_block_sum(acc);
@@ -197,13 +200,13 @@ p1_ti_a_kernel(const int64_t *X, size_t n, size_t ld, uint32_t col, const uint64
 // the same for a run of pairs with one peer: grid.y strides over the pairs; acc[q] zeroed by the host
 __global__ void __launch_bounds__(256)
 p1_ti_a_batch_kernel(const int64_t *X, size_t n, size_t ld, const uint32_t *cols, size_t npairs, const uint64_t *y, const uint64_t *in,
-                     uint64_t *out, uint64_t *acc_out) {
+                     uint64_t *out, uint64_t *acc_out, uint64_t m) {
     for (size_t q = blockIdx.y; q < npairs; q += gridDim.y) {
         const uint32_t col = cols[q];
         uint64_t acc = 0;
         for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
             uint64_t yk = y[q * n + k];
-            out[q * n + k] = (uint64_t)X[k * ld + col] - yk;
+            out[q * n + k] = ((uint64_t)X[k * ld + col] - yk) & m;
             acc += in[q * n + k] * yk;
         }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -420,7 +423,7 @@ extern "C" int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const
         unsigned gx = (unsigned)((h->n + 255) / 256); if (gx > 64) gx = 64;
         for (size_t q0 = 0; q0 < npairs; q0 += 65535) {
             unsigned gy = (unsigned)(npairs - q0 < 65535 ? npairs - q0 : 65535);
-            hipLaunchKernelGGL(p1_mask_kernel, dim3(gx, gy), dim3(256), 0, st, h->X, h->n, h->d + 1, dcols + q0, V + q0 * h->n, sign, out + q0 * h->n);
+            hipLaunchKernelGGL(p1_mask_kernel, dim3(gx, gy), dim3(256), 0, st, h->X, h->n, h->d + 1, dcols + q0, V + q0 * h->n, sign, out + q0 * h->n, maskw(h->w));
             P1CHK(hipGetLastError());
         }
         P1CHK(hipGetLastError());
@@ -432,7 +435,7 @@ extern "C" int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const
         P1CHK(t_scratch.get(h->device, 2, bytes, (void **)&dout));
         P1CHK(hipMemcpyAsync(dV, V, bytes, hipMemcpyHostToDevice, st));
         unsigned g1 = (unsigned)((h->n + 1023) / 1024); if (g1 > 64) g1 = 64;
-        hipLaunchKernelGGL(p1_mask1_kernel, dim3(g1), dim3(1024), 0, st, h->X, h->n, h->d + 1, cols[0], dV, sign, dout);
+        hipLaunchKernelGGL(p1_mask1_kernel, dim3(g1), dim3(1024), 0, st, h->X, h->n, h->d + 1, cols[0], dV, sign, dout, maskw(h->w));
         P1CHK(hipGetLastError());
         P1CHK(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
         P1CHK(hipStreamSynchronize(st));
@@ -445,7 +448,7 @@ extern "C" int lgc_p1_mask(lgc_p1 *h, const uint32_t *cols, size_t npairs, const
     P1CHK(hipMemcpyAsync(dcols, cols, npairs * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     P1CHK(hipMemcpyAsync(dV, V, bytes, hipMemcpyHostToDevice, st));
     unsigned gx = (unsigned)((h->n + 255) / 256); if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(p1_mask_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, st, h->X, h->n, h->d + 1, dcols, dV, sign, dout);
+    hipLaunchKernelGGL(p1_mask_kernel, dim3(gx, (unsigned)npairs), dim3(256), 0, st, h->X, h->n, h->d + 1, dcols, dV, sign, dout, maskw(h->w));
     P1CHK(hipGetLastError());
     P1CHK(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
     P1CHK(hipStreamSynchronize(st));
@@ -535,7 +538,7 @@ extern "C" int lgc_p1_ti_a(lgc_p1 *h, uint32_t col, const uint64_t *y, const uin
     P1CHK(hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, st));
     P1CHK(hipMemsetAsync(dout + n, 0, sizeof(uint64_t), st));
     unsigned g1 = (unsigned)((n + 1023) / 1024); if (g1 > 64) g1 = 64;
-    hipLaunchKernelGGL(p1_ti_a_kernel, dim3(g1), dim3(1024), 0, st, h->X, n, h->d + 1, col, dy, din, dout);
+    hipLaunchKernelGGL(p1_ti_a_kernel, dim3(g1), dim3(1024), 0, st, h->X, n, h->d + 1, col, dy, din, dout, maskw(h->w));
     P1CHK(hipGetLastError());
     P1CHK(hipMemcpyAsync(out_mask, dout, bytes, hipMemcpyDeviceToHost, st));
     uint64_t acc = 0;
@@ -566,7 +569,7 @@ extern "C" int lgc_p1_ti_a_batch(lgc_p1 *h, const uint32_t *cols, size_t npairs,
         P1CHK(hipMemsetAsync(dacc, 0, npairs * sizeof(uint64_t), st));
         unsigned gx = (unsigned)((n + 255) / 256); if (gx > 64) gx = 64;
         unsigned gy = npairs > 65535 ? 65535u : (unsigned)npairs;
-        hipLaunchKernelGGL(p1_ti_a_batch_kernel, dim3(gx, gy), dim3(256), 0, st, h->X, n, h->d + 1, dcols, npairs, y, in, out_mask, dacc);
+        hipLaunchKernelGGL(p1_ti_a_batch_kernel, dim3(gx, gy), dim3(256), 0, st, h->X, n, h->d + 1, dcols, npairs, y, in, out_mask, dacc, maskw(h->w));
         P1CHK(hipGetLastError());
         P1CHK(hipMemcpyAsync(shares, dacc, npairs * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         P1CHK(hipStreamSynchronize(st));
@@ -584,7 +587,7 @@ extern "C" int lgc_p1_ti_a_batch(lgc_p1 *h, const uint32_t *cols, size_t npairs,
     P1CHK(hipMemsetAsync(dout + npairs * n, 0, npairs * sizeof(uint64_t), st));
     unsigned gx = (unsigned)((n + 255) / 256); if (gx > 64) gx = 64;
     unsigned gy = npairs > 65535 ? 65535u : (unsigned)npairs;
-    hipLaunchKernelGGL(p1_ti_a_batch_kernel, dim3(gx, gy), dim3(256), 0, st, h->X, n, h->d + 1, dcols, npairs, dy, din, dout, dout + npairs * n);
+    hipLaunchKernelGGL(p1_ti_a_batch_kernel, dim3(gx, gy), dim3(256), 0, st, h->X, n, h->d + 1, dcols, npairs, dy, din, dout, dout + npairs * n, maskw(h->w));
     P1CHK(hipGetLastError());
     P1CHK(hipMemcpyAsync(out_mask, dout, bytes, hipMemcpyDeviceToHost, st));
     P1CHK(hipMemcpyAsync(shares, dout + npairs * n, npairs * sizeof(uint64_t), hipMemcpyDeviceToHost, st));

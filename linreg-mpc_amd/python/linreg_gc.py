@@ -99,6 +99,9 @@ def lib():
             ("lgc_party_set_input_labels", [vp, sz, vp]), ("lgc_party_garble", [vp, sz, vp]),
             ("lgc_party_evaluate", [vp, sz, vp]), ("lgc_party_decode_bits", [vp, vp]),
             ("lgc_party_finish", [vp, vp, vp, vp, vp]),
+            ("lgc_party_ring_create", [vp, ci, vp, C.POINTER(sz)]), ("lgc_party_ring_open", [vp, vp, ci, sz]),
+            ("lgc_party_garble_ring", [vp, sz]), ("lgc_party_evaluate_ring", [vp, sz]),
+            ("lgc_test_party_garble_ring_stage", [vp, sz, ci, C.POINTER(ci)]), ("lgc_test_party_ring_read", [vp, sz, vp, sz]),
             ("lgc_ot_sender_create", [C.POINTER(vp), ci, C.c_char_p, vp]),
             ("lgc_ot_receiver_create", [C.POINTER(vp), ci, vp, vp]),
             ("lgc_ot_sender_set_device_io", [vp, ci]), ("lgc_ot_receiver_set_device_io", [vp, ci]),
@@ -406,6 +409,34 @@ class Party:
     def evaluate(self, k, tables):
         tables = np.ascontiguousarray(tables, dtype=np.uint8)
         _chk(lib().lgc_party_evaluate(self._h, k, _vp(tables) if tables.size else None))
+
+    # ---- device-resident table ring (garbler and evaluator processes on one node)
+    def ring_create(self, nslots):
+        """garbler: allocate the ring; returns (64-byte hipIpc handle, slot bytes) for the evaluator process"""
+        h = np.zeros(64, dtype=np.uint8); sb = C.c_size_t()
+        _chk(lib().lgc_party_ring_create(self._h, nslots, _vp(h), C.byref(sb)))
+        return h.tobytes(), sb.value
+
+    def ring_open(self, handle, nslots, slot_bytes):
+        _chk(lib().lgc_party_ring_open(self._h, _vp(np.frombuffer(handle, dtype=np.uint8).copy()), nslots, slot_bytes))
+
+    def garble_ring(self, k):
+        _chk(lib().lgc_party_garble_ring(self._h, k))
+
+    def evaluate_ring(self, k):
+        _chk(lib().lgc_party_evaluate_ring(self._h, k))
+
+    def test_garble_ring_stage(self, k, stage):
+        """test hook: stage 1 = record kernel of launch k into the ring path, 2 = its table pass; returns True when the
+        launch is garbled on the critical path (has a table pass)"""
+        crit = C.c_int()
+        _chk(lib().lgc_test_party_garble_ring_stage(self._h, k, stage, C.byref(crit)))
+        return bool(crit.value)
+
+    def test_ring_read(self, k, nbytes):
+        out = np.zeros(max(1, nbytes), dtype=np.uint8)
+        _chk(lib().lgc_test_party_ring_read(self._h, k, _vp(out), nbytes))
+        return out[:nbytes]
 
     def decode_bits(self):
         out = np.zeros(max(1, self.num_reveal), dtype=np.uint64)

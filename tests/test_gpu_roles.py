@@ -77,3 +77,87 @@ def test_two_party_path_garbler_encodes_own_input(lgc, oracle):
     beta, _, _ = E.finish(G.decode_bits())
     exp, _, _ = oracle_solve(oracle, A, b, d, w, p, "cgd", 2, 0.0, 0)
     assert beta.tolist() == exp.tolist()
+
+
+def test_table_ring_holds_ciphertexts_only(lgc):
+    """the hipIpc table ring is mapped by the Evaluator process: at no moment may it hold the garbler's zero-labels
+    (one zero-label next to the active label of the same wire gives R).  Critical-path launches (dividers, square
+    roots, max trees: record kernel + table pass) keep their stash in the garbler's private buffer, so the record
+    kernel leaves the slot untouched -- all-zero on first use -- and the table pass fills it with exactly the bytes
+    the socket path sends (src/input.c:94-108: label pairs never leave the CSP)."""
+    sysm = lgc.make_system(5, 64, 56, "cholesky", 0, 0.001, 2, 1)
+    seed = bytes(range(7, 23))
+    G = lgc.Party(sysm, lgc.GARBLER, seed=seed); ref = lgc.Party(sysm, lgc.GARBLER, seed=seed)
+    nslots = 64
+    G.ring_create(nslots)
+    crit_launches, steps_checked = 0, 0
+    for k in range(G.num_launches):
+        nb = G.table_bytes(k)
+        before = G.test_ring_read(k, nb)
+        if k < nslots:
+            assert not before.any()                              # zero-filled at creation, never used
+        crit = G.test_garble_ring_stage(k, 1)                    # record kernel only
+        after = G.test_ring_read(k, nb)
+        expect = ref.garble(k)                                   # the same launch on the socket path, same seed
+        if crit:
+            crit_launches += 1
+            steps_checked += nb // 2048
+            assert np.array_equal(after, before)                 # nothing reached the shared slot yet
+            G.test_garble_ring_stage(k, 2)                       # table pass
+            after = G.test_ring_read(k, nb)
+        if crit or k < nslots:
+            assert np.array_equal(after, expect)
+        else:                                                    # reused slot: lanes without a gate keep older ciphertexts
+            live = expect != 0
+            assert np.array_equal(after[live], expect[live])
+    assert crit_launches >= 10 and steps_checked > 5000           # sqrt / div launches of the 5 columns
+    G.close(); ref.close()
+
+
+def test_ti_ring_messages_are_truncated_to_32_bits(lgc, oracle):
+    """--ti_ring --width_phase1=32: the masked vectors b + x and a - y are written to device memory the peer provider
+    maps.  X is stored sign-extended to 64 bits, so the kernels must truncate to the protocol width: bits 32..63 of a
+    word would otherwise carry the sign of the private datum plus a carry (the socket path masks on the host)."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    n, d, p, w = 257, 3, 30, 32
+    X = rng.standard_normal((n, d)); X /= np.abs(X).max(axis=0)
+    Xq = oracle.quantize(X, p, n, w).reshape(n, d)
+    assert (Xq < 0).any()
+    L = lgc.lib()
+    L.lgc_p1_set_device_io.argtypes = [C.c_void_p, C.c_int]; L.lgc_p1_set_device_io.restype = C.c_int
+    L.lgc_p1_ti_a_batch.argtypes = [C.c_void_p] * 2 + [C.c_size_t] + [C.c_void_p] * 5; L.lgc_p1_ti_a_batch.restype = C.c_int
+    for f, a in (("lgc_dev_alloc", [C.c_int, C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p]), ("lgc_dev_upload", [C.c_void_p, C.c_void_p, C.c_size_t]),
+                 ("lgc_dev_download", [C.c_void_p, C.c_void_p, C.c_size_t])):
+        getattr(L, f).argtypes = a; getattr(L, f).restype = C.c_int
+    L.lgc_dev_free.argtypes = [C.c_void_p]; L.lgc_dev_free.restype = None
+    ph = lgc.Phase1(Xq, None, w, p)
+    npairs = 3
+    V = rng.integers(0, 1 << 32, size=(npairs, n), dtype=np.uint64)
+    inn = rng.integers(0, 1 << 32, size=(npairs, n), dtype=np.uint64)
+    cols = np.array([0, 2, 1], dtype=np.uint32)
+    host_pos = ph.mask(cols, V, +1); host_neg = ph.mask(cols, V, -1)          # host path: masked on the way out
+    nbytes = npairs * n * 8
+    dV, dIn, dOut = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    for ptr in (dV, dIn, dOut):
+        assert L.lgc_dev_alloc(0, nbytes, C.byref(ptr), None) == 0
+    assert L.lgc_dev_upload(dV, V.ctypes.data_as(C.c_void_p), nbytes) == 0
+    assert L.lgc_dev_upload(dIn, inn.ctypes.data_as(C.c_void_p), nbytes) == 0
+    assert L.lgc_p1_set_device_io(ph._h, 1) == 0
+    out = np.zeros((npairs, n), dtype=np.uint64)
+    for sign, host in ((+1, host_pos), (-1, host_neg)):
+        assert L.lgc_p1_mask(ph._h, cols.ctypes.data_as(C.c_void_p), npairs, dV, sign, dOut) == 0
+        assert L.lgc_dev_download(out.ctypes.data_as(C.c_void_p), dOut, nbytes) == 0
+        assert not (out >> np.uint64(32)).any()                  # what the mapped peer reads: 32-bit words only
+        assert np.array_equal(out, host)
+    sub = np.zeros(npairs, dtype=np.uint64); shares = np.zeros(npairs, dtype=np.uint64)
+    assert L.lgc_p1_ti_a_batch(ph._h, cols.ctypes.data_as(C.c_void_p), npairs, dV, dIn, sub.ctypes.data_as(C.c_void_p), dOut,
+                               shares.ctypes.data_as(C.c_void_p)) == 0
+    assert L.lgc_dev_download(out.ctypes.data_as(C.c_void_p), dOut, nbytes) == 0
+    assert not (out >> np.uint64(32)).any()
+    assert np.array_equal(out, host_neg)                         # a - y, the same message as mask(-1)
+    exp = [(int((inn[q].astype(object) * V[q].astype(object)).sum()) & 0xffffffff) for q in range(npairs)]
+    assert shares.tolist() == exp
+    for ptr in (dV, dIn, dOut):
+        L.lgc_dev_free(ptr)
+    ph.close()
