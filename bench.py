@@ -181,6 +181,27 @@ def two_process_ring(np, d, iters, p, Af, bf, gates, device_index):
                                         "wall_all_s also holds process start, parsing of the 250 000-entry text file, base OTs and input OT"}
 
 
+def self_launch(n):
+    """one child process per GPU; no exec, no GPU call in this (parent) process"""
+    import subprocess
+    port = _free_ports(1)[0]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL), stderr=None))
+    out0, _ = procs[0].communicate()
+    rcs = [q.wait() for q in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +221,12 @@ def main():
     ap.add_argument("--sweep-iters", type=int, default=15)
     ap.add_argument("--sweep-lambdas", type=int, default=64)
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It starts one CHILD per GPU
+    # (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, as torch.distributed.run would set them) before
+    # anything here touches the GPU, relays rank 0's JSON line, and exits non-zero if any rank does.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.child:
+        raise SystemExit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,6 +248,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible; there is no CPU fallback)")
     ndev = torch.cuda.device_count()
     device_index = local_rank % max(1, ndev)     # one rank per GPU; wraps only in single-GPU dry runs
+    if world > ndev and os.environ.get("LGC_BENCH_BACKEND", "nccl") == "nccl":
+        raise SystemExit("bench.py: %d ranks but %d visible GPU(s): an RCCL group needs one GPU per rank "
+                         "(LGC_BENCH_BACKEND=gloo dry-runs N ranks on fewer GPUs)" % (world, ndev))
     torch.cuda.set_device(device_index)
     dist = None
     backend = os.environ.get("LGC_BENCH_BACKEND", "nccl")   # "gloo" only to dry-run N > 1 on one GPU
@@ -238,6 +268,14 @@ def main():
             dist.barrier()                           # creates the RCCL communicator now, not inside the timed region
         else:
             dist.init_process_group(backend=backend)
+
+    # what the process group really is: ranks RCCL sees, and the distinct GPUs behind them
+    rccl_ranks = dist.get_world_size() if (dist is not None and backend == "nccl") else None
+    devices = [device_index]
+    if dist is not None:
+        ids = [None] * dist.get_world_size()
+        dist.all_gather_object(ids, "%s/%d" % (os.uname().nodename, device_index))
+        devices = sorted(set(ids))
 
     d, iters, w, p = args.d, args.iters, args.width, args.precision
     T = d * (d + 1) // 2
@@ -334,10 +372,13 @@ def main():
         sres = sweep.shared_prefix_sweep(sshares if rank == 0 else None, lams, sd, make, dist=dist, tensor_device="cuda", stats=sst)
         barrier()
         sdt = time.perf_counter() - ts
+        phase_keys = ("create_s", "prefix_garble_s", "broadcast_s", "block_s", "gather_s")
+        phases = [float(sst.get(k, 0.0)) for k in phase_keys]
         if dist is not None:
-            tmax = torch.tensor([sdt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            tmax = torch.tensor([sdt] + phases, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            sdt = float(tmax.item())
+            sdt = float(tmax[0].item())
+            phases = [float(v) for v in tmax[1:].tolist()]
         dump = os.environ.get("LGC_BENCH_DUMP")
         if dump:                                                   # tests: what every rank holds after the gather
             json.dump({"rank": rank, "lambdas": lams, "beta": sres.tolist(), "shares": sshares.tolist(), "d": sd, "iters": sit,
@@ -348,6 +389,10 @@ def main():
             sweep_res = {"lambdas": nl, "d": sd, "iterations": sit, "n_gpus": world, "seconds": sdt,
                          "circuits_per_s": nl / sdt, "and_gates": sgates, "and_gates_per_s": sgates / sdt,
                          "prefix_bytes_broadcast": sst.get("prefix_bytes") if world > 1 else 0,
+                         # wall-clock of each phase, max over ranks (python/sweep.py): solver creation on every rank at once;
+                         # rank 0 garbles + exports the prefix while the others wait at the broadcast with their buffers
+                         # allocated; the broadcast itself as rank 0 sees it; this rank's block; the result gather
+                         **dict(zip(phase_keys, phases)),
                          "collectives": ("broadcast(seed, garbled prefix) + all_gather(results) over %s" % backend) if world > 1 else None,
                          "sharding": "contiguous blocks of %d lambdas per rank; prefix (input labels + share-summation tables) garbled once on rank 0" % ((nl + world - 1) // world)}
             sweep_check = (stot, sT, sd, sit, lams, sres, nl)      # compared with the oracle in the cpu_baseline leg
@@ -451,6 +496,7 @@ def main():
             "value": value, "unit": "AND-gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "barrier_backend": (backend if dist is not None else None),
+            "rccl_ranks": rccl_ranks, "devices": devices,
             "vs_baseline": value / REF_RATE if (d == 500 and iters == 15 and w == 64) else None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "phase-2 CGD solve, d=%d, %d iterations, %d-bit fixed point, precision %d, "

@@ -196,6 +196,18 @@ int lgc_party_create(lgc_party **out, int device, const lgc_system *sys, int rol
 int lgc_party_create_sweep(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
                            size_t max_launch_table_bytes, size_t count, const double *lambdas);
 size_t lgc_party_num_circuits(const lgc_party *p);
+/* The sweep on several GPUs of one CSP / Evaluator process (bin/linreg --lambdas --devices=...; SURVEY.md 8(e),
+ * src/cmd/linreg.c:145-199 runs one execYaoProtocol per circuit): each device gets ONE party object holding the
+ * contiguous block [first, first + count) of the sweep's circuits.  All garbler blocks share the seed -- one set
+ * of input labels, one label OT per data provider -- and `first` keeps the gate ids of different blocks disjoint.
+ * The prefix launches [0, lgc_party_prefix_launches) (share summation; lambda enters after it) are garbled /
+ * evaluated by the first block only; lgc_party_share_prefix copies the words they produce to another block of the
+ * same role (another GPU: over xGMI), which then runs the launches from lgc_party_prefix_launches on. */
+int lgc_party_create_sweep_at(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
+                              size_t max_launch_table_bytes, size_t count, const double *lambdas, size_t first);
+size_t lgc_party_prefix_launches(const lgc_party *p);
+uint64_t lgc_party_prefix_and_gates(const lgc_party *p);
+int lgc_party_share_prefix(lgc_party *dst, const lgc_party *src);
 void lgc_party_destroy(lgc_party *p);
 size_t lgc_party_num_launches(const lgc_party *p);
 size_t lgc_party_table_bytes(const lgc_party *p, size_t launch);

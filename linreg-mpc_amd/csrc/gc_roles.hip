@@ -80,20 +80,51 @@ extern "C" void lgc_party_destroy(lgc_party *p) {
 }
 
 static int party_create(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
-                        size_t max_launch_table_bytes, size_t count, const double *lambdas);
+                        size_t max_launch_table_bytes, size_t count, const double *lambdas, size_t first);
 extern "C" int lgc_party_create(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
                                 size_t max_launch_table_bytes) {
-    return party_create(out, device, sys, role, seed, max_launch_table_bytes, 1, 0);
+    return party_create(out, device, sys, role, seed, max_launch_table_bytes, 1, 0, 0);
+}
+extern "C" int lgc_party_create_sweep_at(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
+                                         size_t max_launch_table_bytes, size_t count, const double *lambdas, size_t first) {
+    int rc = check_sweep(sys, count, lambdas);
+    if (rc) return rc;
+    return party_create(out, device, sys, role, seed, max_launch_table_bytes, count, lambdas, first);
 }
 extern "C" int lgc_party_create_sweep(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
                                       size_t max_launch_table_bytes, size_t count, const double *lambdas) {
-    int rc = check_sweep(sys, count, lambdas);
-    if (rc) return rc;
-    return party_create(out, device, sys, role, seed, max_launch_table_bytes, count, lambdas);
+    return lgc_party_create_sweep_at(out, device, sys, role, seed, max_launch_table_bytes, count, lambdas, 0);
 }
 extern "C" size_t lgc_party_num_circuits(const lgc_party *p) { return p ? p->P.replicas : 0; }
+extern "C" size_t lgc_party_prefix_launches(const lgc_party *p) { return p ? p->P.prefix_launches : 0; }
+extern "C" uint64_t lgc_party_prefix_and_gates(const lgc_party *p) {
+    uint64_t g = 0;
+    if (p) for (uint32_t i = 0; i < p->P.prefix_launches; i++) g += p->P.launches[i].gates;
+    return g;
+}
+// Blocks of one sweep on several GPUs of ONE process (bin/linreg --devices): `src` has garbled / evaluated the prefix
+// launches; `dst` (same role, same system, same seed, possibly another device) takes the words of the shared region --
+// constant zero, inputs, share sums -- over xGMI (hipMemcpyPeer) and then runs launches [prefix_launches, n) only.
+extern "C" int lgc_party_share_prefix(lgc_party *dst, const lgc_party *src) {
+    if (!dst || !src) return lgc_fail(LGC_EINVAL, "null party");
+    if (dst->role != src->role || dst->P.shared_end != src->P.shared_end || dst->P.prefix_launches != src->P.prefix_launches ||
+        !src->P.prefix_launches || dst->P.w != src->P.w)
+        return lgc_fail(LGC_EINVAL, "the parties are not blocks of the same sweep");
+    if (dst->role == LGC_ROLE_GARBLER && memcmp(&dst->R, &src->R, sizeof(Lbl)) != 0)
+        return lgc_fail(LGC_EINVAL, "garbler blocks of one sweep share the seed");
+    if (!src->labels_ready) return lgc_fail(LGC_ESTATE, "the source has no input labels yet");
+    RCHK(hipSetDevice(src->device));
+    RCHK(hipDeviceSynchronize());                       // the source's prefix launches are complete
+    RCHK(hipSetDevice(dst->device));
+    const size_t n = (size_t)src->P.shared_end * 64 * sizeof(Lbl);
+    if (dst->device == src->device) RCHK(hipMemcpy(dst->words, src->words, n, hipMemcpyDeviceToDevice));
+    else RCHK(hipMemcpyPeer(dst->words, dst->device, src->words, src->device, n));
+    RCHK(hipDeviceSynchronize());
+    dst->labels_ready = true;
+    return LGC_OK;
+}
 static int party_create(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
-                        size_t max_launch_table_bytes, size_t count, const double *lambdas) {
+                        size_t max_launch_table_bytes, size_t count, const double *lambdas, size_t first) {
     int rc = check_system(sys);
     if (rc) return rc;
     if (!out) return lgc_fail(LGC_EINVAL, "null out");
@@ -110,7 +141,7 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
     if (!max_launch_table_bytes) max_launch_table_bytes = (size_t)256 << 20;
     const uint64_t cap = max_launch_table_bytes / 2048 ? max_launch_table_bytes / 2048 : 1;
     if (lambdas) {
-        rc = build_sweep(p->P, sys, count, lambdas, 0, cap);
+        rc = build_sweep(p->P, sys, count, lambdas, first, cap);
         if (rc) { delete p; return rc; }
     } else {
         build(p->P, sys, cap);

@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "baseot.h"
 #include "protocol.h"
@@ -26,6 +27,21 @@ typedef struct { size_t n, next; const uint32_t *launch; double *time; double t0
 static void note_launch(size_t i, void *ctx) {
     iter_marks *m = ctx;
     while (m->next < m->n && m->launch[m->next] == i) m->time[m->next++] = wall_clock() - m->t0;
+}
+
+/* --devices: one block of the sweep per GPU, one thread and one table link per block */
+enum { kMaxDevices = 16 };
+typedef struct { table_link link; size_t lo, hi; int sending, rc; pthread_t th; } block_job;
+static void *block_main(void *arg) {
+    block_job *b = arg;
+    b->rc = b->sending ? table_link_send_range(&b->link, b->lo, b->hi) : table_link_recv_range(&b->link, b->lo, b->hi, NULL, NULL);
+    return NULL;
+}
+/* contiguous block [lo, hi) of block k out of K; sizes differ by at most one (python/sweep.py: partition) */
+static void block_range(size_t n, size_t K, size_t k, size_t *lo, size_t *hi) {
+    size_t base = n / K, extra = n % K;
+    *lo = k * base + (k < extra ? k : extra);
+    *hi = *lo + base + (k < extra ? 1 : 0);
 }
 
 typedef struct { node *self; int peer, rc; uint8_t delta[16], seeds[128][16]; pthread_t th; } base_ot_job;
@@ -40,6 +56,8 @@ int main(int argc, char **argv) {
     config *c = NULL;
     node *self = NULL;
     lgc_party *party_obj = NULL;
+    lgc_party *blocks[kMaxDevices] = {0};       /* --devices: blocks[0] == party_obj */
+    int devices[kMaxDevices], n_devices = 0;
     int status;
 
     check(argc > 6, "Usage: %s [Input_file] [Precision] [Party] [Algorithm] [Num. iterations CGD] [Lambda] [Options]\n"
@@ -51,7 +69,9 @@ int main(int argc, char **argv) {
           "         --ti_ring: (TI mode) all parties on this node: the vectors of the multiplication protocol stay in HBM\n"
           "         --ot_ring: --use_ot with all data providers on this node: the OT extension's messages stay in HBM\n"
           "         --lambdas=l1,l2,...: regularisation sweep -- one circuit per value on the same shares (the data\n"
-          "                  providers share their inputs once); [Lambda] is then ignored", argv[0]);
+          "                  providers share their inputs once); [Lambda] is then ignored\n"
+          "         --devices=g0,g1,...: (parties 1 and 2, with --lambdas and --table_ring) contiguous blocks of the sweep on\n"
+          "                  these GPUs, one block per entry (an index may repeat); without it LINREG_DEVICE (default 0)", argv[0]);
     char *end;
     errno = 0;
     int precision = (int)strtol(argv[2], &end, 10);
@@ -86,6 +106,18 @@ int main(int argc, char **argv) {
             }
             check(n_lambdas > 0, "--lambdas wants at least one value");
         }
+        else if (!strncmp(argv[i], "--devices=", 10)) {
+            const char *q = argv[i] + 10;
+            while (*q) {
+                char *e2;
+                long v = strtol(q, &e2, 10);
+                check(e2 != q && (*e2 == ',' || !*e2) && v >= 0, "--devices wants a comma-separated list of device indices");
+                check(n_devices < kMaxDevices, "--devices: at most %d entries", kMaxDevices);
+                devices[n_devices++] = (int)v;
+                q = *e2 ? e2 + 1 : e2;
+            }
+            check(n_devices > 0, "--devices wants at least one index");
+        }
         else if (!strcmp(argv[i], "--table_ring")) ring_slots = 8;
         else if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) {}
         else if (sscanf(argv[i], "--table_lanes=%i", &table_lanes) == 1) protocol_set_table_lanes(table_lanes);
@@ -101,6 +133,11 @@ int main(int argc, char **argv) {
     check(precision_phase2 < w2, "Precision of phase 2 must be smaller than bit size of phase 2");
     int num_iterations = !strcmp(algorithm, "cgd") ? atoi(argv[5]) : 0;
     int device = getenv("LINREG_DEVICE") ? atoi(getenv("LINREG_DEVICE")) : 0;
+    if (n_devices) {
+        check(n_lambdas > 0 && ring_slots > 0, "--devices shards a --lambdas sweep and needs --table_ring (CSP and Evaluator on this node)");
+        if ((size_t)n_devices > n_lambdas) n_devices = (int)n_lambdas;       /* no empty blocks */
+        if (party <= 2) device = devices[0];
+    }
 
     status = config_new(&c, argv[1]);
     check(!status, "Could not read config");
@@ -131,6 +168,19 @@ int main(int argc, char **argv) {
     /* table bytes per launch: socket mode moves them through host buffers; ring mode keeps them
      * in HBM (CSP and Evaluator on one node), so launches can be as large as the fused solver's */
     const size_t kTableChunk = ring_slots > 0 ? (size_t)1 << 30 : (size_t)64 << 20;
+    /* the phase-2 object(s) of party 1 / 2: one, or with --devices one block of the sweep per entry (same seed: one set of
+     * input labels, one label OT per data provider; block k starts at circuit lo_k, which keeps its gate ids disjoint) */
+#define CREATE_PARTY(role, seedp) do {                                                                                          \
+        if (n_devices) {                                                                                                      \
+            for (int k_ = 0; k_ < n_devices; k_++) {                                                                          \
+                size_t lo_, hi_;                                                                                              \
+                block_range(n_lambdas, (size_t)n_devices, (size_t)k_, &lo_, &hi_);                                            \
+                LGC(lgc_party_create_sweep_at(&blocks[k_], devices[k_], &sys, role, seedp, kTableChunk, hi_ - lo_, lambdas + lo_, lo_)); \
+            }                                                                                                                 \
+            party_obj = blocks[0];                                                                                            \
+        } else if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, role, seedp, kTableChunk, n_lambdas, lambdas)); \
+        else LGC(lgc_party_create(&party_obj, device, &sys, role, seedp, kTableChunk));                                       \
+    } while (0)
 
     if (party == 1) {
         if (!use_ot) {
@@ -139,8 +189,7 @@ int main(int argc, char **argv) {
         } else {                                                     /* OT mode: the CSP is idle in phase 1 as well */
             uint8_t seed[16];
             check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
-            if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk, n_lambdas, lambdas));
-            else LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk));
+            CREATE_PARTY(LGC_ROLE_GARBLER, seed);
             TRACE("garbler created");
         }
     } else if (party > 2) {
@@ -150,8 +199,7 @@ int main(int argc, char **argv) {
     } else {
         /* The Evaluator has no part in phase 1: it brings up its GPU context, program and buffers while the data
          * providers work, instead of after the barrier with the CSP waiting for it (0.3 s of a 0.9 s config-3 run). */
-        if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, LGC_ROLE_EVALUATOR, NULL, kTableChunk, n_lambdas, lambdas));
-        else LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_EVALUATOR, NULL, kTableChunk));
+        CREATE_PARTY(LGC_ROLE_EVALUATOR, NULL);
         TRACE("evaluator created");
     }
     TRACE("phase 1 done");
@@ -165,8 +213,7 @@ int main(int argc, char **argv) {
         if (!party_obj) {                                            /* TI mode: this process was the initializer until now */
             uint8_t seed[16];
             check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
-            if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk, n_lambdas, lambdas));
-            else LGC(lgc_party_create(&party_obj, device, &sys, LGC_ROLE_GARBLER, seed, kTableChunk));
+            CREATE_PARTY(LGC_ROLE_GARBLER, seed);
             TRACE("garbler created");
         }
         size_t bits = lgc_party_input_bits(party_obj);
@@ -198,6 +245,37 @@ int main(int argc, char **argv) {
         lgc_host_free(m0); lgc_host_free(m1); lgc_host_free(u); lgc_host_free(e);
         free(jobs);
         TRACE("input labels sent");
+        if (n_devices) {
+            /* one table link (hipIpc ring + token connection) and one thread per block.  Block 0 garbles the shared prefix
+             * first; its share sums go to the other GPUs over xGMI; then all blocks run side by side */
+            int fds[kMaxDevices];
+            block_job jb[kMaxDevices];
+            memset(jb, 0, sizeof jb);
+            check(!net_lanes_offer(self, 2, n_devices, fds), "could not open %d token connections to the Evaluator", n_devices);
+            const size_t pre = lgc_party_prefix_launches(blocks[0]);
+            for (int k = 0; k < n_devices; k++)
+                check(!table_link_open(&jb[k].link, self, 2, fds[k], blocks[k], 1, ring_slots, k ? pre : 0), "could not open table link %d", k);
+            check(!table_link_send_range(&jb[0].link, 0, pre), "could not stream the prefix tables");
+            for (int k = 1; k < n_devices; k++) LGC(lgc_party_share_prefix(blocks[k], blocks[0]));
+            TRACE("prefix garbled and shared");
+            for (int k = 0; k < n_devices; k++) {
+                jb[k].lo = pre; jb[k].hi = lgc_party_num_launches(blocks[k]); jb[k].sending = 1;
+                check(!pthread_create(&jb[k].th, NULL, block_main, &jb[k]), "could not start a block thread");
+            }
+            int bad = 0;
+            for (int k = 0; k < n_devices; k++) { pthread_join(jb[k].th, NULL); bad |= jb[k].rc; }
+            check(!bad, "could not stream the garbled tables");
+            TRACE("tables sent");
+            for (int k = 0; k < n_devices; k++) {
+                size_t nr = lgc_party_num_reveal(blocks[k]);
+                uint64_t *dec = malloc((nr + 1) * 8);
+                LGC(lgc_party_decode_bits(blocks[k], dec));
+                check(!send_blob(self, 2, dec, nr * 8), "could not send decode bits");
+                free(dec);
+            }
+            for (int k = 0; k < n_devices; k++) close(fds[k]);
+            goto done;
+        }
         check(!tables_send(self, 2, party_obj, ring_slots, kTableChunk), "could not stream the garbled tables");
         TRACE("tables sent");
         size_t nr = lgc_party_num_reveal(party_obj);
@@ -227,19 +305,53 @@ int main(int argc, char **argv) {
         double *mark_time = malloc((n_marks + 1) * sizeof *mark_time);
         if (n_marks) LGC(lgc_party_iteration_marks(party_obj, mark_launch, mark_gates, n_marks));
         iter_marks marks = {n_marks, 0, mark_launch, mark_time, time_start};
-        check(!tables_recv(self, 1, party_obj, ring_slots, kTableChunk, note_launch, &marks), "could not receive garbled tables");
-        TRACE("tables evaluated");
-        size_t nr = lgc_party_num_reveal(party_obj);
-        uint64_t *dec = malloc((nr + 1) * 8);
-        check(!recv_blob(self, 1, dec, nr * 8), "could not receive decode bits");
         int64_t *beta = malloc((n_lambdas ? n_lambdas : 1) * d * 8), *ab = malloc((T + d) * 8),
                 *trace = malloc(((size_t)num_iterations * (d + 4) + 1) * 8);
-        LGC(lgc_party_finish(party_obj, dec, beta, n_lambdas ? NULL : trace, n_lambdas ? NULL : ab));
-        free(dec);
+        unsigned long long total_gates = 0;
+        if (n_devices) {                                          /* the CSP's counterpart, block by block */
+            int fds[kMaxDevices], got = 0;
+            block_job jb[kMaxDevices];
+            memset(jb, 0, sizeof jb);
+            check(!net_lanes_accept_offer(self, 1, kMaxDevices, &got, fds) && got == n_devices, "the CSP offered %d table links, expected %d (same --devices on both?)", got, n_devices);
+            const size_t pre = lgc_party_prefix_launches(blocks[0]);
+            for (int k = 0; k < n_devices; k++)
+                check(!table_link_open(&jb[k].link, self, 1, fds[k], blocks[k], 0, ring_slots, k ? pre : 0), "could not open table link %d", k);
+            check(!table_link_recv_range(&jb[0].link, 0, pre, NULL, NULL), "could not evaluate the prefix");
+            for (int k = 1; k < n_devices; k++) LGC(lgc_party_share_prefix(blocks[k], blocks[0]));
+            TRACE("prefix evaluated and shared");
+            for (int k = 0; k < n_devices; k++) {
+                jb[k].lo = pre; jb[k].hi = lgc_party_num_launches(blocks[k]); jb[k].sending = 0;
+                check(!pthread_create(&jb[k].th, NULL, block_main, &jb[k]), "could not start a block thread");
+            }
+            int bad = 0;
+            for (int k = 0; k < n_devices; k++) { pthread_join(jb[k].th, NULL); bad |= jb[k].rc; }
+            check(!bad, "could not receive garbled tables");
+            TRACE("tables evaluated");
+            for (int k = 0; k < n_devices; k++) {
+                size_t lo, hi, nr = lgc_party_num_reveal(blocks[k]);
+                block_range(n_lambdas, (size_t)n_devices, (size_t)k, &lo, &hi);
+                uint64_t *dec = malloc((nr + 1) * 8);
+                check(!recv_blob(self, 1, dec, nr * 8), "could not receive decode bits");
+                LGC(lgc_party_finish(blocks[k], dec, beta + lo * d, NULL, NULL));
+                free(dec);
+                /* every block's program holds the prefix; it was garbled once */
+                total_gates += lgc_party_and_gates(blocks[k]) - (k ? lgc_party_prefix_and_gates(blocks[k]) : 0);
+                close(fds[k]);
+            }
+        } else {
+            check(!tables_recv(self, 1, party_obj, ring_slots, kTableChunk, note_launch, &marks), "could not receive garbled tables");
+            TRACE("tables evaluated");
+            size_t nr = lgc_party_num_reveal(party_obj);
+            uint64_t *dec = malloc((nr + 1) * 8);
+            check(!recv_blob(self, 1, dec, nr * 8), "could not receive decode bits");
+            LGC(lgc_party_finish(party_obj, dec, beta, n_lambdas ? NULL : trace, n_lambdas ? NULL : ab));
+            free(dec);
+            total_gates = lgc_party_and_gates(party_obj);
+        }
         if (n_lambdas) {                                         /* sweep: one Result line per lambda, in order */
             printf("Time taken for OT: %f\nOT time: %f\n", t_ot, t_ot);
             printf("Time elapsed: %f\n", wall_clock() - time);
-            printf("Number of gates: %lld\n", (long long)lgc_party_and_gates(party_obj));
+            printf("Number of gates: %llu\n", total_gates);
             for (size_t t = 0; t < n_lambdas; t++) {
                 printf("Lambda: %.17g\nResult: ", lambdas[t]);
                 for (size_t i = 0; i < d; i++) printf("%20.15f ", fixed_to_double(beta[t * d + i], precision));
@@ -303,6 +415,7 @@ int main(int argc, char **argv) {
     }
 
 done:
+    for (int k = 1; k < n_devices; k++) if (blocks[k]) lgc_party_destroy(blocks[k]);
     if (party_obj) lgc_party_destroy(party_obj);
     node_destroy(&self);
     config_destroy(&c);
@@ -311,6 +424,7 @@ done:
     free(lambdas);
     return 0;
 error:
+    for (int k = 1; k < n_devices; k++) if (blocks[k]) lgc_party_destroy(blocks[k]);
     if (party_obj) lgc_party_destroy(party_obj);
     config_destroy(&c);
     node_destroy(&self);

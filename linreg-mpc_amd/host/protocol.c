@@ -300,23 +300,59 @@ static void table_pipe_stop(table_pipe *t, pthread_t *th) {
     }
 }
 
+/* ---- ring mode as a link: one (garbler block, evaluator block) pair, its hipIpc ring, and the byte channel that carries
+ * the 80-byte hello and the one-byte ready / ack tokens -- the party connection (fd < 0), or a connection of its own
+ * when several blocks of a sweep run side by side on several GPUs (bin/linreg --devices: one link and one thread per
+ * device).  A link handles the launches [start, end) of its party object, in any number of consecutive ranges. */
+static int link_io(table_link *l, void *buf, size_t n, int wr) {
+    if (l->fd < 0) return wr ? send_blob(l->self, l->peer, buf, n) : recv_blob(l->self, l->peer, buf, n);
+    return net_io_all(l->fd, buf, n, wr);
+}
+int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, int sending, int ring_slots, size_t start) {
+    memset(l, 0, sizeof *l);
+    l->self = self; l->peer = peer; l->fd = fd; l->po = po; l->start = start; l->end = lgc_party_num_launches(po);
+    ring_hello h;
+    memset(&h, 0, sizeof h);
+    if (sending) {
+        size_t sb = 0;
+        TCHK(lgc_party_ring_create(po, ring_slots, h.handle, &sb));
+        h.nslots = (uint64_t)ring_slots; h.slot_bytes = sb;
+        if (link_io(l, &h, sizeof h, 1)) return 1;
+    } else {
+        if (link_io(l, &h, sizeof h, 0)) return 1;
+        TCHK(lgc_party_ring_open(po, h.handle, (int)h.nslots, (size_t)h.slot_bytes));
+    }
+    l->nslots = (size_t)h.nslots;
+    return 0;
+}
+/* garbler: launches [lo, hi); launch i reuses the slot of launch i - nslots and waits for its ack */
+int table_link_send_range(table_link *l, size_t lo, size_t hi) {
+    uint8_t tok = 0;
+    for (size_t i = lo; i < hi; i++) {
+        if (i - l->start >= l->nslots && link_io(l, &tok, 1, 0)) return 1;      /* slot is free again */
+        TCHK(lgc_party_garble_ring(l->po, i));
+        tok = 1;
+        if (link_io(l, &tok, 1, 1)) return 1;
+    }
+    return 0;
+}
+int table_link_recv_range(table_link *l, size_t lo, size_t hi, void (*after_launch)(size_t launch, void *ctx), void *ctx) {
+    uint8_t tok = 0;
+    for (size_t i = lo; i < hi; i++) {
+        if (link_io(l, &tok, 1, 0)) return 1;                                   /* launch i is in its slot */
+        TCHK(lgc_party_evaluate_ring(l->po, i));
+        if (after_launch) after_launch(i, ctx);
+        if (i + l->nslots < l->end && link_io(l, &tok, 1, 1)) return 1;
+    }
+    return 0;
+}
+
 int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk) {
     const size_t nl = lgc_party_num_launches(po);
     if (ring_slots > 0) {
-        ring_hello h;
-        size_t sb = 0;
-        memset(&h, 0, sizeof h);
-        TCHK(lgc_party_ring_create(po, ring_slots, h.handle, &sb));
-        h.nslots = (uint64_t)ring_slots; h.slot_bytes = sb;
-        if (send_blob(self, peer, &h, sizeof h)) return 1;
-        uint8_t tok = 0;
-        for (size_t i = 0; i < nl; i++) {
-            if (i >= (size_t)ring_slots && recv_blob(self, peer, &tok, 1)) return 1;   /* slot is free again */
-            TCHK(lgc_party_garble_ring(po, i));
-            tok = 1;
-            if (send_blob(self, peer, &tok, 1)) return 1;
-        }
-        return 0;
+        table_link l;
+        if (table_link_open(&l, self, peer, -1, po, 1, ring_slots, 0)) return 1;
+        return table_link_send_range(&l, 0, nl);
     }
     /* socket mode: launch i + 1 is garbled and copied out while launch i is on the wire */
     table_pipe tp;
@@ -342,17 +378,9 @@ int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
                 void (*after_launch)(size_t launch, void *ctx), void *ctx) {
     const size_t nl = lgc_party_num_launches(po);
     if (ring_slots > 0) {
-        ring_hello h;
-        if (recv_blob(self, peer, &h, sizeof h)) return 1;
-        TCHK(lgc_party_ring_open(po, h.handle, (int)h.nslots, (size_t)h.slot_bytes));
-        uint8_t tok = 0;
-        for (size_t i = 0; i < nl; i++) {
-            if (recv_blob(self, peer, &tok, 1)) return 1;                               /* launch i is in its slot */
-            TCHK(lgc_party_evaluate_ring(po, i));
-            if (after_launch) after_launch(i, ctx);
-            if (i + (size_t)h.nslots < nl && send_blob(self, peer, &tok, 1)) return 1;
-        }
-        return 0;
+        table_link l;
+        if (table_link_open(&l, self, peer, -1, po, 0, ring_slots, 0)) return 1;
+        return table_link_recv_range(&l, 0, nl, after_launch, ctx);
     }
     /* socket mode: launch i + 1 is read from the socket while launch i is copied in and evaluated */
     table_pipe tp;

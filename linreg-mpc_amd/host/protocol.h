@@ -37,6 +37,11 @@ void protocol_set_table_lanes(int k);   /* --table_lanes=K: socket-mode table st
 int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk);
 int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk,
                 void (*after_launch)(size_t launch, void *ctx), void *ctx);
+/* ring mode in pieces, for several blocks of a sweep side by side (bin/linreg --devices): see protocol.c */
+typedef struct { node *self; int peer, fd; lgc_party *po; size_t start, end, nslots; } table_link;
+int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, int sending, int ring_slots, size_t start);
+int table_link_send_range(table_link *l, size_t lo, size_t hi);
+int table_link_recv_range(table_link *l, size_t lo, size_t hi, void (*after_launch)(size_t launch, void *ctx), void *ctx);
 int run_trusted_initializer(node *self, config *c, int w1, int device);
 int run_party(node *self, config *c, int precision, int precision_p2, int w1, int w2, int use_ot, int device,
               uint64_t **res_A, uint64_t **res_b);

@@ -97,12 +97,18 @@ def shared_prefix_sweep(shares, lambdas, d, make_solver, dist=None, tensor_devic
     shares: (nshares, T + d) uint64, needed on rank 0 only (the other ranks receive the garbled
     prefix, not the inputs).  make_solver(block_of_lambdas, first_index, seed16) returns an object with
     set_shares / prefix_bytes / prefix_garble / prefix_export(ptr) / prefix_import(ptr) / run / beta /
-    close (linreg_gc.Solver).  Returns the (len(lambdas), d) int64 results on every rank."""
+    close (linreg_gc.Solver).  Returns the (len(lambdas), d) int64 results on every rank.
+    stats (dict, optional) receives this rank's wall-clock per phase: create_s (program + device memory, all ranks at
+    once), prefix_garble_s (rank 0: garble + export; the other ranks have their solver and receive buffer ready and
+    wait at the broadcast), broadcast_s (the collective as this rank sees it), block_s, gather_s."""
     import os
+    import time
     import torch
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     lo, hi = partition(len(lambdas), world, rank)
+    clock = time.perf_counter
+    t = {}
     # one garbler seed for the whole sweep: the ranks share the prefix, hence R and the input labels
     sd = torch.tensor(list(seed if seed is not None else os.urandom(16)), dtype=torch.uint8)
     if dist is not None:
@@ -110,36 +116,53 @@ def shared_prefix_sweep(shares, lambdas, d, make_solver, dist=None, tensor_devic
             sd = sd.to(tensor_device)
         dist.broadcast(sd, src=0)
     seed16 = bytes(sd.cpu().tolist())
+    t0 = clock()
     solver = make_solver(list(lambdas[lo:hi]), lo, seed16) if hi > lo else None
-    nb = torch.tensor([solver.prefix_bytes() if rank == 0 else 0], dtype=torch.int64)
-    if dist is not None:
+    # the size of the prefix is a function of the program alone: every rank with a block knows it without a message;
+    # a rank without one (more ranks than lambdas) builds no solver and takes no part in the broadcast's payload
+    use_bcast = world > 1 or (dist is not None and os.environ.get("LGC_BENCH_FORCE_DIST") == "1")   # one-rank hardware check
+    nb = torch.tensor([solver.prefix_bytes() if solver is not None else 0], dtype=torch.int64)
+    if dist is not None and world > len(lambdas):
         if dist.get_backend() == "nccl":
             nb = nb.to(tensor_device)
-        dist.broadcast(nb, src=0)
+        dist.all_reduce(nb, op=dist.ReduceOp.MAX)
     nbytes = int(nb.item())
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=tensor_device) if use_bcast else None
+    t["create_s"] = clock() - t0
+    t0 = clock()
     if rank == 0:
         solver.set_shares(shares)
         solver.prefix_garble()
-    if world > 1 or (dist is not None and os.environ.get("LGC_BENCH_FORCE_DIST") == "1"):   # one-rank hardware check of the collective
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=tensor_device)
-        if rank == 0:
+        if use_bcast:
             solver.prefix_export(buf.data_ptr())
+    t["prefix_garble_s"] = clock() - t0
+    t0 = clock()
+    if use_bcast:
         _bcast_bytes(buf, dist)
+        if buf.is_cuda:
+            torch.cuda.synchronize()
         if solver is not None and rank != 0:
             solver.prefix_import(buf.data_ptr())
         del buf
+    t["broadcast_s"] = clock() - t0
     per = (len(lambdas) + world - 1) // world
     mine = np.zeros((per, d), dtype=np.int64)
+    t0 = clock()
     if solver is not None:
         solver.run()
         mine[:hi - lo] = solver.beta()
         if stats is not None:
             stats.update(solver.stats())
         solver.close()
+    t["block_s"] = clock() - t0
     if stats is not None:
         stats["prefix_bytes"] = nbytes
     if dist is None:
+        t["gather_s"] = 0.0
+        if stats is not None:
+            stats.update(t)
         return mine[:hi - lo]
+    t0 = clock()
     out = torch.from_numpy(mine)
     if dist.get_backend() == "nccl":
         out = out.to(tensor_device)
@@ -149,4 +172,7 @@ def shared_prefix_sweep(shares, lambdas, d, make_solver, dist=None, tensor_devic
     for r in range(world):
         rlo, rhi = partition(len(lambdas), world, r)
         res[rlo:rhi] = outs[r].cpu().numpy()[:rhi - rlo]
+    t["gather_s"] = clock() - t0
+    if stats is not None:
+        stats.update(t)
     return res

@@ -24,16 +24,23 @@ def _free_port():
 
 def test_bench_two_ranks_share_one_gpu(tmp_path, oracle):
     env = dict(os.environ, LGC_BENCH_BACKEND="gloo", LGC_BENCH_DUMP=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # plain `python bench.py --gpus 2`, no launcher: bench.py starts its own ranks (what a driver without torchrun gets)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
            "--dimension", "24", "--iters", "2", "--sweep-d", "6", "--sweep-iters", "3", "--sweep-lambdas", "5",
            "--no-cpu-baseline", "--no-traffic", "--no-e2e"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["barrier_backend"] == "gloo"
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["n_gpus"] == out["rccl_ranks"] or out["barrier_backend"] == "gloo"
+    assert out["rccl_ranks"] is None and len(out["devices"]) == 1           # two ranks, one GPU, no RCCL group: said so
     sw = out["sweep64"]
+    for k in ("create_s", "prefix_garble_s", "broadcast_s", "block_s", "gather_s"):
+        assert sw[k] >= 0.0
+    assert sw["block_s"] > 0.0 and sw["prefix_garble_s"] > 0.0
     assert sw["n_gpus"] == 2 and sw["lambdas"] == 5 and sw["prefix_bytes_broadcast"] > 0 and "broadcast" in sw["collectives"]
     dumps = [json.load(open(os.path.join(str(tmp_path), "sweep_rank%d.json" % k))) for k in (0, 1)]
     assert dumps[0]["beta"] == dumps[1]["beta"]                      # every rank holds the gathered results
@@ -45,6 +52,34 @@ def test_bench_two_ranks_share_one_gpu(tmp_path, oracle):
     for k, lam in enumerate(d0["lambdas"]):                          # rank 0 ran 0..2, rank 1 ran 3..4 from the broadcast prefix
         exp, _, _ = oracle_solve(oracle, tot[:T], tot[T:], d, w, p, "cgd", iters, lam, 1)
         assert [int(v) for v in exp] == d0["beta"][k], (k, lam)
+
+
+def test_bench_launcher_and_self_launch_agree(tmp_path):
+    """the torch.distributed.run form the driver documents still works (WORLD_SIZE set: no second level of children)"""
+    env = dict(os.environ, LGC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--dimension", "12", "--iters", "1", "--no-sweep", "--no-cpu-baseline", "--no-traffic", "--no-e2e"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["barrier_backend"] == "gloo" and out["rccl_ranks"] is None
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """--gpus 2 over RCCL on a one-GPU box cannot work (two ranks, one device): the launcher must say so with a non-zero
+    exit code instead of printing a one-rank line"""
+    import linreg_gc
+    if linreg_gc.device_count() >= 2:
+        pytest.skip("this box has two GPUs: the run would succeed")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LGC_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dimension", "12",
+           "--iters", "1", "--no-sweep", "--no-cpu-baseline", "--no-traffic", "--no-e2e"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{") and '"n_gpus": 1' in l]
 
 
 def test_bench_collectives_through_rccl_one_rank(tmp_path, oracle):
@@ -61,6 +96,7 @@ def test_bench_collectives_through_rccl_one_rank(tmp_path, oracle):
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["barrier_backend"] == "nccl"
+    assert out["rccl_ranks"] == 1 and len(out["devices"]) == 1
     d0 = json.load(open(os.path.join(str(tmp_path), "sweep_rank0.json")))
     d, w, p, iters = d0["d"], d0["width"], d0["precision"], d0["iters"]
     tot = np.array(d0["shares"], dtype=np.uint64).sum(axis=0, dtype=np.uint64)

@@ -321,6 +321,40 @@ def test_five_process_lambda_sweep(tmp_path, golden_dir, oracle, extra):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devs", ["0,0", "0,0,0", "0,1"], ids=["two-blocks-one-gpu", "three-blocks-one-gpu", "two-gpus"])
+def test_five_process_lambda_sweep_on_several_devices(tmp_path, golden_dir, oracle, devs):
+    """bin/linreg ... --lambdas=... --devices=g0,g1,... --table_ring: CSP and Evaluator each hold one block of the sweep
+    per entry (one party object, one hipIpc ring, one thread each); block 0 garbles / evaluates the shared prefix and the
+    other blocks take its share sums from device memory.  Host code is C, no torch.  Every Result line equals the
+    oracle's single-lambda run, the stdout contract (Lambda: / Result: per value, in order) is the single-device one and
+    the gate count is the one-program count (the prefix counted once).  "0,1" needs two GPUs (src/cmd/linreg.c:145-199
+    runs one execYaoProtocol per circuit; src/linear.oc:31,52-57: lambda enters after the share sums)."""
+    import linreg_gc
+    if "1" in devs and linreg_gc.device_count() < 2:
+        pytest.skip("needs two visible GPUs (the driver's multi-GPU node; one-GPU boxes skip)")
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    src = os.path.join(golden_dir, "readme_example.in")
+    infile = str(tmp_path / "readme.in")
+    P = _rewrite_ports(src, infile)
+    lams = [0.001, 0.0, 0.25, 1e-6, 0.5]
+    lam_opt = "--lambdas=" + ",".join(repr(l) for l in lams)
+    outs = _run_all(infile, P, ["56", "cgd", "10", "123", lam_opt, "--table_ring", "--devices=" + devs])
+    ev = outs[1].strip().splitlines()
+    got = [(float(ev[i].split()[1]), re.findall("-?[0-9]+\\.[0-9]+", ev[i + 1])) for i in range(len(ev) - 1)
+           if ev[i].startswith("Lambda:") and ev[i + 1].startswith("Result:")]
+    assert [g[0] for g in got] == lams
+    assert got[0][1] == README_RESULT
+    for lam, res in got:
+        beta = oracle.linreg_file(src, 56, -1, 64, 64, 2, 10, lam)
+        assert res == ["%.15f" % (int(b) / 2.0 ** 56) for b in beta], lam
+    gates = int(re.search("Number of gates: ([0-9]+)", outs[1]).group(1))
+    one = _run_all(infile, P, ["56", "cgd", "10", "123", lam_opt, "--table_ring"])
+    assert gates == int(re.search("Number of gates: ([0-9]+)", one[1]).group(1))
+    for k in range(2, P + 2):                                          # the data providers ran exactly as in a single-lambda run
+        assert "connected successfully to CSP and Evaluator" in outs[k]
+
+
+@pytest.mark.gpu
 def test_network_accounting_matches_profile_network(tmp_path):
     """-DPROFILE_NETWORK parity (experiments/test_phase1_aws.py:61, 245-252).  The published run
     experiments/results/phase1_network/test_LR_1000000x100_2_0_p{1..4}.out reads, per peer in party order,
