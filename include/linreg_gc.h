@@ -352,6 +352,12 @@ void lgc_release_cached_memory(void);
  * effect at the next launch.  Exists for A/B timing and for the interchangeability test. */
 void lgc_set_split_kernels(int garbler, int evaluator);
 
+/* The matrix-vector products of CGD at width 64 (src/cgd.oc:119-125, 96 % of the gates of a d = 500 solve) use a
+ * Karatsuba multiplier -- three 32 x 32 arrays per product, 110 gate steps against 129 -- by default; 0 selects the
+ * plain 64 x 64 array everywhere.  Same integers either way.  Process-wide, takes effect for programs built
+ * afterwards; the two roles of one solve must agree (as on every other parameter of the program). */
+void lgc_set_karatsuba(int on);
+
 /* Test hooks (tests/test_gpu_roles.py; not part of the drop-in surface).  lgc_test_party_garble_ring_stage
  * issues launch k as lgc_party_garble_ring does, in halves: stage 1 = the record kernel (stops before the table
  * pass of a critical-path launch; *is_critical_path tells whether the launch has one), stage 2 = the table pass.

@@ -247,6 +247,136 @@ struct Circ {
         AC = shl2(be, carry, 1);
     }
 
+    // ---- Karatsuba multiply-accumulate, w = 64 (the matrix-vector products of cgd.oc:119-125: 96 % of the gates of
+    // a d = 500 solve).  With the operands read as unsigned words A = A1 2^32 + A0, B = B1 2^32 + B0,
+    //     a b = A B - 2^64 (sa B + sb A)                       (mod 2^128; sa, sb: the sign bits)
+    //     A B = Lo + 2^32 (H + Lo - DA DB) + 2^64 H,           Lo = A0 B0, H = A1 B1, DA = A1 - A0, DB = B1 - B0
+    // so one product costs three unsigned 32 x 32 arrays -- Lo, H and DQ = |DA| |DB| -- instead of one 64 x 64 array.
+    // A 32 x 32 array fills half a wave: TWO products run side by side (product k in lanes 0..31, product k' in lanes
+    // 32..63 of every packed word), 3 x 63 gate steps per pair.  |DA| and the sign of DA do not depend on the other
+    // operand: they are computed once per word (hdiff: once per solve for the matrix, once per iteration for the vector)
+    // and stored `delta` words above the operand.  The sub-products arrive as L + 2^32 (S + C) (low half resolved,
+    // high half carry-save); everything is then added in carry-save form:
+    //     LOW  (bits 32..63, both products packed): S0 + C0 + L0 + L1 +- L2                    3 steps per pair
+    //     HIGH (bits 64..64+p-1, per product): L1|S1, S0|C1, C0, S1, C1, +-S2, +-C2 and the two sign corrections
+    //          -(sa & B), -(sb & A) (2 steps to form them)                                      7 steps per product
+    //     the carry into bit p out of the dropped bits 32..p-1 (only L0 lives below bit 32)     10 steps per pair
+    //     (AS, AC) += bits p..p+63                                                              2 steps per product
+    // Negated operands enter complemented over a lane mask that reaches the top of the range, +1 at their lowest lane:
+    // a CSA step has a free slot in lane 0 of its shifted carry word, and there are exactly as many slots as corrections
+    // (LOW: n; HIGH: the three carries out of LOW, n, n, ~n, 1).  224 steps per pair against 2 x 129.
+    static GC_HD W half_lo(B &be, W x, int h) { return h ? be.shr(x, 32) : be.sel(lanes(32), x, be.zero()); }
+    static GC_HD W half_hi(B &be, W x, int h) { return h ? be.sel(~lanes(32), x, be.zero()) : be.shl(x, 32); }
+    // two independent unsigned 32 x 32 products per wave: value = L + 2^32 (S + C) in each half
+    static GC_HD void umul32x2(B &be, W a, W b, W &L, W &S, W &C) {
+        const uint64_t all = ~0ull;
+        S = be.zero(); L = be.zero(); C = be.zero();
+        for (int r = 0; r < 32; r++) {
+            W pp = be.AND(a, be.bcast2(b, r), all);
+            if (r == 0) {
+                S = pp;
+            } else {
+                W t = be.AND(be.XOR(S, pp), be.XOR(C, pp), all);
+                W Sn = be.XOR(be.XOR(S, C), pp);
+                C = be.XOR(t, pp);
+                S = Sn;
+            }
+            L = be.sel(m2(1ull << r), be.bcast2(S, 0), L);
+            S = shr2(be, S, 1);
+        }
+    }
+    // carry-save step on both halves: carries stay inside their half; cin (lanes 0 / 32 only) joins the new carry word;
+    // cout: the carries out of lanes 31 / 63, delivered in lanes 0 / 32
+    // carry-save steps of the recombination: the gate goes through B::AND_ool, which a GPU backend may keep out of line
+    // (one copy of the AES body instead of one per call site; the array rows stay inlined)
+    static GC_HD void csa_ool(B &be, W &S, W &C, W X, int n, W cin_lane0) {
+        const uint64_t act = lanes(n);
+        W t = be.AND_ool(be.XOR(S, X), be.XOR(C, X), act);
+        W carry = be.XOR(t, be.sel(act, X, be.zero()));
+        S = be.XOR(be.XOR(S, C), X);
+        C = be.XOR(be.sel(act, be.shl(carry, 1), be.zero()), cin_lane0);
+    }
+    static GC_HD void csa2(B &be, W &S, W &C, W X, W cin, W *cout) {
+        W t = be.AND_ool(be.XOR(S, X), be.XOR(C, X), ~0ull);
+        W carry = be.XOR(t, X);
+        S = be.XOR(be.XOR(S, C), X);
+        if (cout) *cout = shr2(be, carry, 31);
+        C = be.XOR(shl2(be, carry, 1), cin);
+    }
+    // carry out of lanes [0, nb) of x + y in each half, delivered in lanes 0 / 32.  Only the carry OUT is wanted, so
+    // the (generate, propagate) pairs are combined in a tree anchored at lane nb - 1 instead of a full prefix network: at
+    // distance `dist` the node at lane l = nb - 1 - 2 m dist absorbs the node at l - dist,
+    //     G_l ^= P_l & G_(l-dist),    P_l = P_l & P_(l-dist),
+    // and the two ANDs of a node share ONE gate step: the first in lane l, the second in lane l - dist, whose own
+    // node has just been consumed.  1 + ceil(log2 nb) steps (Kogge-Stone: 2 log2 nb).
+    static GC_HD W carry2(B &be, W x, W y, int nb) {
+        if (nb <= 0) return be.zero();
+        W G = be.AND_ool(x, y, m2(lanes(nb))), Pg = be.XOR(x, y);
+        for (int dist = 1; dist < nb; dist <<= 1) {
+            uint64_t mA = 0, mB = 0;
+            for (int l = nb - 1; l - dist >= 0; l -= 2 * dist) { mA |= 1ull << l; mB |= 1ull << (l - dist); }
+            W Xo = be.sel(m2(mA), Pg, shr2(be, Pg, dist));
+            W Yo = be.sel(m2(mA), shl2(be, G, dist), Pg);
+            W T = be.AND_ool(Xo, Yo, m2(mA | mB));
+            G = be.XOR(G, be.sel(m2(mA), T, be.zero()));
+            Pg = be.sel(m2(mA), shl2(be, T, dist), Pg);
+        }
+        return be.sel(m2(1ull), shr2(be, G, nb - 1), be.zero());
+    }
+    // |A1 - A0| in lanes 0..31, [A1 < A0] in lane 32
+    static GC_HD W hdiff(B &be, W a) {
+        W x = be.shr(a, 32), y = be.sel(lanes(32), a, be.zero()), ge;
+        W d = sub(be, x, y, 32, &ge);
+        W neg = be.NOTm(ge, ~0ull);
+        W m = condneg(be, d, neg, 32);
+        return be.XOR(be.sel(lanes(32), m, be.zero()), be.sel(1ull << 32, neg, be.zero()));
+    }
+    // (AS, AC) += wrap_64((a b) >> p) + wrap_64((a' b') >> p), carry-save.  a0 / a1, b0 / b1: the operand words of the two
+    // products; hdiff of every operand word lies `delta` words above it.  Operands are loaded where they are used (packed
+    // halves: load2 = lanes 0..31 of both words, load2h = lanes 32..63), so that few labels are live across the arrays.
+    static GC_HD void mack2(B &be, W &AS, W &AC, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t delta, int p) {
+        const uint64_t all = ~0ull;
+        W L0, S0, C0, L1, S1, C1, L2, S2, C2;
+        umul32x2(be, be.load2(a0, a1), be.load2(b0, b1), L0, S0, C0);
+        umul32x2(be, be.load2h(a0, a1), be.load2h(b0, b1), L1, S1, C1);
+        umul32x2(be, be.load2(a0 + delta, a1 + delta), be.load2(b0 + delta, b1 + delta), L2, S2, C2);
+        // DA DB = (-1)^(sA ^ sB) DQ enters Mid with a minus sign: n = 1 where DQ is subtracted
+        W n = be.NOTm(be.bcast2(be.XOR(be.load2h(a0 + delta, a1 + delta), be.load2h(b0 + delta, b1 + delta)), 0), all);
+        // LOW: lane j of a half = bit 32 + j
+        W SL = S0, CL = C0, o1, o2, o3;
+        csa2(be, SL, CL, L1, be.zero(), &o1);
+        csa2(be, SL, CL, L0, be.zero(), &o2);
+        csa2(be, SL, CL, be.XOR(L2, n), be.sel(m2(1ull), n, be.zero()), &o3);
+        W cp = carry2(be, SL, CL, p - 32);
+        const int nh = p;                                  // HIGH: lane i = bit 64 + i, bits below 64 + p matter
+        const uint64_t ah = lanes(nh);
+        for (int h = 0; h < 2; h++) {
+            W SS = be.zero(), CC = be.zero();
+            if (nh > 0) {
+                W nn = be.bcast(n, 32 * h);
+                SS = be.XOR(half_lo(be, L1, h), half_hi(be, S1, h));
+                CC = be.XOR(half_lo(be, S0, h), half_hi(be, C1, h));
+                csa_ool(be, SS, CC, half_lo(be, C0, h), nh, be.sel(1ull, half_lo(be, o1, h), be.zero()));
+                csa_ool(be, SS, CC, half_lo(be, S1, h), nh, be.sel(1ull, half_lo(be, o2, h), be.zero()));
+                csa_ool(be, SS, CC, half_lo(be, C1, h), nh, be.sel(1ull, half_lo(be, o3, h), be.zero()));
+                csa_ool(be, SS, CC, be.sel(ah, be.XOR(half_lo(be, S2, h), nn), be.zero()), nh, be.sel(1ull, nn, be.zero()));
+                csa_ool(be, SS, CC, be.sel(ah, be.XOR(half_lo(be, C2, h), nn), be.zero()), nh, be.sel(1ull, nn, be.zero()));
+                // sign corrections -(sa & B) and -(sb & A), low p bits of the operand words at bit 64
+                W aw = be.load(h ? a1 : a0), bw = be.load(h ? b1 : b0);
+                W c1 = be.NOTm(be.AND_ool(bw, be.bcast(aw, 63), ah), ah);
+                csa_ool(be, SS, CC, c1, nh, be.sel(1ull, be.NOTm(nn, 1ull), be.zero()));
+                W c2 = be.NOTm(be.AND_ool(aw, be.bcast(bw, 63), ah), ah);
+                csa_ool(be, SS, CC, c2, nh, be.sel(1ull, be.konst(1ull), be.zero()));
+                SS = be.sel(ah, SS, be.zero());
+                CC = be.sel(ah, CC, be.zero());
+            }
+            W LS = be.XOR(half_lo(be, L0, h), half_hi(be, SL, h)), LC = half_hi(be, CL, h);
+            W X = be.XOR(be.shr(LS, p), be.shl(SS, 64 - p)), Y = be.XOR(be.shr(LC, p), be.shl(CC, 64 - p));
+            csa_ool(be, AS, AC, X, 64, be.sel(1ull, half_lo(be, cp, h), be.zero()));
+            csa_ool(be, AS, AC, Y, 64, be.zero());
+        }
+    }
+
     // ---- wide inner-product accumulator: sum of exact products mod 2^(w+p)
     struct IpAcc { W LS, LC, HS, HC; };
     static GC_HD void ip_zero(B &be, IpAcc &A) { A.LS = A.LC = A.HS = A.HC = be.zero(); }
@@ -412,6 +542,7 @@ struct PlainBackend {
         gates += (uint64_t)__builtin_popcountll(act);
         return a & b & act;
     }
+    GC_HD W AND_ool(W a, W b, uint64_t act) { return AND(a, b, act); }
     // two independent gate steps (numbered step, step+1) that a backend may run concurrently
     GC_HD void AND2(W a1, W b1, uint64_t act1, W a2, W b2, uint64_t act2, W &c1, W &c2) {
         c1 = AND(a1, b1, act1);

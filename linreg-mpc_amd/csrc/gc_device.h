@@ -313,6 +313,17 @@ struct GpuBackend {
         xsel ^= 1;
         return and_quad(lt, R, a, b, gid, slot, on, wave, xch + xsel * 512, lane);
     }
+    // the gates of the Karatsuba recombination (Circ::mack2): ~17 call sites per product pair.  In the MAC kernel they share
+    // ONE out-of-line copy of the gate body -- inlined, 35 more copies of 4 AES-128 would push the kernel far beyond the
+    // instruction cache -- while the two gates of the array rows (84 % of the steps) stay inlined
+    __device__ __forceinline__ W AND_ool(W a, W b, uint64_t act) {
+        if (MODE != MODE_MAC) return AND(a, b, act);
+        const bool on = bit(act);
+        const uint64_t gid = step * 64 + (uint64_t)lane;
+        Lbl *slot = tab + (step - launch_step0) * 128 + lane;
+        step++;
+        return and_outlined(lt, R, a, b, gid, slot, on);
+    }
     __device__ __forceinline__ void AND2(W a1, W b1, uint64_t act1, W a2, W b2, uint64_t act2, W &c1, W &c2) {
         if (MODE != MODE_QUAD) {
             c1 = AND(a1, b1, act1);
@@ -500,6 +511,9 @@ struct GpuBackend {
     __device__ __forceinline__ W load2(uint32_t lo, uint32_t hi) const {
         return ld_lbl(words + (size_t)(lane < 32 ? lo : hi) * 64 + (lane & 31));
     }
+    __device__ __forceinline__ W load2h(uint32_t lo, uint32_t hi) const {
+        return ld_lbl(words + (size_t)(lane < 32 ? lo : hi) * 64 + 32 + (lane & 31));
+    }
     __device__ __forceinline__ void store2(uint32_t lo, uint32_t hi, W v) {
         if (MODE != MODE_QUAD || wave == 0) st_lbl(words + (size_t)(lane < 32 ? lo : hi) * 64 + (lane & 31), v);
     }
@@ -568,6 +582,18 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
         uint32_t s_hi = __builtin_amdgcn_readfirstlane((uint32_t)(r.step0 >> 32));
         be.step = ((uint64_t)s_hi << 32) | s_lo;
         Lbl S = lzero(), Cc = lzero();
+        if (__builtin_amdgcn_readfirstlane(r.op) == OP_MACK) {
+            const uint32_t delta = __builtin_amdgcn_readfirstlane(r.c);
+            uint32_t k = 0;
+            for (; k + 1 < r.cnt; k += 2) {
+                const uint32_t a0 = r.a + (int32_t)k * r.sa, b0 = r.b + (int32_t)k * r.sb;
+                C::mack2(be, S, Cc, a0, a0 + r.sa, b0, b0 + r.sb, delta, p);
+            }
+            if (k < r.cnt) C::mac(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
+            be.store(r.dst, S);
+            be.store(r.dst + 1, Cc);
+            continue;
+        }
         if (__builtin_amdgcn_readfirstlane(r.op) == OP_MAC2) {
             for (uint32_t k = 0; k < r.cnt; k++)
                 C::mac2(be, S, Cc, be.load2(r.a + (int32_t)k * r.sa, r.a + (int32_t)(r.cnt + k) * r.sa),

@@ -197,8 +197,9 @@ static uint64_t lambda_to_fixed(double lambda, int p, int w) {
     return (uint64_t)(int64_t)t;
 }
 
-static void build(Program &P, const lgc_system *sys, uint64_t cap_steps = 0) {
+static void build(Program &P, const lgc_system *sys, uint64_t cap_steps = 0, size_t merge_hint = 1) {
     if (cap_steps) P.cap_steps = cap_steps;
+    P.merge_hint = merge_hint;
     int iters = sys->algorithm == LGC_ALG_CGD ? sys->num_iterations : 0;
     build_program(P, sys->algorithm, sys->d, sys->width, sys->precision, iters, sys->nshares, sys->normalize,
                   lambda_to_fixed(sys->lambda, sys->precision, sys->width), sys->reveal_inputs, sys->trace);
@@ -225,7 +226,7 @@ static int check_sweep(const lgc_system *sys, size_t count, const double *lambda
 // the merged program of `count` circuits; cap_steps as for build()
 static int build_sweep(Program &P, const lgc_system *sys, size_t count, const double *lambdas, size_t first, uint64_t cap_steps = 0) {
     Program base;
-    build(base, sys, cap_steps);
+    build(base, sys, cap_steps, count);
     if ((uint64_t)base.n_words * count >= (1ull << 31)) return lgc_fail(LGC_EINVAL, "sweep too large: %zu circuits x %u words", count, base.n_words);
     std::vector<uint64_t> lf(count);
     for (size_t t = 0; t < count; t++) lf[t] = lambda_to_fixed(lambdas[t], sys->precision, sys->width);
@@ -778,6 +779,7 @@ extern "C" void *lgc_host_alloc(size_t bytes) {
 }
 extern "C" void lgc_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+extern "C" void lgc_set_karatsuba(int on) { program_karatsuba() = on != 0; }
 extern "C" void lgc_set_split_kernels(int garbler, int evaluator) {
     gc_split_enabled(true).store(garbler != 0);
     gc_split_enabled(false).store(evaluator != 0);

@@ -38,6 +38,9 @@ enum Op : uint32_t {
     OP_REVEAL,  // decode[dst] = colour bits of word a (cnt unused)
     OP_MAC2,    // 32-bit only: two OP_MAC chunks per wave; products k (lanes 0..31) and cnt+k (lanes 32..63);
                 // (S,C) of the first chunk -> dst, dst+1, of the second -> dst+2, dst+3
+    OP_MACK,    // 64-bit only: OP_MAC through the Karatsuba circuit (Circ::mack2), two products at a time; the words
+                // hdiff(x) of both operand vectors lie c words above the operands: (a + k*sa) + c, (b + k*sb) + c
+    OP_HDIFF,   // dst = hdiff(a): |hi32(a) - lo32(a)| and its sign, for OP_MACK
     OP_COUNT_
 };
 
@@ -72,6 +75,20 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
         be.store2(r.dst, r.dst + 2, S);
         be.store2(r.dst + 1, r.dst + 3, Cc);
     } break;
+    case OP_MACK: {
+        W S = be.zero(), Cc = be.zero();
+        uint32_t k = 0;
+        for (; k + 1 < r.cnt; k += 2) {
+            const uint32_t a0 = r.a + (int32_t)k * r.sa, a1 = a0 + r.sa, b0 = r.b + (int32_t)k * r.sb, b1 = b0 + r.sb;
+            C::mack2(be, S, Cc, a0, a1, b0, b1, r.c, p);
+        }
+        if (k < r.cnt) C::mac(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
+        be.store(r.dst, S);
+        be.store(r.dst + 1, Cc);
+    } break;
+    case OP_HDIFF:
+        be.store(r.dst, C::hdiff(be, be.load(r.a)));
+        break;
     case OP_SUM:
     case OP_SUBSUM: {
         W S = be.load(r.a), Cc = be.zero();
@@ -159,6 +176,8 @@ struct PlainMachine : PlainBackend {
     void store(uint32_t id, W v) { words[id] = v; }
     // lanes 0..31 of word lo | lanes 0..31 of word hi moved to lanes 32..63 (and back)
     W load2(uint32_t lo, uint32_t hi) const { return (words[lo] & 0xffffffffull) | (words[hi] << 32); }
+    // lanes 32..63 of word lo in lanes 0..31 | lanes 32..63 of word hi
+    W load2h(uint32_t lo, uint32_t hi) const { return (words[lo] >> 32) | (words[hi] & 0xffffffff00000000ull); }
     void store2(uint32_t lo, uint32_t hi, W v) { words[lo] = v & 0xffffffffull; words[hi] = v >> 32; }
     void reveal(uint32_t slot, W v) { if (decode) decode[slot] = v; }
 };
@@ -169,6 +188,7 @@ inline void rec_cost(const Rec &r, int w, int p, uint64_t &steps, uint64_t &gate
     struct CostMachine : PlainBackend {
         W load(uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
         W load2(uint32_t, uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
+        W load2h(uint32_t, uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
         void store(uint32_t, W) {}
         void store2(uint32_t, uint32_t, W) {}
         void reveal(uint32_t, W) {}

@@ -58,6 +58,8 @@ struct Program {
     uint64_t prefix_steps;
 
     // ---- builder state
+    size_t merge_hint = 1;       // this program will be replicated this many times (replicate_program): the dot products of
+                                 // ONE circuit then need only 1 / merge_hint of the records that fill the chip
     uint64_t cap_steps;          // split launches above this many steps
     uint64_t step_cursor;
     std::map<std::pair<uint32_t, uint32_t>, std::pair<uint64_t, uint64_t>> cost_cache;
@@ -89,7 +91,7 @@ struct Program {
     void emit(Rec r) {
         uint64_t s, g;
         cost(r, s, g);
-        bool mac = (r.op == OP_MAC || r.op == OP_MAC2);
+        bool mac = (r.op == OP_MAC || r.op == OP_MAC2 || r.op == OP_MACK);
         if (!open || launches.back().steps + s > cap_steps || launches.back().mac_only != mac) {
             Launch L;
             L.first_rec = (uint32_t)recs.size();
@@ -149,7 +151,9 @@ struct Program {
 
     // dot products in carry-save form, chunked so that a launch has enough waves.
     // result words: dst[i] = base[i] - sum_k A[i][k]*B[k]  (subtract) or  = sum (no base)
-    struct DotJob { uint32_t dst, base, a, b; uint32_t len; bool has_base; };
+    // kdelta != 0 (64-bit only): the products go through the Karatsuba circuit (OP_MACK); hdiff of every operand
+    // word of the job lies kdelta words above it (the caller has emitted the OP_HDIFF records)
+    struct DotJob { uint32_t dst, base, a, b; uint32_t len; bool has_base; uint32_t kdelta = 0; };
     // MAC records of a batch of dot products for `chunk` products per record (two chunks per record
     // when w == 32); fills the partial-word bookkeeping of every job
     void dots_records(const std::vector<DotJob> &jobs, uint32_t scratch, size_t chunk, std::vector<Rec> &out,
@@ -172,7 +176,8 @@ struct Program {
                     k0 += 2 * len;
                 } else {
                     uint32_t len = left < chunk ? left : (uint32_t)chunk;
-                    out.push_back(mk(OP_MAC, cur, J.a + k0, J.b + k0, 0, len));
+                    if (J.kdelta && w == 64) out.push_back(mk(OP_MACK, cur, J.a + k0, J.b + k0, J.kdelta, len));
+                    else out.push_back(mk(OP_MAC, cur, J.a + k0, J.b + k0, 0, len));
                     cur += 2;
                     nparts += 2;
                     k0 += len;
@@ -289,7 +294,7 @@ struct Program {
     size_t dots_chunk(size_t total, size_t target_waves) {
         size_t chunk = (total + target_waves - 1) / target_waves;
         uint64_t s1, g1;
-        cost(mk(OP_MAC, 0, 0, 0, 0, 1), s1, g1);
+        cost(mk(OP_MAC, 0, 0, 0, 0, 1), s1, g1);      // (an upper bound for OP_MACK records as well)
         size_t by_slot = (size_t)(cap_steps / ((uint64_t)kMinRecsPerLaunch * s1));
         if (chunk > by_slot) chunk = by_slot;
         if (chunk < 1) chunk = 1;
@@ -357,6 +362,10 @@ static const size_t kTargetWaves = 12288;
 //   normalize = 1: data-provider path (linear.oc:52-65): diag += lambda, off-diag and b divided by d
 //   normalize = 0: two-party benchmark path (linear.oc:96-135): a = in1 + in2, nothing else
 //   reveal_ab: debug reveal of a and b (linear.oc:68-84)
+// Karatsuba products in the matrix-vector launches of CGD (64-bit; Circ::mack2).  Process-wide switch for A/B runs
+// (lgc_set_karatsuba); garbler and evaluator must agree, as on everything else that shapes the program.
+inline int &program_karatsuba() { static int on = 1; return on; }
+
 inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters, size_t nshares,
                           int normalize, uint64_t lambda_fixed, int reveal_ab, int trace) {
     P.w = w; P.p = p; P.d = d; P.nshares = nshares;
@@ -419,8 +428,23 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
                        gAp = P.alloc(1);
         const uint32_t sc_max = P.alloc(Program::max_tree_scratch(d));
         const uint32_t sc_ip = P.alloc(2 * Program::inner_scratch(d));
-        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d, d, kTargetWaves));
+        // records per matrix-vector product: enough to fill the chip -- together with the other circuits of a merged sweep
+        size_t mv_waves = kTargetWaves / (P.merge_hint ? P.merge_hint : 1);
+        if (mv_waves < 2 * d) mv_waves = 2 * d < kTargetWaves ? 2 * d : kTargetWaves;     // at least two records per row
+        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d, d, mv_waves));
         if (trace) P.rv_trace = P.alloc_reveal((size_t)iters * (d + 4));
+        // Karatsuba products for A p (w = 64): the words hdiff(M[i][j]) -- once per solve -- and hdiff(p[k]) -- once per
+        // iteration -- live in a shadow of the word range [M, pv + d), kdelta words above their operands
+        uint32_t kdelta = 0;
+        if (w == 64 && iters > 0 && program_karatsuba() && P.dots_chunk(d * d, mv_waves) >= 2) {   // (needs two products per record)
+            kdelta = P.alloc((size_t)(pv + D - M)) - M;
+            for (size_t i = 0; i < d; i++)
+                for (size_t j = 0; j <= i; j++) P.emit(Program::mk(OP_HDIFF, Mi(i, j) + kdelta, Mi(i, j)));
+            P.new_launch();
+            for (size_t i = 0; i < d; i++)
+                for (size_t j = 0; j < i; j++) P.emit(Program::mk(OP_COPY, Mi(j, i) + kdelta, Mi(i, j) + kdelta));
+            P.new_launch();
+        }
         // cgd.oc:96-106
         for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_SUB, g + (uint32_t)i, 0, bv + (uint32_t)i));
         P.new_launch();
@@ -430,12 +454,16 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.new_launch();
         for (int it = 0; it < iters; it++) {
             // pA = A p  (cgd.oc:119-125)
+            if (kdelta) {
+                for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_HDIFF, pv + (uint32_t)i + kdelta, pv + (uint32_t)i));
+                P.new_launch();
+            }
             std::vector<Program::DotJob> jobs(d);
             for (size_t i = 0; i < d; i++) {
-                Program::DotJob J = {pA + (uint32_t)i, 0, Mi(i, 0), pv, D, false};
+                Program::DotJob J = {pA + (uint32_t)i, 0, Mi(i, 0), pv, D, false, kdelta};
                 jobs[i] = J;
             }
-            P.dots(jobs, sc_dot, kTargetWaves);
+            P.dots(jobs, sc_dot, mv_waves);
             {                                        // q = <pA,p> (:128), gp = <g,p> (:130)
                 std::vector<Program::IpJob> ij(2);
                 Program::IpJob j0 = {q, pA, pv}, j1 = {gp, g, pv};
@@ -592,6 +620,30 @@ inline void replicate_program(Program &P, const Program &P0, size_t count, const
             P.prefix_steps = P.total_steps;
             P.step_cursor = P0.prefix_steps + (uint64_t)first_copy * (P0.total_steps - P0.prefix_steps);
         }
+        // a merged launch that exceeds the table cap is cut into EQUAL pieces (a ragged last piece of a MAC launch would
+        // be a launch of a few hundred records: most of the chip idle, or the wrong kernel altogether)
+        const uint64_t cap_keep = P.cap_steps;
+        if (!prefix && L.nrec) {
+            const uint64_t tot = L.steps * (uint64_t)count, pieces = (tot + cap_keep - 1) / cap_keep;
+            uint64_t smax = 0;
+            for (uint32_t k = 0; k < L.nrec; k++) { uint64_t s1, g1; P.cost(P0.recs[L.first_rec + k], s1, g1); if (s1 > smax) smax = s1; }
+            uint64_t best_pieces = pieces;
+            if (L.mac_only && pieces >= 1 && (uint64_t)L.nrec * count >= 2 * 4096) {
+                // MAC launches run in whole rounds of the chip (dots()): among a few piece counts take the cheapest
+                double best = -1.0;
+                const uint64_t R = (uint64_t)L.nrec * count;
+                for (uint64_t q = pieces; q <= pieces + 3; q++) {
+                    const size_t per = (size_t)((R + q - 1) / q);
+                    if ((uint64_t)per * smax > cap_keep) continue;
+                    const double c_est = (double)q * ((double)smax * (64.0 * round_cost(per, 4096) + 24.0 * round_cost(per, 3072)) + 3e2);
+                    if (best < 0 || c_est < best) { best = c_est; best_pieces = q; }
+                }
+            }
+            if (best_pieces > 1) {
+                const uint64_t soft = (tot + best_pieces - 1) / best_pieces + smax;
+                if (soft < cap_keep) P.cap_steps = soft;
+            }
+        }
         for (size_t t = 0; t < (prefix ? 1 : count); t++) {
             const uint32_t wo = (uint32_t)t * P.word_stride, ro = (uint32_t)t * P.reveal_stride;
             for (uint32_t k = 0; k < L.nrec; k++) {
@@ -603,6 +655,7 @@ inline void replicate_program(Program &P, const Program &P0, size_t count, const
                     if (L.first_rec + k == P0.lam_rec) { r.a = (uint32_t)lambda_fixed[t]; r.b = (uint32_t)(lambda_fixed[t] >> 32); }
                     break;
                 case OP_IDIVC: r.dst = mv(r.dst); r.a = mv(r.a); break;          // c is an immediate
+                case OP_MACK: r.dst = mv(r.dst); r.a = mv(r.a); r.b = mv(r.b); break;   // c is an offset between words of one circuit
                 case OP_REVEAL: r.dst += ro; r.a = mv(r.a); break;               // dst is a decode slot
                 case OP_MAX: {
                     // max_tree folds in the constant zero as the SECOND operand through a stride of -a
@@ -615,6 +668,7 @@ inline void replicate_program(Program &P, const Program &P0, size_t count, const
                 P.emit(r);
             }
         }
+        P.cap_steps = cap_keep;
         P.new_launch();
         while (next_iter < P0.iter_launch.size() && P0.iter_launch[next_iter] == li) {
             P.iter_launch.push_back((uint32_t)(P.launches.size() - 1));

@@ -575,6 +575,12 @@ def set_split_kernels(garbler=True, evaluator=True):
     lib().lgc_set_split_kernels(int(bool(garbler)), int(bool(evaluator)))
 
 
+def set_karatsuba(on=True):
+    """Karatsuba products in the CGD matrix-vector launches (width 64) for programs built from now on"""
+    lib().lgc_set_karatsuba.argtypes = [C.c_int]; lib().lgc_set_karatsuba.restype = None
+    lib().lgc_set_karatsuba(int(bool(on)))
+
+
 def aes_bench(waves=8192, blocks_per_lane=256, device=0):
     rate, chk = C.c_double(), C.c_uint32()
     _chk(lib().lgc_aes_bench(device, waves, blocks_per_lane, C.byref(rate), C.byref(chk)))

@@ -131,8 +131,10 @@ struct CpuBackend {
         c1 = AND(a1, b1, act1);
         c2 = AND(a2, b2, act2);
     }
+    W AND_ool(const W &a, const W &b, uint64_t act) { return AND(a, b, act); }
     W load(uint32_t id) const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_loadu_si128(words + (size_t)id * 64 + i); return r; }
     W load2(uint32_t lo, uint32_t hi) const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_loadu_si128(words + (size_t)(i < 32 ? lo : hi) * 64 + (i & 31)); return r; }
+    W load2h(uint32_t lo, uint32_t hi) const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_loadu_si128(words + (size_t)(i < 32 ? lo : hi) * 64 + 32 + (i & 31)); return r; }
     void store2(uint32_t lo, uint32_t hi, const W &v) { for (int i = 0; i < 64; i++) _mm_storeu_si128(words + (size_t)(i < 32 ? lo : hi) * 64 + (i & 31), v.l[i]); }
     void store(uint32_t id, const W &v) { for (int i = 0; i < 64; i++) _mm_storeu_si128(words + (size_t)id * 64 + i, v.l[i]); }
     void reveal(uint32_t slot, const W &v) {
@@ -155,6 +157,13 @@ int gcc_plain_run(const Rec *recs, size_t nrec, int w, int p, uint64_t *words, u
     if (steps) *steps = m.steps;
     if (gates) *gates = m.gates;
     return 0;
+}
+
+// gate steps / AND gates of one record (the builder's cost model: rec_cost)
+void gcc_rec_cost(uint32_t op, uint32_t cnt, int w, int p, uint64_t *steps, uint64_t *gates) {
+    Rec r;
+    r.op = op; r.cnt = cnt; r.dst = 0; r.a = 0; r.b = 0; r.c = 0; r.sa = 1; r.sb = 1; r.step0 = 0;
+    rec_cost(r, w, p, *steps, *gates);
 }
 
 // the same with the step order of the latency-bound GPU kernels (B::kPairSteps: independent gate steps

@@ -54,6 +54,14 @@ class GcCpu:
         steps = self.lib.gcc_plain_op(op, w, p, c, int(paired), _p(a), _p(b), _p(out), a.size)
         return out, steps
 
+    def rec_cost(self, op, cnt, w, p):
+        """(gate steps, AND gates) of one record of `cnt` items"""
+        s, g = C.c_uint64(), C.c_uint64()
+        self.lib.gcc_rec_cost.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        self.lib.gcc_rec_cost.restype = None
+        self.lib.gcc_rec_cost(op, cnt, w, p, C.byref(s), C.byref(g))
+        return s.value, g.value
+
     def derive_R(self, seed):
         out = np.zeros(16, dtype=np.uint8)
         self.lib.gcc_derive_R(seed, _p(out))

@@ -83,3 +83,64 @@ def test_mul_matches_oracle(gccpu, oracle, w, paired):
         for x, y, g in zip(a, b, got):
             exp = oracle.mul(_signed(x, w), _signed(y, w), p, w) & ((1 << w) - 1)
             assert int(g) == exp, (w, p, hex(int(x)), hex(int(y)))
+
+
+REC = np.dtype([("op", "<u4"), ("cnt", "<u4"), ("dst", "<u4"), ("a", "<u4"), ("b", "<u4"), ("c", "<u4"),
+                ("sa", "<i4"), ("sb", "<i4"), ("step0", "<u8")])
+OP_MAC, OP_MACK, OP_HDIFF = 1, 20, 21
+
+
+def _mac_reference(oracle, a, b, p):
+    """sum_k wrap_64((a_k b_k) >> p) mod 2^64 with the oracle's multiplication (src/fixed.oc:149-162)"""
+    tot = 0
+    for x, y in zip(a, b):
+        tot += oracle.mul(_signed(x, 64), _signed(y, 64), p, 64)
+    return tot & ((1 << 64) - 1)
+
+
+@pytest.mark.parametrize("p", [56, 63, 33, 32, 31, 8, 1, 0, 48])
+def test_karatsuba_mac_matches_oracle(gccpu, oracle, p):
+    """OP_MACK (three 32 x 32 arrays per product, two products per wave) accumulates exactly what OP_MAC does:
+    the sum of the oracle's truncated products, for every precision the command line accepts at w = 64, on edge
+    operands (all-ones, sign boundaries, halves equal / zero) and random ones, even and odd chunk lengths."""
+    rng = np.random.default_rng(900 + p)
+    m = (1 << 64) - 1
+    edge = [0, 1, m, m - 1, 1 << 63, (1 << 63) - 1, (1 << 63) + 1, 0xffffffff, 0x100000000, 0xffffffff00000000, 0x00000001ffffffff,
+            0x8000000080000000, 0x7fffffff7fffffff, 0x5555555555555555, 0xaaaaaaaaaaaaaaaa, 0xfffffffe00000001, 0x123456789abcdef0]
+    ea = [x for x in edge for _ in edge]; eb = [y for _ in edge for y in edge]
+    ra = [int(v) for v in rng.integers(0, 1 << 63, size=400, dtype=np.uint64) * 2 + rng.integers(0, 2, size=400, dtype=np.uint64)]
+    rb = [int(v) for v in rng.integers(0, 1 << 63, size=400, dtype=np.uint64) * 2 + rng.integers(0, 2, size=400, dtype=np.uint64)]
+    # small-magnitude operands of either sign (what a fixed-point solve mostly sees)
+    sa = [int(v) & m for v in rng.integers(-(1 << 40), 1 << 40, size=100)]
+    sb = [int(v) & m for v in rng.integers(-(1 << 58), 1 << 58, size=100)]
+    A = np.array(ea + ra + sa, dtype=np.uint64); Bv = np.array(eb + rb + sb, dtype=np.uint64)
+    n = len(A)
+    for cnt in (2, 7, 1, 20):
+        groups = n // cnt
+        # word file: 0 | a (n) | b (n) | hdiff a (n) | hdiff b (n) | results (2 per group, MACK) | results (2 per group, MAC)
+        base_a, base_b = 1, 1 + n
+        delta = 2 * n
+        res_k, res_m = 1 + 4 * n, 1 + 4 * n + 2 * groups
+        words = np.zeros(1 + 4 * n + 4 * groups, dtype=np.uint64)
+        words[base_a:base_a + n] = A; words[base_b:base_b + n] = Bv
+        recs = np.zeros(2 * n + 2 * groups, dtype=REC)
+        step = 0
+        sh, _ = gccpu.rec_cost(OP_HDIFF, 1, 64, p)
+        for i in range(2 * n):
+            recs[i] = (OP_HDIFF, 1, 1 + delta + i, 1 + i, 0, 0, 1, 1, step); step += sh
+        sk, gk = gccpu.rec_cost(OP_MACK, cnt, 64, p)
+        sm, gm = gccpu.rec_cost(OP_MAC, cnt, 64, p)
+        for g in range(groups):
+            recs[2 * n + g] = (OP_MACK, cnt, res_k + 2 * g, base_a + g * cnt, base_b + g * cnt, delta, 1, 1, step); step += sk
+        for g in range(groups):
+            recs[2 * n + groups + g] = (OP_MAC, cnt, res_m + 2 * g, base_a + g * cnt, base_b + g * cnt, 0, 1, 1, step); step += sm
+        steps, gates = gccpu.plain_run(recs.view(np.uint8), len(recs), 64, p, words, np.zeros(1, dtype=np.uint64))
+        assert steps == step
+        for g in range(groups):
+            exp = _mac_reference(oracle, A[g * cnt:(g + 1) * cnt], Bv[g * cnt:(g + 1) * cnt], p)
+            got_k = (int(words[res_k + 2 * g]) + int(words[res_k + 2 * g + 1])) & m
+            got_m = (int(words[res_m + 2 * g]) + int(words[res_m + 2 * g + 1])) & m
+            assert got_m == exp, (p, cnt, g)
+            assert got_k == exp, (p, cnt, g, [hex(int(v)) for v in A[g * cnt:(g + 1) * cnt]], [hex(int(v)) for v in Bv[g * cnt:(g + 1) * cnt]])
+        if cnt % 2 == 0 and p == 56:
+            assert sk < 0.88 * sm and gk < 0.92 * gm, (sk, sm, gk, gm)        # fewer gate steps AND fewer gates than the array
