@@ -635,7 +635,7 @@ inline void replicate_program(Program &P, const Program &P0, size_t count, const
                 for (uint64_t q = pieces; q <= pieces + 3; q++) {
                     const size_t per = (size_t)((R + q - 1) / q);
                     if ((uint64_t)per * smax > cap_keep) continue;
-                    const double c_est = (double)q * ((double)smax * (64.0 * round_cost(per, 4096) + 24.0 * round_cost(per, 3072)) + 3e2);
+                    const double c_est = (double)q * ((double)smax * (64.0 * Program::round_cost(per, 4096) + 24.0 * Program::round_cost(per, 3072)) + 3e2);
                     if (best < 0 || c_est < best) { best = c_est; best_pieces = q; }
                 }
             }
