@@ -334,6 +334,10 @@ def main():
     # exclusive per-kernel durations (HIP events on the launching stream)
     solver.run(profile=True)
     stx = solver.stats()
+    # the table ring of this solver is its one large allocation (twice the largest launch: 113 GB at d = 500): gone
+    # before the sweep and the separate-process runs below bring their own
+    solver.close()
+    lgc.release_cached_memory()
     gates = st["and_gates"]
     total_gates = gates * args.steps * world
     value = total_gates / elapsed
@@ -424,8 +428,20 @@ def main():
         aes_achieved = 4.0 * mac_gates / xg if xg > 0 else 0.0
         aes_achieved_eval = 2.0 * mac_gates / xe if xe > 0 else 0.0
         achieved_excl = alg_bytes_per_launch / (xg / n_launch_per_solve) / 1e9 if xg > 0 else 0.0
+        # SURVEY.md 8(d) asks for both readings: the word machine's own traffic (labels stay on chip: 32 B of table per
+        # AND each way -- `achieved` / `frac` above) and what a flat gate list of the same circuit would move:
+        # 96 B per AND and 64 B per XOR on each side, every label through HBM
+        n_xor = int(prog.info.total_xors)
+        flat_bytes = 192.0 * gates + 128.0 * n_xor
+        step_s = elapsed / args.steps
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
+                    "binding": "lds_aes",
+                    "flat_list_equiv": {"bytes_per_solve": flat_bytes, "GBs": flat_bytes / step_s / 1e9,
+                                        "frac": flat_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                                        "formula": "192 N_AND + 128 N_XOR over the whole solve / seconds per solve",
+                                        "n_and": gates, "n_xor": n_xor,
+                                        "n_xor_rule": "word-level XORs of two wire words x width (lane moves, public selects, inverters = wiring)"},
                     "kernel": "gc_mac_kernel<garbler>", "avg_launch_ms": avg_dur * 1e3,
                     "alg_bytes_per_launch": alg_bytes_per_launch,
                     "achieved_exclusive": achieved_excl, "avg_launch_ms_exclusive": xg / n_launch_per_solve * 1e3,
@@ -485,6 +501,16 @@ def main():
                     sweep_res["exact_vs_oracle"] = ok
             except Exception as e:
                 cpu["checker_error"] = str(e)
+        # the headline solve itself against the oracle (after all timing; the oracle solves d = 500 in seconds)
+        headline_exact = None
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                import orc
+                from helpers import oracle_solve
+                expb, _, _ = oracle_solve(orc.load(), tot[:T], tot[T:], d, w, p, "cgd", iters, 0.0, 0)
+                headline_exact = [int(v) for v in expb] == [int(v) for v in beta_fixed]
+            except Exception as e:
+                headline_exact = "checker error: %s" % e
         import shutil
         for res in (e2e or []):
             ck = res.pop("_check", None)
@@ -503,7 +529,8 @@ def main():
                                    "two-party masked input (test_linear_system path), garbler+evaluator co-located; "
                                    "one independent system per GPU" % (d, iters, w, p),
                        "d": d, "iterations": iters, "width": w, "precision": p, "sharding": "circuits x%d" % world},
-            "and_gates_per_solve": gates, "gate_steps_per_solve": st["gate_steps"],
+            "and_gates_per_solve": gates, "n_xor_per_solve": n_xor, "gate_steps_per_solve": st["gate_steps"],
+            "exact_vs_oracle": headline_exact,
             "table_bytes_per_solve": st["table_bytes"], "launches_per_solve": st["launches"],
             "ref_equiv_gates_per_solve": refg,
             "ref_equiv_gates_per_s": (refg * args.steps * world / elapsed) if refg else None,
@@ -515,7 +542,6 @@ def main():
             "beta0": float(int(beta_fixed[0]) / scale),
         }
         print(json.dumps(out), flush=True)
-    solver.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

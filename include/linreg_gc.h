@@ -158,6 +158,8 @@ typedef struct {
                                                         (x >= shared_end) and decode slots r + t * reveal_stride */
     uint32_t shared_end, prefix_launches;            /* words [0, shared_end) and launches [0, prefix_launches) are */
     uint64_t prefix_steps;                           /* the lambda-independent prefix (inputs, share sums) */
+    uint64_t total_xors;                             /* XOR gates a flat gate list of this circuit would hold (word XORs x width): */
+                                                     /* reporting only (bytes = 192 N_AND + 128 N_XOR)            */
 } lgc_program_info;
 typedef struct lgc_program lgc_program;
 int lgc_program_build(lgc_program **out, const lgc_system *sys);
@@ -173,6 +175,12 @@ const lgc_launch *lgc_program_launches(const lgc_program *p);
  * garbler may overwrite that range once launch wait_for[i] (-1: nobody) has been evaluated.
  * ring_bytes = 0 asks for the solver's own choice (twice the largest launch).  Arrays: n_launches. */
 int lgc_program_ring_plan(const lgc_program *p, size_t ring_bytes, size_t *ring_bytes_out, size_t *offsets, int64_t *wait_for);
+
+/* The gate count the REFERENCE's own circuit has for this solve (two-party input path; exact fits to every
+ * result file under experiments/results/phase2_32 and phase2_64) -- this build's circuits are smaller, so results files and
+ * rates carry both counts (bin/test_linear_system prints it, python/results.py writes it as an extra column).
+ * cgd: the cumulative count after `iterations` iterations.  LGC_EINVAL for ldlt (nothing published).  Host only. */
+int lgc_reference_gate_count(int algorithm, int width, size_t d, int iterations, uint64_t *gates);
 
 /* One-shot convenience: create + set + run + get + destroy. */
 int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[16], const uint64_t *shares,

@@ -276,6 +276,7 @@ extern "C" int lgc_program_info_get(const lgc_program *p, lgc_program_info *info
     info->shared_end = P.shared_end;
     info->prefix_launches = P.prefix_launches;
     info->prefix_steps = P.prefix_steps;
+    info->total_xors = P.total_xors;
     return LGC_OK;
 }
 static_assert(sizeof(lgc_record) == sizeof(Rec), "record layout");
@@ -778,6 +779,30 @@ extern "C" void *lgc_host_alloc(size_t bytes) {
     return p;
 }
 extern "C" void lgc_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// AND-gate count of the REFERENCE's circuit for the same solve (Obliv-C + absentminded-crypto-kit, two-party input path of
+// bin/test_linear_system): exact polynomial fits to the gate counts in experiments/results/phase2_{32,64}/*.out
+// (every d the reference published: 10, 20, 50, 100, 200, 500).  cgd: count after `iterations`
+// iterations as the result files list it (the last row equals the total).  No fit exists for ldlt.
+extern "C" int lgc_reference_gate_count(int algorithm, int width, size_t d, int iterations, uint64_t *gates) {
+    if (!gates) return lgc_fail(LGC_EINVAL, "null argument");
+    if ((width != 32 && width != 64) || d < 1 || iterations < 0) return lgc_fail(LGC_EINVAL, "bad argument");
+    const unsigned __int128 D = d;
+    unsigned __int128 v = 0;
+    if (algorithm == LGC_ALG_CGD) {
+        unsigned __int128 per, tot20;
+        if (width == 64) { per = 19300 * D * D + 221432 * D + 206191; tot20 = 386233 * D * D + 4534169 * D + 4123635; }
+        else { per = 4064 * D * D + 29155 * D + 8728; tot20 = (162591 * D * D + 1175767 * D) / 2 + 174560; }
+        v = tot20 - 20 * per + (unsigned __int128)iterations * per;
+    } else if (algorithm == LGC_ALG_CHOLESKY) {
+        if (width == 64) v = (9572 * D * D * D + 3 * 71691 * D * D + 584068 * D) / 3 + 31;
+        else v = (4064 * D * D * D + 37899 * D * D + 49489 * D) / 6 + 31;
+    } else {
+        return lgc_fail(LGC_EINVAL, "the reference published no gate counts for this algorithm");
+    }
+    *gates = (uint64_t)v;
+    return LGC_OK;
+}
 
 extern "C" void lgc_set_karatsuba(int on) { program_karatsuba() = on != 0; }
 extern "C" void lgc_set_split_kernels(int garbler, int evaluator) {

@@ -52,7 +52,7 @@ struct Rec {
 };
 
 // number of gate steps / active AND gates of one record (host side)
-inline void rec_cost(const Rec &r, int w, int p, uint64_t &steps, uint64_t &gates);
+inline void rec_cost(const Rec &r, int w, int p, uint64_t &steps, uint64_t &gates, uint64_t *xors);
 
 // Backend extras required here: load(id) / store(id, W) / reveal(slot, W).
 template <class B>
@@ -184,8 +184,13 @@ struct PlainMachine : PlainBackend {
 
 // cost of a record: run it on a scratch plaintext machine (the circuits'
 // control flow is data-independent, so any operand values give the counts)
-inline void rec_cost(const Rec &r, int w, int p, uint64_t &steps, uint64_t &gates) {
+// xors (optional): XOR gates a flat gate list of the same circuit would hold -- every word-level XOR of two wire words
+// counted as w gates (lane moves, selections by public masks, constants and inverters are wiring): the figure behind
+// SURVEY.md 8(d)'s flat-list traffic formula 192 N_AND + 128 N_XOR, which this engine's word machine never pays
+inline void rec_cost(const Rec &r, int w, int p, uint64_t &steps, uint64_t &gates, uint64_t *xors = 0) {
     struct CostMachine : PlainBackend {
+        uint64_t nx = 0;
+        W XOR(W a, W b) { nx++; return a ^ b; }
         W load(uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
         W load2(uint32_t, uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
         W load2h(uint32_t, uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
@@ -196,6 +201,7 @@ inline void rec_cost(const Rec &r, int w, int p, uint64_t &steps, uint64_t &gate
     exec_record(m, r, w, p);
     steps = m.steps;
     gates = m.gates;
+    if (xors) *xors = m.nx * (uint64_t)w;
 }
 
 }  // namespace gc

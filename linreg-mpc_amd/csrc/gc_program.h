@@ -20,6 +20,13 @@
 namespace gc {
 
 static const size_t kMinRecsPerLaunch = 8192;   // >= 2x the chip's resident waves (256 CUs x 12-16)
+// Largest launch of the co-located solver, in gate steps (2 KiB of garbled table each): 2^25 = 64 GiB of tables.  A MAC
+// launch runs in whole rounds of the chip (one workgroup per CU: 4096 garbler / 3072 evaluator records per round), so the
+// fewer launches a matrix-vector product is cut into, the less is lost to partly filled last rounds: with 2^23 the d = 500
+// product (27.5 M steps with Karatsuba records) fell into four launches of 3.81 / 5.09 rounds -- the evaluator ran six
+// rounds for five rounds of work -- with 2^25 it is ONE launch of 15.3 / 20.3 rounds.  The table ring is twice the
+// largest launch: 113 GB of the 288 GB of an MI355X at d = 500.
+static const uint64_t kDefaultCapSteps = 1ull << 25;
 
 struct Launch {
     uint32_t first_rec, nrec;   // slice of Program::recs
@@ -42,6 +49,7 @@ struct Program {
     uint32_t rv_trace;           // decode slot of trace[0] (cgd: iters x (d+4)), or ~0u
     uint32_t rv_ab;              // decode slot of the debug reveal of a, b (T + d), or ~0u
     uint64_t total_steps, total_gates;
+    uint64_t total_xors = 0;     // flat-list XOR gates (rec_cost): reporting only
     uint64_t max_launch_steps;
     // cgd: per iteration, the last launch of the iteration and the AND gates emitted up to there
     // (the points where cgd.oc:190-194 prints yaoGateCount() and the running time)
@@ -63,12 +71,13 @@ struct Program {
     uint64_t cap_steps;          // split launches above this many steps
     uint64_t step_cursor;
     std::map<std::pair<uint32_t, uint32_t>, std::pair<uint64_t, uint64_t>> cost_cache;
+    std::map<std::pair<uint32_t, uint32_t>, uint64_t> xor_cache;
     bool open;
 
     Program() : w(64), p(56), d(0), T(0), nshares(0), n_words(1), n_reveal(0), in_base(0), rv_beta(0),
                 rv_trace(~0u), rv_ab(~0u), total_steps(0), total_gates(0), max_launch_steps(0),
                 replicas(1), word_stride(0), reveal_stride(0), lam_rec(~0u), shared_end(1), prefix_launches(0),
-                prefix_steps(0), cap_steps(1ull << 23), step_cursor(0), open(false) {}
+                prefix_steps(0), cap_steps(kDefaultCapSteps), step_cursor(0), open(false) {}
 
     uint32_t alloc(size_t n) { uint32_t r = n_words; n_words += (uint32_t)n; return r; }
     uint32_t alloc_reveal(size_t n) { uint32_t r = n_reveal; n_reveal += (uint32_t)n; return r; }
@@ -78,9 +87,10 @@ struct Program {
         std::pair<uint32_t, uint32_t> key(r.op, r.cnt);
         auto it = cost_cache.find(key);
         if (it == cost_cache.end()) {
-            uint64_t s, g;
-            rec_cost(r, w, p, s, g);
+            uint64_t s, g, x = 0;
+            rec_cost(r, w, p, s, g, &x);
             it = cost_cache.insert(std::make_pair(key, std::make_pair(s, g))).first;
+            xor_cache[key] = x;
         }
         steps = it->second.first;
         gates = it->second.second;
@@ -112,6 +122,7 @@ struct Program {
         step_cursor += s;
         total_steps += s;
         total_gates += g;
+        total_xors += xor_cache[std::make_pair(r.op, r.cnt)];
         if (L.steps > max_launch_steps) max_launch_steps = L.steps;
     }
 

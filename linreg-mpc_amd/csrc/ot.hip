@@ -59,24 +59,38 @@ ot_cols_kernel(const uint32_t *rk0, const uint32_t *rk1, uint64_t ctr0, uint32_t
     const LdsTab4 lt = lds_tab4_make(lds_te0);
     const uint32_t dw = j < 32 ? delta.x : (j < 64 ? delta.y : (j < 96 ? delta.z : delta.w));
     const bool dj = (dw >> (j & 31)) & 1u;
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < m128; b += gridDim.x * blockDim.x) {
-        const uint64_t c = ctr0 + b;
+    // two counter blocks per trip (two AES in flight per key); the grid is a few workgroups per COLUMN, not per 1024
+    // blocks: every workgroup stages the 128 KiB table image once (~25 us), which with 64 workgroups per column cost
+    // more than the encryption itself
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < m128; b += 2 * stride) {
+        const uint32_t b2 = b + stride;
+        const bool two = b2 < m128;
+        const uint64_t c = ctr0 + b, c2 = ctr0 + (two ? b2 : b);
+        uint32_t s0[2][4] = {{(uint32_t)c, (uint32_t)(c >> 32), 0u, 0u}, {(uint32_t)c2, (uint32_t)(c2 >> 32), 0u, 0u}};
+        aes_encrypt_n<2, LdsTab4>(lt, sk0, s0);
         if (MODE == 0) {
-            uint32_t s0[1][4] = {{(uint32_t)c, (uint32_t)(c >> 32), 0u, 0u}};
-            uint32_t s1[1][4] = {{(uint32_t)c, (uint32_t)(c >> 32), 0u, 0u}};
-            aes_encrypt_n<1, LdsTab4>(lt, sk0, s0);
-            aes_encrypt_n<1, LdsTab4>(lt, sk1, s1);
-            uint4 cb = cbits[b];
-            out0[(size_t)j * m128 + b] = make_uint4(s0[0][0], s0[0][1], s0[0][2], s0[0][3]);
-            out1[(size_t)j * m128 + b] = make_uint4(s0[0][0] ^ s1[0][0] ^ cb.x, s0[0][1] ^ s1[0][1] ^ cb.y,
-                                                    s0[0][2] ^ s1[0][2] ^ cb.z, s0[0][3] ^ s1[0][3] ^ cb.w);
+            uint32_t s1[2][4] = {{(uint32_t)c, (uint32_t)(c >> 32), 0u, 0u}, {(uint32_t)c2, (uint32_t)(c2 >> 32), 0u, 0u}};
+            aes_encrypt_n<2, LdsTab4>(lt, sk1, s1);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (e == 1 && !two) break;
+                const uint32_t bb = e ? b2 : b;
+                uint4 cb = cbits[bb];
+                out0[(size_t)j * m128 + bb] = make_uint4(s0[e][0], s0[e][1], s0[e][2], s0[e][3]);
+                out1[(size_t)j * m128 + bb] = make_uint4(s0[e][0] ^ s1[e][0] ^ cb.x, s0[e][1] ^ s1[e][1] ^ cb.y,
+                                                         s0[e][2] ^ s1[e][2] ^ cb.z, s0[e][3] ^ s1[e][3] ^ cb.w);
+            }
         } else {
-            uint32_t s0[1][4] = {{(uint32_t)c, (uint32_t)(c >> 32), 0u, 0u}};
-            aes_encrypt_n<1, LdsTab4>(lt, sk0, s0);
-            uint4 u = Uin[(size_t)j * m128 + b];
-            uint32_t k = dj ? 0xffffffffu : 0u;
-            out0[(size_t)j * m128 + b] = make_uint4(s0[0][0] ^ (u.x & k), s0[0][1] ^ (u.y & k), s0[0][2] ^ (u.z & k),
-                                                    s0[0][3] ^ (u.w & k));
+            const uint32_t k = dj ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (e == 1 && !two) break;
+                const uint32_t bb = e ? b2 : b;
+                uint4 u = Uin[(size_t)j * m128 + bb];
+                out0[(size_t)j * m128 + bb] = make_uint4(s0[e][0] ^ (u.x & k), s0[e][1] ^ (u.y & k), s0[e][2] ^ (u.z & k),
+                                                         s0[e][3] ^ (u.w & k));
+            }
         }
     }
 }
@@ -127,19 +141,30 @@ ot_gilboa_send_kernel(const uint4 *rows, uint4 delta, const uint64_t *bvals, uin
     const int lw = w == 32 ? 5 : 6;
     for (uint64_t q = blockIdx.y; q < npairs; q += gridDim.y) {
         uint64_t acc = 0;
-        for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m_per_pair; t += (uint64_t)gridDim.x * blockDim.x) {
-            const uint64_t i = q * m_per_pair + t;
-            const uint64_t k = t >> lw;                 // w is 32 or 64: no 64-bit division in the inner loop
-            const int bit = (int)(t & (uint64_t)(w - 1));
-            Lbl x[2] = {u4_lbl(rows[i]), lxor(u4_lbl(rows[i]), u4_lbl(delta))};
-            uint64_t tw[2] = {tweak0 + i, tweak0 + i};
-            Lbl h[2];
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        // two OTs per trip: four hashes, two in flight at a time (the pattern of the MAC kernel's garble_and)
+        for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m_per_pair; t += 2 * stride) {
+            const uint64_t t2 = t + stride;
+            const bool two = t2 < m_per_pair;
+            const uint64_t i = q * m_per_pair + t, i2 = q * m_per_pair + (two ? t2 : t);
+            const Lbl r1 = u4_lbl(rows[i]), r2 = u4_lbl(rows[i2]);
+            Lbl x[4] = {r1, lxor(r1, u4_lbl(delta)), r2, lxor(r2, u4_lbl(delta))};
+            uint64_t tw[4] = {tweak0 + i, tweak0 + i, tweak0 + i2, tweak0 + i2};
+            Lbl h[4];
             hash_n<2, LdsTab4>(lt, c_rk, x, tw, h, c_rk24);
-            uint64_t x0 = ((uint64_t)h[0].x | ((uint64_t)h[0].y << 32)) & mask;
-            uint64_t h1 = ((uint64_t)h[1].x | ((uint64_t)h[1].y << 32)) & mask;
-            uint64_t d = (bvals[q * n + k] << bit) & mask;
-            y[i] = (x0 + d - h1) & mask;
-            acc -= x0;
+            hash_n<2, LdsTab4>(lt, c_rk, x + 2, tw + 2, h + 2, c_rk24);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (e == 1 && !two) break;
+                const uint64_t tt = e ? t2 : t, ii = e ? i2 : i;
+                const uint64_t k = tt >> lw;            // w is 32 or 64: no 64-bit division in the inner loop
+                const int bit = (int)(tt & (uint64_t)(w - 1));
+                uint64_t x0 = ((uint64_t)h[2 * e].x | ((uint64_t)h[2 * e].y << 32)) & mask;
+                uint64_t h1 = ((uint64_t)h[2 * e + 1].x | ((uint64_t)h[2 * e + 1].y << 32)) & mask;
+                uint64_t d = (bvals[q * n + k] << bit) & mask;
+                y[ii] = (x0 + d - h1) & mask;
+                acc -= x0;
+            }
         }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
         if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&shares[q], (unsigned long long)acc);
@@ -156,17 +181,26 @@ ot_gilboa_recv_kernel(const uint4 *rows, const uint64_t *avals, uint64_t n, int 
     const int lw = w == 32 ? 5 : 6;
     for (uint64_t q = blockIdx.y; q < npairs; q += gridDim.y) {
         uint64_t acc = 0;
-        for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m_per_pair; t += (uint64_t)gridDim.x * blockDim.x) {
-            const uint64_t i = q * m_per_pair + t;
-            const uint64_t k = t >> lw;                 // w is 32 or 64: no 64-bit division in the inner loop
-            const int bit = (int)(t & (uint64_t)(w - 1));
-            Lbl x = u4_lbl(rows[i]);
-            uint64_t tw = tweak0 + i;
-            Lbl h;
-            hash_n<1, LdsTab4>(lt, c_rk, &x, &tw, &h, c_rk24);
-            uint64_t v = ((uint64_t)h.x | ((uint64_t)h.y << 32)) & mask;
-            if ((avals[q * n + k] >> bit) & 1ull) v += y[i];
-            acc += v;
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m_per_pair; t += 2 * stride) {
+            const uint64_t t2 = t + stride;
+            const bool two = t2 < m_per_pair;
+            const uint64_t i = q * m_per_pair + t, i2 = q * m_per_pair + (two ? t2 : t);
+            Lbl x[2] = {u4_lbl(rows[i]), u4_lbl(rows[i2])};
+            uint64_t tw[2] = {tweak0 + i, tweak0 + i2};
+            const uint64_t yv[2] = {y[i], y[i2]};         // in flight during the hashes
+            Lbl h[2];
+            hash_n<2, LdsTab4>(lt, c_rk, x, tw, h, c_rk24);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (e == 1 && !two) break;
+                const uint64_t tt = e ? t2 : t;
+                const uint64_t k = tt >> lw;            // w is 32 or 64: no 64-bit division in the inner loop
+                const int bit = (int)(tt & (uint64_t)(w - 1));
+                uint64_t v = ((uint64_t)h[e].x | ((uint64_t)h[e].y << 32)) & mask;
+                if ((avals[q * n + k] >> bit) & 1ull) v += yv[e];
+                acc += v;
+            }
         }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
         if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&shares[q], (unsigned long long)acc);
@@ -202,14 +236,24 @@ ot_labels_send_kernel(const uint4 *rows, uint4 delta, const uint4 *m0, const uin
     __shared__ uint32_t lds_te0[2 * kLdsTabWords];
     lds_tab4_fill(lds_te0);
     const LdsTab4 lt = lds_tab4_make(lds_te0);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
-        Lbl x[2] = {u4_lbl(rows[i]), lxor(u4_lbl(rows[i]), u4_lbl(delta))};
-        uint64_t tw[2] = {tweak0 + i, tweak0 + i};
-        Lbl h[2];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += 2 * stride) {
+        const bool two = i + stride < m;
+        const uint64_t i2 = two ? i + stride : i;
+        const Lbl r1 = u4_lbl(rows[i]), r2 = u4_lbl(rows[i2]);
+        Lbl x[4] = {r1, lxor(r1, u4_lbl(delta)), r2, lxor(r2, u4_lbl(delta))};
+        uint64_t tw[4] = {tweak0 + i, tweak0 + i, tweak0 + i2, tweak0 + i2};
+        Lbl h[4];
         hash_n<2, LdsTab4>(lt, c_rk, x, tw, h, c_rk24);
-        uint4 a = m0[i], b = m1[i];
-        e[2 * i] = make_uint4(a.x ^ h[0].x, a.y ^ h[0].y, a.z ^ h[0].z, a.w ^ h[0].w);
-        e[2 * i + 1] = make_uint4(b.x ^ h[1].x, b.y ^ h[1].y, b.z ^ h[1].z, b.w ^ h[1].w);
+        hash_n<2, LdsTab4>(lt, c_rk, x + 2, tw + 2, h + 2, c_rk24);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (k == 1 && !two) break;
+            const uint64_t ii = k ? i2 : i;
+            uint4 a = m0[ii], b = m1[ii];
+            e[2 * ii] = make_uint4(a.x ^ h[2 * k].x, a.y ^ h[2 * k].y, a.z ^ h[2 * k].z, a.w ^ h[2 * k].w);
+            e[2 * ii + 1] = make_uint4(b.x ^ h[2 * k + 1].x, b.y ^ h[2 * k + 1].y, b.z ^ h[2 * k + 1].z, b.w ^ h[2 * k + 1].w);
+        }
     }
 }
 __global__ void __launch_bounds__(1024)
@@ -217,15 +261,37 @@ ot_labels_recv_kernel(const uint4 *rows, const uint64_t *cbits, const uint4 *e, 
     __shared__ uint32_t lds_te0[2 * kLdsTabWords];
     lds_tab4_fill(lds_te0);
     const LdsTab4 lt = lds_tab4_make(lds_te0);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
-        Lbl x = u4_lbl(rows[i]);
-        uint64_t tw = tweak0 + i;
-        Lbl h;
-        hash_n<1, LdsTab4>(lt, c_rk, &x, &tw, &h, c_rk24);
-        uint32_t c = (uint32_t)(cbits[i >> 6] >> (i & 63)) & 1u;
-        uint4 ev = e[2 * i + c];
-        out[i] = make_uint4(ev.x ^ h.x, ev.y ^ h.y, ev.z ^ h.z, ev.w ^ h.w);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += 2 * stride) {
+        const bool two = i + stride < m;
+        const uint64_t i2 = two ? i + stride : i;
+        Lbl x[2] = {u4_lbl(rows[i]), u4_lbl(rows[i2])};
+        uint64_t tw[2] = {tweak0 + i, tweak0 + i2};
+        const uint32_t c1 = (uint32_t)(cbits[i >> 6] >> (i & 63)) & 1u, c2 = (uint32_t)(cbits[i2 >> 6] >> (i2 & 63)) & 1u;
+        const uint4 ev1 = e[2 * i + c1], ev2 = e[2 * i2 + c2];      // in flight during the hashes
+        Lbl h[2];
+        hash_n<2, LdsTab4>(lt, c_rk, x, tw, h, c_rk24);
+        out[i] = make_uint4(ev1.x ^ h[0].x, ev1.y ^ h[0].y, ev1.z ^ h[0].z, ev1.w ^ h[0].w);
+        if (two) out[i2] = make_uint4(ev2.x ^ h[1].x, ev2.y ^ h[1].y, ev2.z ^ h[1].z, ev2.w ^ h[1].w);
     }
+}
+
+// Launch geometry.  Every workgroup of these kernels stages the 128 KiB four-table AES image in LDS before its first
+// block (one workgroup per CU, ~25 us), so a launch uses about two workgroups per CU and lets them loop -- not one
+// workgroup per 1024 items: with 16 384 workgroups for a 64-pair batch the staging alone took 1.7 ms of each 2.1 ms
+// payload kernel (profiles/r2e_ot_kernel_stats.csv; after: profiles/r3_ot_kernel_stats.csv).
+static const unsigned kOtGroups = 512;
+static unsigned ot_cols_groups(uint64_t m128) {           // workgroups per column (grid.y = 128 columns)
+    unsigned gx = (unsigned)((m128 + 2047) / 2048);
+    const unsigned cap = kOtGroups / 128;
+    return gx > cap ? cap : (gx ? gx : 1);
+}
+static void ot_pair_grid(uint64_t mpp, uint64_t npairs, unsigned &gx, unsigned &gy) {   // grid.y strides over the pairs
+    gy = npairs > kOtGroups ? kOtGroups : (unsigned)(npairs ? npairs : 1);
+    gx = (unsigned)((mpp + 2047) / 2048);
+    const unsigned cap = kOtGroups / gy ? kOtGroups / gy : 1;
+    if (gx > cap) gx = cap;
+    if (!gx) gx = 1;
 }
 
 // =============================================================== sessions
@@ -368,7 +434,7 @@ static int recv_extend(lgc_ot_receiver *r, lgc_ot_receiver::Slot *sl, uint64_t m
     uint4 *U = reinterpret_cast<uint4 *>(u_out);
     if (!r->dev_io) { OTCHK(r->U.ensure(cbytes)); U = static_cast<uint4 *>(r->U.p); }
     OTCHK(sl->rows.ensure((size_t)m128 * 128 * 16));
-    unsigned gx = (m128 + 1023) / 1024; if (gx > 64) gx = 64;
+    unsigned gx = ot_cols_groups(m128);
     hipLaunchKernelGGL((ot_cols_kernel<0>), dim3(gx, 128), dim3(1024), 0, r->st, r->rk0, r->rk1, r->ctr, m128,
                        (const uint4 *)sl->cbits.p, (const uint4 *)0, make_uint4(0, 0, 0, 0), (uint4 *)r->T0.p, U);
     OTLAUNCH();
@@ -392,7 +458,7 @@ static int send_extend(lgc_ot_sender *s, uint64_t m, const uint8_t *u_in) {
         OTCHK(hipMemcpyAsync(s->U.p, u_in, cbytes, hipMemcpyHostToDevice, s->st));
         U = static_cast<const uint4 *>(s->U.p);
     }
-    unsigned gx = (m128 + 1023) / 1024; if (gx > 64) gx = 64;
+    unsigned gx = ot_cols_groups(m128);
     hipLaunchKernelGGL((ot_cols_kernel<1>), dim3(gx, 128), dim3(1024), 0, s->st, s->rk, (const uint32_t *)0, s->ctr, m128,
                        (const uint4 *)0, U, s->delta, (uint4 *)s->Q.p, (uint4 *)0);
     OTLAUNCH();
@@ -463,8 +529,8 @@ extern "C" int lgc_ot_gilboa_send(lgc_ot_sender *s, const uint64_t *b, size_t np
     }
     OTCHK(s->sh.ensure(npairs * 8));
     OTCHK(hipMemsetAsync(s->sh.p, 0, npairs * 8, s->st));
-    unsigned gx = (unsigned)((mpp + 1023) / 1024); if (gx > 256) gx = 256;
-    unsigned gy = npairs > 65535 ? 65535u : (unsigned)npairs;
+    unsigned gx, gy;
+    ot_pair_grid(mpp, npairs, gx, gy);
     hipLaunchKernelGGL(ot_gilboa_send_kernel, dim3(gx, gy), dim3(1024), 0, s->st, (const uint4 *)s->rows.p, s->delta, db, (uint64_t)n,
                        width, mpp, (uint64_t)npairs, s->tweak, dy, (uint64_t *)s->sh.p);
     OTLAUNCH();
@@ -491,8 +557,8 @@ extern "C" int lgc_ot_gilboa_recv_finish(lgc_ot_receiver *r, const uint64_t *y_i
     OTCHK(r->sh.ensure(sl->npairs * 8));
     OTCHK(hipMemsetAsync(r->sh.p, 0, sl->npairs * 8, r->st));
     const uint64_t mpp = sl->n * (uint64_t)sl->w;
-    unsigned gx = (unsigned)((mpp + 1023) / 1024); if (gx > 256) gx = 256;
-    unsigned gy = sl->npairs > 65535 ? 65535u : (unsigned)sl->npairs;
+    unsigned gx, gy;
+    ot_pair_grid(mpp, sl->npairs, gx, gy);
     hipLaunchKernelGGL(ot_gilboa_recv_kernel, dim3(gx, gy), dim3(1024), 0, r->st, (const uint4 *)sl->rows.p, sl->avals_dev, sl->n, sl->w,
                        mpp, sl->npairs, sl->tweak_cur, dy, (uint64_t *)r->sh.p);
     OTLAUNCH();
@@ -543,7 +609,7 @@ extern "C" int lgc_ot_labels_send(lgc_ot_sender *s, const uint8_t *msg0, const u
         OTCHK(hipMemcpyAsync(s->m1.p, msg1, m * 16, hipMemcpyHostToDevice, s->st));
         d0 = (const uint4 *)s->m0.p; d1 = (const uint4 *)s->m1.p; de = (uint4 *)s->e.p;
     }
-    unsigned gx = (unsigned)((m + 1023) / 1024); if (gx > 512) gx = 512;
+    unsigned gx = (unsigned)((m + 2047) / 2048); if (gx > kOtGroups) gx = kOtGroups;
     hipLaunchKernelGGL(ot_labels_send_kernel, dim3(gx), dim3(1024), 0, s->st, (const uint4 *)s->rows.p, s->delta, d0, d1, (uint64_t)m,
                        s->tweak, de);
     OTLAUNCH();
@@ -566,7 +632,7 @@ extern "C" int lgc_ot_labels_recv_finish(lgc_ot_receiver *r, const uint8_t *e_in
         OTCHK(hipMemcpyAsync(r->e.p, e_in, sl->m * 32, hipMemcpyHostToDevice, r->st));
         de = (const uint4 *)r->e.p; dout = (uint4 *)r->out.p;
     }
-    unsigned gx = (unsigned)((sl->m + 1023) / 1024); if (gx > 512) gx = 512;
+    unsigned gx = (unsigned)((sl->m + 2047) / 2048); if (gx > kOtGroups) gx = kOtGroups;
     hipLaunchKernelGGL(ot_labels_recv_kernel, dim3(gx), dim3(1024), 0, r->st, (const uint4 *)sl->rows.p, (const uint64_t *)sl->cbits.p, de,
                        sl->m, sl->tweak_cur, dout);
     OTLAUNCH();

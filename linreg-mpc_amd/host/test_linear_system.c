@@ -168,6 +168,12 @@ int main(int argc, char **argv) {
         }
         printf("Time elapsed: %f\n", wall_clock() - time);
         printf("Number of gates: %lld\n", gates);
+        {   /* the same solve in the reference's own circuit: keeps result files comparable with
+             * experiments/results/phase2_{32,64}; nothing is printed where the reference published no count (ldlt) */
+            uint64_t refg = 0;
+            if (lgc_reference_gate_count(sys.algorithm, sys.width, d, sys.num_iterations, &refg) == 0)
+                printf("Reference-equivalent gates: %llu\n", (unsigned long long)refg);
+        }
         printf("Result: ");
         for (size_t i = 0; i < d; i++) printf("%20.15f ", fixed_to_double(beta[i], precision));
         printf("\n");

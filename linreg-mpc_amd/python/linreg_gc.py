@@ -54,7 +54,8 @@ class ProgramInfo(C.Structure):
                 ("rv_trace", C.c_uint32), ("rv_inputs", C.c_uint32), ("total_steps", C.c_uint64),
                 ("total_gates", C.c_uint64), ("max_launch_steps", C.c_uint64),
                 ("replicas", C.c_uint32), ("word_stride", C.c_uint32), ("reveal_stride", C.c_uint32),
-                ("shared_end", C.c_uint32), ("prefix_launches", C.c_uint32), ("prefix_steps", C.c_uint64)]
+                ("shared_end", C.c_uint32), ("prefix_launches", C.c_uint32), ("prefix_steps", C.c_uint64),
+                ("total_xors", C.c_uint64)]
 
 
 _lib = None
@@ -573,6 +574,16 @@ def release_cached_memory():
 def set_split_kernels(garbler=True, evaluator=True):
     """which kernel runs the latency-bound launches of each role (16-wave column-split or 4-wave); interchangeable"""
     lib().lgc_set_split_kernels(int(bool(garbler)), int(bool(evaluator)))
+
+
+def reference_gate_count(algorithm, width, d, iterations=0):
+    """AND gates of the reference's circuit for the same solve, or None where it published none"""
+    L = lib()
+    L.lgc_reference_gate_count.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
+    L.lgc_reference_gate_count.restype = C.c_int
+    g = C.c_uint64()
+    alg = ALG[algorithm] if isinstance(algorithm, str) else int(algorithm)
+    return int(g.value) if L.lgc_reference_gate_count(alg, width, d, iterations, C.byref(g)) == 0 else None
 
 
 def set_karatsuba(on=True):

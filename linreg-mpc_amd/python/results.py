@@ -26,7 +26,7 @@ _NUMS = re.compile(r"((\s*[\d\.-]+)+)\s*$")
 
 def parse_exec(text, alg):
     """Returns dict(ot_time, time, gate_count, result, iter_solutions, iter_times, iter_gates)."""
-    out = dict(ot_time=0.0, time=None, gate_count=None, result=None, iter_solutions=[], iter_times=[],
+    out = dict(ot_time=0.0, time=None, gate_count=None, ref_gate_count=None, result=None, iter_solutions=[], iter_times=[],
                iter_gates=[])
     for line in text.splitlines():
         m = re.match(r"OT\s+time:\s*(\S+)", line)
@@ -50,6 +50,9 @@ def parse_exec(text, alg):
         m = re.match(r"Number\s+of\s+gates:\s*(\S+)", line)
         if m:
             out["gate_count"] = int(m.group(1))
+        m = re.match(r"Reference-equivalent\s+gates:\s*(\S+)", line)
+        if m:
+            out["ref_gate_count"] = int(m.group(1))
         m = re.match(r"Result:\s*(.+)", line)
         if m:
             out["result"] = [float(v) for v in m.group(1).split()]
@@ -64,8 +67,13 @@ def write_phase2_out(path, n, d, alg, run, solution, X=None, y=None, lam=0.0, co
     error = float(np.linalg.norm(result - solution))
     if objective_value is None:
         objective_value = objective(X, y, solution, lam, n) if X is not None else float("nan")
-    lines = ["n d algorithm ot_time time error gate_count",
-             "{0} {1} {2} {3} {4} {5} {6}".format(n, d, alg, run["ot_time"], run["time"], error, run["gate_count"])]
+    # gate_count is THIS build's circuit; ref_gate_count (extra last column, -1 where unknown) is the reference's count for
+    # the same solve, the figure experiments/results/phase2_{32,64}/*.out hold: rates computed from either stay comparable
+    # (the column is added only when the run reported the figure: files without it are byte-for-byte the reference's layout)
+    ref = run.get("ref_gate_count")
+    lines = ["n d algorithm ot_time time error gate_count" + (" ref_gate_count" if ref is not None else ""),
+             "{0} {1} {2} {3} {4} {5} {6}".format(n, d, alg, run["ot_time"], run["time"], error, run["gate_count"])
+             + (" %d" % ref if ref is not None else "")]
     if alg == "cgd":
         gates = list(run["iter_gates"])
         # the reference shifts the per-iteration counts so that the last row equals the total

@@ -163,7 +163,7 @@ int gcc_plain_run(const Rec *recs, size_t nrec, int w, int p, uint64_t *words, u
 void gcc_rec_cost(uint32_t op, uint32_t cnt, int w, int p, uint64_t *steps, uint64_t *gates) {
     Rec r;
     r.op = op; r.cnt = cnt; r.dst = 0; r.a = 0; r.b = 0; r.c = 0; r.sa = 1; r.sb = 1; r.step0 = 0;
-    rec_cost(r, w, p, *steps, *gates);
+    rec_cost(r, w, p, *steps, *gates, 0);
 }
 
 // the same with the step order of the latency-bound GPU kernels (B::kPairSteps: independent gate steps
@@ -458,7 +458,7 @@ double gcc_baseline_mac(int w, int p, uint32_t nrec, uint32_t chunk, uint64_t *a
         Rec r;
         r.op = OP_MAC; r.cnt = chunk; r.dst = 1 + 2 * chunk + 2 * i; r.a = 1; r.b = 1 + chunk; r.c = 0;
         r.sa = 1; r.sb = 1; r.step0 = step_cursor;
-        if (i == 0) rec_cost(r, w, p, steps, gates);
+        if (i == 0) rec_cost(r, w, p, steps, gates, 0);
         step_cursor += steps;
         c.recs.push_back(r);
     }

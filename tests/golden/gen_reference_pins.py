@@ -40,13 +40,15 @@ def errors():
             rec = {"file": folder + "/" + os.path.basename(path), "n": int(n), "d": int(d), "alg": alg, "width": int(m.group(6)),
                    "sigma": float(m.group(3)), "iters": int(m.group(7)), "error": float(err), "gate_count": int(gates)}
             if alg == "cgd":
-                it = []
+                it, ig = [], []
                 for l in lines[3:]:
                     f = l.split()
                     if len(f) != 5 or not f[0].isdigit():
                         break
                     it.append(float(f[1]))
+                    ig.append(int(f[4]))
                 rec["iter_errors"] = it
+                rec["iter_gates"] = ig          # cumulative gate count after iteration i (column gate_count_i)
             out.append(rec)
     return out
 

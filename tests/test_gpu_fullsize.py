@@ -39,7 +39,7 @@ def test_config3_cgd15_d100(lgc, oracle):
 def test_headline_cgd15_d500_bit_exact(lgc, oracle):
     """the bench workload itself: d=500 CGD-15, 64-bit, every per-iteration reveal compared"""
     st = _run(lgc, oracle, 1500, 500, 64, 56, "cgd", 15, 2, 0, 0.0, 4)
-    assert st["and_gates"] > 3e10
+    assert 2.5e10 < st["and_gates"] <= 2.9e10          # Karatsuba matrix-vector products (3.22e10 with the plain array)
 
 
 def test_config4_cgd20_d500_32bit(lgc, oracle):

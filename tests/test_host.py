@@ -232,8 +232,14 @@ def test_test_linear_system_binary(tmp_path, oracle, alg, w, p, ring):
     out = str(tmp_path / "ls.out")
     err = results.write_phase2_out(out, 40, d, alg, run, sol, condition_number=float(np.linalg.cond(A)))
     rows = open(out).read().split("\n")
-    assert rows[0] == "n d algorithm ot_time time error gate_count"
+    # this build's gate count, and next to it the reference's count for the same solve (none for ldlt)
+    import linreg_gc
+    refg = linreg_gc.reference_gate_count(alg, w, d, iters if alg == "cgd" else 0)
+    assert run["ref_gate_count"] == refg and (refg is None) == (alg == "ldlt")
+    assert rows[0] == "n d algorithm ot_time time error gate_count" + ("" if refg is None else " ref_gate_count")
     assert rows[1].split()[:3] == ["40", str(d), alg] and abs(float(rows[1].split()[5]) - err) < 1e-12
+    if refg is not None:
+        assert int(rows[1].split()[7]) == refg and refg > run["gate_count"]
     if alg == "cgd":
         assert rows[2] == "iter_i error_i obj_i time_i gate_count_i" and len(rows) == 3 + iters + 10
         assert int(rows[2 + iters].split()[4]) == run["gate_count"]

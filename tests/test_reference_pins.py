@@ -164,3 +164,28 @@ def test_gpu_error_matches_reference_runs(lgc, oracle, w, alg, d):
     refs = [r["error"] for r in REF[(w, "cholesky" if alg == "ldlt" else alg, d)]]
     err = float(np.linalg.norm(sx(got.astype(np.uint64), w) / 2.0 ** p - x))
     assert min(refs) / (BAND * (3 if alg == "ldlt" else 1)) <= err <= max(refs) * BAND * (3 if alg == "ldlt" else 1), (err, refs)
+
+
+def test_reference_gate_count_polynomials_match_every_published_file(golden_dir):
+    """lgc_reference_gate_count reproduces the gate_count column of every
+    experiments/results/phase2_{32,64}/*.out of the current circuits (all six d values of the 64-bit runs, both
+    algorithms) and, for cgd, the cumulative count after EVERY iteration -- the figure bench.py's
+    ref_equiv_gates_per_s and the ref_gate_count column of python/results.py are built on."""
+    import json
+    import linreg_gc
+    recs = json.load(open(os.path.join(golden_dir, "reference_errors.json")))
+    seen = set()
+    for r in recs:
+        # phase2_64/ also holds *_32_* files of an older 32-bit implementation (SURVEY.md 6.1 note): not the current fixed.oc
+        if ("_%d_" % r["width"]) not in r["file"] or not r["file"].startswith("phase2_%d/" % r["width"]):
+            continue
+        total = linreg_gc.reference_gate_count(r["alg"], r["width"], r["d"], r["iters"] if r["alg"] == "cgd" else 0)
+        assert total == r["gate_count"], r["file"]
+        if r["alg"] == "cgd":
+            for it, g in enumerate(r["iter_gates"], start=1):
+                assert linreg_gc.reference_gate_count("cgd", r["width"], r["d"], it) == g, (r["file"], it)
+        seen.add((r["alg"], r["width"], r["d"]))
+    assert {d for a, w, d in seen if a == "cgd" and w == 64} == {10, 20, 50, 100, 200, 500}
+    assert {d for a, w, d in seen if a == "cholesky" and w == 64} >= {20, 100, 500}
+    assert linreg_gc.reference_gate_count("ldlt", 64, 10) is None
+    assert linreg_gc.reference_gate_count("cgd", 64, 500, 15) == 74149847180          # BASELINE.md 1.1
