@@ -258,13 +258,15 @@ struct Circ {
     // and stored `delta` words above the operand.  The sub-products arrive as L + 2^32 (S + C) (low half resolved,
     // high half carry-save); everything is then added in carry-save form:
     //     LOW  (bits 32..63, both products packed): S0 + C0 + L0 + L1 +- L2                    3 steps per pair
+    //     the carry into bit p out of the dropped bits 32..p-1 (only L0 lives below bit 32):    1 + ceil(log2(p-32)) per pair
+    //          only the carry OUT is wanted, so the (generate, propagate) pairs are combined in a tree anchored at the
+    //          top lane, both ANDs of a node in ONE gate step (the second in the lane of the node just consumed)
     //     HIGH (bits 64..64+p-1, per product): L1|S1, S0|C1, C0, S1, C1, +-S2, +-C2 and the two sign corrections
-    //          -(sa & B), -(sb & A) (2 steps to form them)                                      7 steps per product
-    //     the carry into bit p out of the dropped bits 32..p-1 (only L0 lives below bit 32)     10 steps per pair
+    //          -(sa & B), -(sb & A) (2 steps to form them)                                      9 steps per product
     //     (AS, AC) += bits p..p+63                                                              2 steps per product
     // Negated operands enter complemented over a lane mask that reaches the top of the range, +1 at their lowest lane:
     // a CSA step has a free slot in lane 0 of its shifted carry word, and there are exactly as many slots as corrections
-    // (LOW: n; HIGH: the three carries out of LOW, n, n, ~n, 1).  224 steps per pair against 2 x 129.
+    // (LOW: n; HIGH: the three carries out of LOW, n, n, ~n, 1).  220 steps per pair at p = 56 against 2 x 129.
     static GC_HD W half_lo(B &be, W x, int h) { return h ? be.shr(x, 32) : be.sel(lanes(32), x, be.zero()); }
     static GC_HD W half_hi(B &be, W x, int h) { return h ? be.sel(~lanes(32), x, be.zero()) : be.shl(x, 32); }
     // two independent unsigned 32 x 32 products per wave: value = L + 2^32 (S + C) in each half
@@ -285,44 +287,6 @@ struct Circ {
             S = shr2(be, S, 1);
         }
     }
-    // carry-save step on both halves: carries stay inside their half; cin (lanes 0 / 32 only) joins the new carry word;
-    // cout: the carries out of lanes 31 / 63, delivered in lanes 0 / 32
-    // carry-save steps of the recombination: the gate goes through B::AND_ool, which a GPU backend may keep out of line
-    // (one copy of the AES body instead of one per call site; the array rows stay inlined)
-    static GC_HD void csa_ool(B &be, W &S, W &C, W X, int n, W cin_lane0) {
-        const uint64_t act = lanes(n);
-        W t = be.AND_ool(be.XOR(S, X), be.XOR(C, X), act);
-        W carry = be.XOR(t, be.sel(act, X, be.zero()));
-        S = be.XOR(be.XOR(S, C), X);
-        C = be.XOR(be.sel(act, be.shl(carry, 1), be.zero()), cin_lane0);
-    }
-    static GC_HD void csa2(B &be, W &S, W &C, W X, W cin, W *cout) {
-        W t = be.AND_ool(be.XOR(S, X), be.XOR(C, X), ~0ull);
-        W carry = be.XOR(t, X);
-        S = be.XOR(be.XOR(S, C), X);
-        if (cout) *cout = shr2(be, carry, 31);
-        C = be.XOR(shl2(be, carry, 1), cin);
-    }
-    // carry out of lanes [0, nb) of x + y in each half, delivered in lanes 0 / 32.  Only the carry OUT is wanted, so
-    // the (generate, propagate) pairs are combined in a tree anchored at lane nb - 1 instead of a full prefix network: at
-    // distance `dist` the node at lane l = nb - 1 - 2 m dist absorbs the node at l - dist,
-    //     G_l ^= P_l & G_(l-dist),    P_l = P_l & P_(l-dist),
-    // and the two ANDs of a node share ONE gate step: the first in lane l, the second in lane l - dist, whose own
-    // node has just been consumed.  1 + ceil(log2 nb) steps (Kogge-Stone: 2 log2 nb).
-    static GC_HD W carry2(B &be, W x, W y, int nb) {
-        if (nb <= 0) return be.zero();
-        W G = be.AND_ool(x, y, m2(lanes(nb))), Pg = be.XOR(x, y);
-        for (int dist = 1; dist < nb; dist <<= 1) {
-            uint64_t mA = 0, mB = 0;
-            for (int l = nb - 1; l - dist >= 0; l -= 2 * dist) { mA |= 1ull << l; mB |= 1ull << (l - dist); }
-            W Xo = be.sel(m2(mA), Pg, shr2(be, Pg, dist));
-            W Yo = be.sel(m2(mA), shl2(be, G, dist), Pg);
-            W T = be.AND_ool(Xo, Yo, m2(mA | mB));
-            G = be.XOR(G, be.sel(m2(mA), T, be.zero()));
-            Pg = be.sel(m2(mA), shl2(be, T, dist), Pg);
-        }
-        return be.sel(m2(1ull), shr2(be, G, nb - 1), be.zero());
-    }
     // |A1 - A0| in lanes 0..31, [A1 < A0] in lane 32
     static GC_HD W hdiff(B &be, W a) {
         W x = be.shr(a, 32), y = be.sel(lanes(32), a, be.zero()), ge;
@@ -332,48 +296,138 @@ struct Circ {
         return be.XOR(be.sel(lanes(32), m, be.zero()), be.sel(1ull << 32, neg, be.zero()));
     }
     // (AS, AC) += wrap_64((a b) >> p) + wrap_64((a' b') >> p), carry-save.  a0 / a1, b0 / b1: the operand words of the two
-    // products; hdiff of every operand word lies `delta` words above it.  Operands are loaded where they are used (packed
-    // halves: load2 = lanes 0..31 of both words, load2h = lanes 32..63), so that few labels are live across the arrays.
-    static GC_HD void mack2(B &be, W &AS, W &AC, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t delta, int p) {
+    // products, da0 .. db1: the words holding their hdiff.  A single product is paired with the constant-zero word (id 0,
+    // whose hdiff is word 0 as well).  The three arrays run as ONE loop -- a single copy of the two inlined gate bodies in
+    // a GPU kernel -- whose results go to a small array indexed by the loop counter: on the GPU that array lives in
+    // scratch memory, so the nine sub-product words do not occupy registers while the next array is hashed.  Operands are
+    // loaded where they are used (load2s: lanes 32 half .. 32 half + 31 of two words, packed).
+    static GC_HD void mack2(B &be, W &AS, W &AC, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t da0, uint32_t da1,
+                            uint32_t db0, uint32_t db1, int p) {
         const uint64_t all = ~0ull;
-        W L0, S0, C0, L1, S1, C1, L2, S2, C2;
-        umul32x2(be, be.load2(a0, a1), be.load2(b0, b1), L0, S0, C0);
-        umul32x2(be, be.load2h(a0, a1), be.load2h(b0, b1), L1, S1, C1);
-        umul32x2(be, be.load2(a0 + delta, a1 + delta), be.load2(b0 + delta, b1 + delta), L2, S2, C2);
+        W sub[9];                                          // (L, S, C) of Lo = A0 B0, H = A1 B1, DQ = |DA| |DB|
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (int t = 0; t < 3; t++) {
+            const bool dq = t == 2;
+            W L, S, C;
+            umul32x2(be, be.load2s(dq ? da0 : a0, dq ? da1 : a1, t == 1), be.load2s(dq ? db0 : b0, dq ? db1 : b1, t == 1), L, S, C);
+            sub[3 * t] = L; sub[3 * t + 1] = S; sub[3 * t + 2] = C;
+        }
         // DA DB = (-1)^(sA ^ sB) DQ enters Mid with a minus sign: n = 1 where DQ is subtracted
-        W n = be.NOTm(be.bcast2(be.XOR(be.load2h(a0 + delta, a1 + delta), be.load2h(b0 + delta, b1 + delta)), 0), all);
-        // LOW: lane j of a half = bit 32 + j
-        W SL = S0, CL = C0, o1, o2, o3;
-        csa2(be, SL, CL, L1, be.zero(), &o1);
-        csa2(be, SL, CL, L0, be.zero(), &o2);
-        csa2(be, SL, CL, be.XOR(L2, n), be.sel(m2(1ull), n, be.zero()), &o3);
-        W cp = carry2(be, SL, CL, p - 32);
-        const int nh = p;                                  // HIGH: lane i = bit 64 + i, bits below 64 + p matter
+        W n = be.NOTm(be.bcast2(be.XOR(be.load2s(da0, da1, 1), be.load2s(db0, db1, 1)), 0), all);
+        // The recombination is written as two loops with ONE gate each (`switch` on the step number around it): a GPU
+        // kernel then holds one inlined copy of the gate body per loop instead of one per carry-save step.
+        // ---- phase A, both products packed (lane j of a half = bit 32 + j): LOW = S0 + C0 + L1 + L0 +- L2 in three
+        // carry-save steps (carries out of bit 63 -> o1..o3), then the carry out of its lanes [0, p - 32) (carry2's tree)
+        W SL = sub[1], CL = sub[2], o1 = be.zero(), o2 = be.zero(), o3 = be.zero(), cp = be.zero();
+        {
+            const int nb = p - 32;
+            int levels = 0;
+            for (int dist = 1; dist < nb; dist <<= 1) levels++;
+            const int nsteps = 3 + (nb > 0 ? 1 + levels : 0);
+            W X = be.zero(), G = be.zero(), Pg = be.zero();
+            int dist = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+            for (int i = 0; i < nsteps; i++) {
+                W ga, gb;
+                uint64_t act = all, mA = 0, mB = 0;
+                if (i < 3) {
+                    X = i == 0 ? sub[3] : (i == 1 ? sub[0] : be.XOR(sub[6], n));
+                    ga = be.XOR(SL, X); gb = be.XOR(CL, X);
+                } else if (i == 3) {
+                    ga = SL; gb = CL; act = m2(lanes(nb));
+                } else {
+                    for (int l = nb - 1; l - dist >= 0; l -= 2 * dist) { mA |= 1ull << l; mB |= 1ull << (l - dist); }
+                    ga = be.sel(m2(mA), Pg, shr2(be, Pg, dist));
+                    gb = be.sel(m2(mA), shl2(be, G, dist), Pg);
+                    act = m2(mA | mB);
+                }
+                W t = be.AND(ga, gb, act);
+                if (i < 3) {
+                    W carry = be.XOR(t, X);
+                    SL = be.XOR(be.XOR(SL, CL), X);
+                    W co = shr2(be, carry, 31);
+                    if (i == 0) o1 = co; else if (i == 1) o2 = co; else o3 = co;
+                    CL = shl2(be, carry, 1);
+                    if (i == 2) CL = be.XOR(CL, be.sel(m2(1ull), n, be.zero()));
+                } else if (i == 3) {
+                    G = t; Pg = be.XOR(SL, CL);
+                } else {
+                    G = be.XOR(G, be.sel(m2(mA), t, be.zero()));
+                    Pg = be.sel(m2(mA), shl2(be, t, dist), Pg);
+                    dist <<= 1;
+                }
+            }
+            if (nb > 0) cp = be.sel(m2(1ull), shr2(be, G, nb - 1), be.zero());
+        }
+        // ---- phase B, per product: HIGH (lane i = bit 64 + i, bits below 64 + p matter) = L1|S1 + S0|C1 + C0 + S1 + C1 +- S2
+        // +- C2 - (sa & B) - (sb & A): steps 0..8 (5 and 7 form the sign corrections); steps 9, 10 add bits p..p+63 of
+        // the product to the accumulator, which takes the place of (SS, CC) for those two steps
+        const int nh = p;
         const uint64_t ah = lanes(nh);
         for (int h = 0; h < 2; h++) {
-            W SS = be.zero(), CC = be.zero();
-            if (nh > 0) {
-                W nn = be.bcast(n, 32 * h);
-                SS = be.XOR(half_lo(be, L1, h), half_hi(be, S1, h));
-                CC = be.XOR(half_lo(be, S0, h), half_hi(be, C1, h));
-                csa_ool(be, SS, CC, half_lo(be, C0, h), nh, be.sel(1ull, half_lo(be, o1, h), be.zero()));
-                csa_ool(be, SS, CC, half_lo(be, S1, h), nh, be.sel(1ull, half_lo(be, o2, h), be.zero()));
-                csa_ool(be, SS, CC, half_lo(be, C1, h), nh, be.sel(1ull, half_lo(be, o3, h), be.zero()));
-                csa_ool(be, SS, CC, be.sel(ah, be.XOR(half_lo(be, S2, h), nn), be.zero()), nh, be.sel(1ull, nn, be.zero()));
-                csa_ool(be, SS, CC, be.sel(ah, be.XOR(half_lo(be, C2, h), nn), be.zero()), nh, be.sel(1ull, nn, be.zero()));
-                // sign corrections -(sa & B) and -(sb & A), low p bits of the operand words at bit 64
-                W aw = be.load(h ? a1 : a0), bw = be.load(h ? b1 : b0);
-                W c1 = be.NOTm(be.AND_ool(bw, be.bcast(aw, 63), ah), ah);
-                csa_ool(be, SS, CC, c1, nh, be.sel(1ull, be.NOTm(nn, 1ull), be.zero()));
-                W c2 = be.NOTm(be.AND_ool(aw, be.bcast(bw, 63), ah), ah);
-                csa_ool(be, SS, CC, c2, nh, be.sel(1ull, be.konst(1ull), be.zero()));
-                SS = be.sel(ah, SS, be.zero());
-                CC = be.sel(ah, CC, be.zero());
+            W nn = be.bcast(n, 32 * h);
+            W SS = be.XOR(half_lo(be, sub[3], h), half_hi(be, sub[4], h));
+            W CC = be.XOR(half_lo(be, sub[1], h), half_hi(be, sub[5], h));
+            W aw = be.load(h ? a1 : a0), bw = be.load(h ? b1 : b0);
+            W X = be.zero(), Yacc = be.zero(), cin = be.zero();
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+            for (int i = (nh > 0 ? 0 : 9); i < 11; i++) {
+                W ga, gb;
+                uint64_t act = ah;
+                const bool corr = i == 5 || i == 7;
+                if (corr) {
+                    ga = i == 5 ? bw : aw;
+                    gb = be.bcast(i == 5 ? aw : bw, 63);
+                } else {
+                    if (i < 5) {
+                        const int k = i == 0 ? 2 : (i == 1 ? 4 : (i == 2 ? 5 : (i == 3 ? 7 : 8)));
+                        X = half_lo(be, sub[k], h);
+                        if (i >= 3) X = be.sel(ah, be.XOR(X, nn), be.zero());
+                        cin = i == 0 ? half_lo(be, o1, h) : (i == 1 ? half_lo(be, o2, h) : (i == 2 ? half_lo(be, o3, h) : nn));
+                    } else if (i == 6) {
+                        cin = be.NOTm(nn, 1ull);                   // X: the correction formed in step 5
+                    } else if (i == 8) {
+                        cin = be.konst(1ull);
+                    } else if (i == 9) {
+                        SS = be.sel(ah, SS, be.zero());
+                        CC = be.sel(ah, CC, be.zero());
+                        W LS = be.XOR(half_lo(be, sub[0], h), half_hi(be, SL, h)), LC = half_hi(be, CL, h);
+                        X = be.XOR(be.shr(LS, p), be.shl(SS, 64 - p));
+                        Yacc = be.XOR(be.shr(LC, p), be.shl(CC, 64 - p));
+                        SS = AS; CC = AC;
+                        cin = half_lo(be, cp, h);
+                        act = all;
+                    } else {                                        // i == 10
+                        X = Yacc;
+                        cin = be.zero();
+                        act = all;
+                    }
+                    ga = be.XOR(SS, X); gb = be.XOR(CC, X);
+                }
+                W t = be.AND(ga, gb, act);
+                if (corr) {
+                    X = be.NOTm(t, ah);
+                } else {
+                    W carry = be.XOR(t, be.sel(act, X, be.zero()));
+                    SS = be.XOR(be.XOR(SS, CC), X);
+                    CC = be.XOR(be.sel(act, be.shl(carry, 1), be.zero()), be.sel(1ull, cin, be.zero()));
+                }
             }
-            W LS = be.XOR(half_lo(be, L0, h), half_hi(be, SL, h)), LC = half_hi(be, CL, h);
-            W X = be.XOR(be.shr(LS, p), be.shl(SS, 64 - p)), Y = be.XOR(be.shr(LC, p), be.shl(CC, 64 - p));
-            csa_ool(be, AS, AC, X, 64, be.sel(1ull, half_lo(be, cp, h), be.zero()));
-            csa_ool(be, AS, AC, Y, 64, be.zero());
+            AS = SS; AC = CC;
+        }
+    }
+    // the products of one OP_MACK record: pairs (2k, 2k + 1); a last single product is paired with the zero word
+    static GC_HD void mack_rec(B &be, W &AS, W &AC, uint32_t a, uint32_t b, int32_t sa, int32_t sb, uint32_t cnt, uint32_t delta, int p) {
+        for (uint32_t k = 0; k < cnt; k += 2) {
+            const bool two = k + 1 < cnt;
+            const uint32_t a0 = a + (int32_t)k * sa, b0 = b + (int32_t)k * sb, a1 = two ? a0 + sa : 0u, b1 = two ? b0 + sb : 0u;
+            mack2(be, AS, AC, a0, a1, b0, b1, a0 + delta, two ? a1 + delta : 0u, b0 + delta, two ? b1 + delta : 0u, p);
         }
     }
 
@@ -542,7 +596,6 @@ struct PlainBackend {
         gates += (uint64_t)__builtin_popcountll(act);
         return a & b & act;
     }
-    GC_HD W AND_ool(W a, W b, uint64_t act) { return AND(a, b, act); }
     // two independent gate steps (numbered step, step+1) that a backend may run concurrently
     GC_HD void AND2(W a1, W b1, uint64_t act1, W a2, W b2, uint64_t act2, W &c1, W &c2) {
         c1 = AND(a1, b1, act1);

@@ -313,17 +313,6 @@ struct GpuBackend {
         xsel ^= 1;
         return and_quad(lt, R, a, b, gid, slot, on, wave, xch + xsel * 512, lane);
     }
-    // the gates of the Karatsuba recombination (Circ::mack2): ~17 call sites per product pair.  In the MAC kernel they share
-    // ONE out-of-line copy of the gate body -- inlined, 35 more copies of 4 AES-128 would push the kernel far beyond the
-    // instruction cache -- while the two gates of the array rows (84 % of the steps) stay inlined
-    __device__ __forceinline__ W AND_ool(W a, W b, uint64_t act) {
-        if (MODE != MODE_MAC) return AND(a, b, act);
-        const bool on = bit(act);
-        const uint64_t gid = step * 64 + (uint64_t)lane;
-        Lbl *slot = tab + (step - launch_step0) * 128 + lane;
-        step++;
-        return and_outlined(lt, R, a, b, gid, slot, on);
-    }
     __device__ __forceinline__ void AND2(W a1, W b1, uint64_t act1, W a2, W b2, uint64_t act2, W &c1, W &c2) {
         if (MODE != MODE_QUAD) {
             c1 = AND(a1, b1, act1);
@@ -514,6 +503,9 @@ struct GpuBackend {
     __device__ __forceinline__ W load2h(uint32_t lo, uint32_t hi) const {
         return ld_lbl(words + (size_t)(lane < 32 ? lo : hi) * 64 + 32 + (lane & 31));
     }
+    __device__ __forceinline__ W load2s(uint32_t lo, uint32_t hi, bool upper) const {
+        return ld_lbl(words + (size_t)(lane < 32 ? lo : hi) * 64 + (upper ? 32 : 0) + (lane & 31));
+    }
     __device__ __forceinline__ void store2(uint32_t lo, uint32_t hi, W v) {
         if (MODE != MODE_QUAD || wave == 0) st_lbl(words + (size_t)(lane < 32 ? lo : hi) * 64 + (lane & 31), v);
     }
@@ -582,18 +574,6 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
         uint32_t s_hi = __builtin_amdgcn_readfirstlane((uint32_t)(r.step0 >> 32));
         be.step = ((uint64_t)s_hi << 32) | s_lo;
         Lbl S = lzero(), Cc = lzero();
-        if (__builtin_amdgcn_readfirstlane(r.op) == OP_MACK) {
-            const uint32_t delta = __builtin_amdgcn_readfirstlane(r.c);
-            uint32_t k = 0;
-            for (; k + 1 < r.cnt; k += 2) {
-                const uint32_t a0 = r.a + (int32_t)k * r.sa, b0 = r.b + (int32_t)k * r.sb;
-                C::mack2(be, S, Cc, a0, a0 + r.sa, b0, b0 + r.sb, delta, p);
-            }
-            if (k < r.cnt) C::mac(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
-            be.store(r.dst, S);
-            be.store(r.dst + 1, Cc);
-            continue;
-        }
         if (__builtin_amdgcn_readfirstlane(r.op) == OP_MAC2) {
             for (uint32_t k = 0; k < r.cnt; k++)
                 C::mac2(be, S, Cc, be.load2(r.a + (int32_t)k * r.sa, r.a + (int32_t)(r.cnt + k) * r.sa),
@@ -607,6 +587,47 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
         be.store(r.dst, S);
         be.store(r.dst + 1, Cc);
     }
+}
+
+// OP_MACK launches (Karatsuba products, Circ::mack2): the same geometry as gc_mac_kernel, in a kernel of its own.  Four
+// inlined gate bodies: the two of the 32 x 32 array loop (one copy: the three arrays of a pair are one loop) and one in
+// each of the two recombination loops; the nine sub-product words of a pair wait in scratch memory meanwhile.
+// (Out-of-line gates for the recombination, or one kernel for OP_MAC and OP_MACK together, measured no faster / slower:
+// the combined kernel spilled 175 VGPRs.)
+template <bool GARBLER, int TPB>
+__global__ void __launch_bounds__(TPB)
+gc_mack_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
+    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    lds_tab4_fill(lds_te0);
+    typedef GpuBackend<GARBLER, MODE_MAC, LdsTab4> B;
+    B be;
+    be.R = R;
+    be.words = words;
+    be.tab = tab;
+    be.decode = 0;
+    be.xsel = 0;
+    be.launch_step0 = launch_step0;
+    be.lane = threadIdx.x & 63;
+    be.wave = 0;
+    be.xch = 0;
+    be.lt = lds_tab4_make(lds_te0);
+    const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid >= nrec) return;
+    Rec r = recs[wid];
+    r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);
+    r.dst = __builtin_amdgcn_readfirstlane(r.dst);
+    r.a = __builtin_amdgcn_readfirstlane(r.a);
+    r.b = __builtin_amdgcn_readfirstlane(r.b);
+    r.c = __builtin_amdgcn_readfirstlane(r.c);
+    r.sa = __builtin_amdgcn_readfirstlane(r.sa);
+    r.sb = __builtin_amdgcn_readfirstlane(r.sb);
+    uint32_t s_lo = __builtin_amdgcn_readfirstlane((uint32_t)r.step0);
+    uint32_t s_hi = __builtin_amdgcn_readfirstlane((uint32_t)(r.step0 >> 32));
+    be.step = ((uint64_t)s_hi << 32) | s_lo;
+    Lbl S = lzero(), Cc = lzero();
+    Circ<B>::mack_rec(be, S, Cc, r.a, r.b, r.sa, r.sb, r.cnt, r.c, p);
+    be.store(r.dst, S);
+    be.store(r.dst + 1, Cc);
 }
 
 // every other record type.  QUAD = true: one 4-wave workgroup per record (narrow, latency-bound

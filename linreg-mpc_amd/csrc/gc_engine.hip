@@ -322,6 +322,7 @@ struct lgc_solver {
     std::vector<double> t_iter;
     bool have_shares, ran;
     bool prefix_ready;    // sweep: input labels and prefix tables are in place (garbled here or imported)
+    bool prefix_imported = false;
     lgc_stats st;
     lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), streamE(0), streamT(0), ev0(0), ev1(0), ev_in(0), ring_bytes(0), tab_alloc_bytes(0),
                    have_shares(false), ran(false), prefix_ready(false) { memset(&st, 0, sizeof(st)); }
@@ -498,7 +499,11 @@ extern "C" int lgc_solver_set_shares(lgc_solver *s, const uint64_t *shares) {
 
 extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
     if (!s) return lgc_fail(LGC_EINVAL, "null solver");
-    if (!s->have_shares) return lgc_fail(LGC_ESTATE, "lgc_solver_set_shares has not been called");
+    // input labels come either from the shares on this device or with an imported prefix; an importing rank that runs
+    // twice needs a new import (its prefix words were valid for ONE run and it never had the shares)
+    if (!s->have_shares && !s->prefix_ready)
+        return lgc_fail(LGC_ESTATE, s->prefix_imported ? "the imported prefix has been consumed: import again before the next run"
+                                                       : "lgc_solver_set_shares has not been called");
     HIPCHK(hipSetDevice(s->device));
     const Program &P = s->P;
     size_t wbytes = (size_t)P.n_words * 64 * sizeof(Lbl);
@@ -699,8 +704,8 @@ extern "C" int lgc_solver_prefix_import(lgc_solver *s, const void *dev_buf) {
     HIPCHK(hipSetDevice(s->device));
     int rc = prefix_copy(s, const_cast<char *>(static_cast<const char *>(dev_buf)), false);
     if (rc) return rc;
-    s->prefix_ready = true;
-    s->have_shares = true;        // the evaluator's input labels came with the prefix
+    s->prefix_ready = true;       // the evaluator's input labels came with the prefix (s->vals stays unset: have_shares
+    s->prefix_imported = true;    // is NOT touched -- a later run without a fresh import fails instead of garbling garbage)
     return LGC_OK;
 }
 

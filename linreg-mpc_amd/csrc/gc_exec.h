@@ -77,12 +77,7 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
     } break;
     case OP_MACK: {
         W S = be.zero(), Cc = be.zero();
-        uint32_t k = 0;
-        for (; k + 1 < r.cnt; k += 2) {
-            const uint32_t a0 = r.a + (int32_t)k * r.sa, a1 = a0 + r.sa, b0 = r.b + (int32_t)k * r.sb, b1 = b0 + r.sb;
-            C::mack2(be, S, Cc, a0, a1, b0, b1, r.c, p);
-        }
-        if (k < r.cnt) C::mac(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
+        C::mack_rec(be, S, Cc, r.a, r.b, r.sa, r.sb, r.cnt, r.c, p);
         be.store(r.dst, S);
         be.store(r.dst + 1, Cc);
     } break;
@@ -178,6 +173,7 @@ struct PlainMachine : PlainBackend {
     W load2(uint32_t lo, uint32_t hi) const { return (words[lo] & 0xffffffffull) | (words[hi] << 32); }
     // lanes 32..63 of word lo in lanes 0..31 | lanes 32..63 of word hi
     W load2h(uint32_t lo, uint32_t hi) const { return (words[lo] >> 32) | (words[hi] & 0xffffffff00000000ull); }
+    W load2s(uint32_t lo, uint32_t hi, bool upper) const { return upper ? load2h(lo, hi) : load2(lo, hi); }
     void store2(uint32_t lo, uint32_t hi, W v) { words[lo] = v & 0xffffffffull; words[hi] = v >> 32; }
     void reveal(uint32_t slot, W v) { if (decode) decode[slot] = v; }
 };
@@ -194,6 +190,7 @@ inline void rec_cost(const Rec &r, int w, int p, uint64_t &steps, uint64_t &gate
         W load(uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
         W load2(uint32_t, uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
         W load2h(uint32_t, uint32_t) const { return 0x5a5a5a5a5a5a5a5aull; }
+        W load2s(uint32_t, uint32_t, bool) const { return 0x5a5a5a5a5a5a5a5aull; }
         void store(uint32_t, W) {}
         void store2(uint32_t, uint32_t, W) {}
         void reveal(uint32_t, W) {}

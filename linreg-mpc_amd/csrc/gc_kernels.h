@@ -52,6 +52,11 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
         hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3(wgs), dim3(per * 64), 0, st, recs + L.first_rec, L.nrec, words, tab,
                            L.step0, R, w, p);
     } break;
+    case LM_MACK: if constexpr (PART == 0) {
+        constexpr int TPB = G ? kTpbMackG : kTpbMackE;
+        hipLaunchKernelGGL((gc_mack_kernel<G, TPB>), dim3((L.nrec + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, st, recs + L.first_rec,
+                           L.nrec, words, tab, L.step0, R, w, p);
+    } break;
     case LM_WIDE: if constexpr (PART == 1) {
         // records (waves) per workgroup: as few as keep the launch within one workgroup per CU, at most TPB / 64 --
         // a launch of 800 dividers runs as 200 workgroups of 4 waves, one round, instead of 67 CUs with 12 waves each

@@ -22,6 +22,13 @@ namespace gc {
 #define GC_TPB_MACE 768
 #endif
 static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
+#ifndef GC_TPB_MACKG
+#define GC_TPB_MACKG 1024
+#endif
+#ifndef GC_TPB_MACKE
+#define GC_TPB_MACKE 768
+#endif
+static constexpr int kTpbMackG = GC_TPB_MACKG, kTpbMackE = GC_TPB_MACKE;
 #ifndef GC_MAC_EXCLUSIVE
 #define GC_MAC_EXCLUSIVE 1
 #endif
@@ -143,6 +150,7 @@ static inline unsigned gc_mac_waves(uint32_t nrec, unsigned lo, unsigned hi) {
 enum LaunchMode {
     LM_NONE = 0,     // no records
     LM_MAC,          // gc_mac_kernel: one wave per record, throughput
+    LM_MACK,         // gc_mack_kernel: the same for OP_MACK records (Karatsuba products)
     LM_WIDE,         // gc_exec_kernel<.., false, 4, ..>: one wave per generic record
     LM_SPLIT,        // gc_split_kernel: 16 waves per record, column-split (garbler: critical path + table pass)
     LM_QUAD4,        // GC_QUAD4 builds only: 4 waves per record on the four-table image (garbler: critical path + table pass)
@@ -150,7 +158,7 @@ enum LaunchMode {
 };
 static inline LaunchMode gc_launch_mode(const Launch &L, bool garbler) {
     if (L.nrec == 0) return LM_NONE;
-    if (L.mac_only && L.nrec >= kNarrowMac) return LM_MAC;
+    if (L.mac_only && L.nrec >= kNarrowMac) return L.mack ? LM_MACK : LM_MAC;
     if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) return LM_WIDE;
     if (GC_SPLIT && L.nrec <= kSplitMaxRecs && gc_split_enabled(garbler).load(std::memory_order_relaxed)) return LM_SPLIT;
     if (GC_QUAD4 && L.nrec <= kQuadOnePerCu) return LM_QUAD4;
@@ -192,7 +200,7 @@ static inline hipError_t gc_launch_records(LaunchMode m, const Rec *recs, const 
                                           int w, int p, hipStream_t st) {
     switch (m) {
     case LM_NONE: return hipSuccess;
-    case LM_MAC: return G ? gc_launch_records_g_0(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_0(m, recs, L, words, dec, tab, R, w, p, st);
+    case LM_MAC: case LM_MACK: return G ? gc_launch_records_g_0(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_0(m, recs, L, words, dec, tab, R, w, p, st);
     case LM_SPLIT: return G ? gc_launch_records_g_2(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_2(m, recs, L, words, dec, tab, R, w, p, st);
     case LM_WIDE: return G ? gc_launch_records_g_1(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_1(m, recs, L, words, dec, tab, R, w, p, st);
     default: return G ? gc_launch_records_g_3(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_3(m, recs, L, words, dec, tab, R, w, p, st);

@@ -11,6 +11,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
 #include <map>
 #include <utility>
 #include <vector>
@@ -33,6 +34,7 @@ struct Launch {
     uint64_t step0, steps;      // gate steps covered
     uint64_t gates;             // active AND gates
     bool mac_only;
+    bool mack;                  // mac_only launch whose records are OP_MACK (Karatsuba products: a kernel of their own)
 };
 
 enum Alg { ALG_CHOLESKY = 0, ALG_LDLT = 1, ALG_CGD = 2 };
@@ -102,7 +104,8 @@ struct Program {
         uint64_t s, g;
         cost(r, s, g);
         bool mac = (r.op == OP_MAC || r.op == OP_MAC2 || r.op == OP_MACK);
-        if (!open || launches.back().steps + s > cap_steps || launches.back().mac_only != mac) {
+        const bool mack = r.op == OP_MACK;
+        if (!open || launches.back().steps + s > cap_steps || launches.back().mac_only != mac || launches.back().mack != mack) {
             Launch L;
             L.first_rec = (uint32_t)recs.size();
             L.nrec = 0;
@@ -110,6 +113,7 @@ struct Program {
             L.steps = 0;
             L.gates = 0;
             L.mac_only = mac;
+            L.mack = mack;
             launches.push_back(L);
             open = true;
         }
@@ -186,12 +190,22 @@ struct Program {
                     nparts += 4;
                     k0 += 2 * len;
                 } else {
-                    uint32_t len = left < chunk ? left : (uint32_t)chunk;
-                    if (J.kdelta && w == 64) out.push_back(mk(OP_MACK, cur, J.a + k0, J.b + k0, J.kdelta, len));
-                    else out.push_back(mk(OP_MAC, cur, J.a + k0, J.b + k0, 0, len));
-                    cur += 2;
-                    nparts += 2;
-                    k0 += len;
+                    // ceil(len / chunk) records of (nearly) equal length rather than full chunks and a remainder: the
+                    // records of a launch run in lock step, round by round.  Karatsuba records take their products two
+                    // at a time: even lengths (a single leftover product would be paired with the zero word)
+                    const uint32_t nrec_job = (uint32_t)((left + chunk - 1) / chunk);      // (w == 32: `left` is the odd last product)
+                    const bool kara = J.kdelta && w == 64;
+                    const uint32_t unit = kara ? 2u : 1u, units = (left + unit - 1) / unit;
+                    for (uint32_t q = 0; q < nrec_job && k0 < J.len; q++) {
+                        uint32_t un = units / nrec_job + (q < units % nrec_job ? 1u : 0u);
+                        uint32_t len = un * unit;
+                        if (len > J.len - k0) len = J.len - k0;
+                        if (!len) continue;
+                        out.push_back(mk(kara ? OP_MACK : OP_MAC, cur, J.a + k0, J.b + k0, kara ? J.kdelta : 0, len));
+                        cur += 2;
+                        nparts += 2;
+                        k0 += len;
+                    }
                 }
             }
             parts[i].second = nparts;
@@ -241,6 +255,9 @@ struct Program {
             best_launches = 0;
         }
         new_launch();
+        // longest records first: a round of the chip then holds records of one length (the records of a launch are
+        // independent, so their order is free)
+        std::stable_sort(recs_best.begin(), recs_best.end(), [](const Rec &x, const Rec &y) { return x.cnt > y.cnt; });
         const size_t R = recs_best.size();
         const size_t per = best_launches ? (R + best_launches - 1) / best_launches : R;
         for (size_t i = 0; i < R; i++) {

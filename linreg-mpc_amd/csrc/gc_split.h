@@ -268,6 +268,7 @@ struct SplitBackend {
     __device__ __forceinline__ W load2h(uint32_t lo, uint32_t hi) const {
         return ld_u32_global(col(words + (size_t)(lane < 32 ? lo : hi) * 64 + 32 + (lane & 31)));
     }
+    __device__ __forceinline__ W load2s(uint32_t lo, uint32_t hi, bool upper) const { return upper ? load2h(lo, hi) : load2(lo, hi); }
     __device__ __forceinline__ void store(uint32_t id, W v) { st_u32_global(col(words + (size_t)id * 64 + lane), v); }
     __device__ __forceinline__ void store2(uint32_t lo, uint32_t hi, W v) {
         st_u32_global(col(words + (size_t)(lane < 32 ? lo : hi) * 64 + (lane & 31)), v);
@@ -299,7 +300,6 @@ struct SplitBackend {
         lds_barrier();
         return bit(act) ? (result(0) ^ result(1)) : 0u;
     }
-    __device__ __forceinline__ W AND_ool(W a, W b, uint64_t act) { return AND(a, b, act); }
     __device__ __forceinline__ void AND2(W a1, W b1, uint64_t act1, W a2, W b2, uint64_t act2, W &c1, W &c2) {
         SplitDesc d = {2u, act1, act2, step};
         step += 2;

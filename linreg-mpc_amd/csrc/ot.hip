@@ -307,7 +307,7 @@ struct DevBuf {
     DevBuf() : p(0), cap(0) {}
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p) { (void)hipMemset(p, 0, cap); (void)hipFree(p); }   // q-rows / messages never stay behind in freed memory
         p = 0; cap = 0;
         size_t want = bytes + bytes / 8;                  // headroom: batches of slightly different size do not reallocate
         hipError_t e = hipMalloc(&p, want);

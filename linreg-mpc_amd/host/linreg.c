@@ -242,7 +242,9 @@ int main(int argc, char **argv) {
             check(!send_blob(self, k, e, bits * 32), "OT: could not send to party %d", k);
             lgc_ot_sender_destroy(S);
         }
+        memset(m0, 0, bits * 16); memset(m1, 0, bits * 16);              /* both labels of every input bit: their XOR is R */
         lgc_host_free(m0); lgc_host_free(m1); lgc_host_free(u); lgc_host_free(e);
+        memset(jobs, 0, (size_t)P * sizeof *jobs);                        /* base-OT delta and seeds */
         free(jobs);
         TRACE("input labels sent");
         if (n_devices) {

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/time.h>
 #include <sys/socket.h>
 #include <time.h>
 #include <unistd.h>
@@ -168,39 +169,68 @@ void node_destroy(node **nn) {
     *nn = 0;
 }
 
-typedef struct { uint32_t k, port; } lane_offer;
+/* Extra connections to a peer (table links of bin/linreg --devices, --table_lanes).  The offering side listens on the
+ * LOCAL ADDRESS OF THE PARTY CONNECTION only, tells the peer port and a random 16-byte cookie over that connection,
+ * and accepts a lane only from the peer's address and only with the cookie; accept and the cookie read time out. */
+typedef struct { uint32_t k, port; uint8_t cookie[16]; } lane_offer;
+typedef struct { uint32_t lane; uint8_t cookie[16]; } lane_hello;
+enum { kLaneTimeoutSec = 30 };
+static void set_timeouts(int s, int sec) {
+    struct timeval tv = {sec, 0};
+    (void)setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    (void)setsockopt(s, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+}
 int net_lanes_offer(node *n, int peer, int k, int *fds) {
     if (peer < 1 || peer > n->num_parties || n->fd[peer - 1] < 0 || k < 0) return -1;
-    if (k == 0) {                                        /* "no lanes": the peer still expects the offer */
-        lane_offer none = {0, 0};
-        return net_send(n, peer, &none, sizeof none) ? -1 : 0;
-    }
+    lane_offer o;
+    memset(&o, 0, sizeof o);
+    if (k == 0) return net_send(n, peer, &o, sizeof o) ? -1 : 0;      /* "no lanes": the peer still expects the offer */
+    struct sockaddr_in sa, pa;
+    socklen_t sl = sizeof sa, pl = sizeof pa;
+    if (getsockname(n->fd[peer - 1], (struct sockaddr *)&sa, &sl) < 0 || sa.sin_family != AF_INET) return -1;
+    if (getpeername(n->fd[peer - 1], (struct sockaddr *)&pa, &pl) < 0 || pa.sin_family != AF_INET) return -1;
     int ls = socket(AF_INET, SOCK_STREAM, 0);
     if (ls < 0) return -1;
-    struct sockaddr_in sa;
-    memset(&sa, 0, sizeof sa);
-    sa.sin_family = AF_INET; sa.sin_port = 0; sa.sin_addr.s_addr = INADDR_ANY;
-    socklen_t sl = sizeof sa;
+    sa.sin_port = 0;                                     /* the interface the peer already reaches us on, any free port */
+    sl = sizeof sa;
     if (bind(ls, (struct sockaddr *)&sa, sizeof sa) < 0 || listen(ls, k) < 0 || getsockname(ls, (struct sockaddr *)&sa, &sl) < 0) {
         close(ls);
         return -1;
     }
-    lane_offer o = {(uint32_t)k, (uint32_t)ntohs(sa.sin_port)};
+    o.k = (uint32_t)k; o.port = (uint32_t)ntohs(sa.sin_port);
+    FILE *ur = fopen("/dev/urandom", "rb");
+    if (!ur || fread(o.cookie, 1, sizeof o.cookie, ur) != sizeof o.cookie) { if (ur) fclose(ur); close(ls); return -1; }
+    fclose(ur);
     if (net_send(n, peer, &o, sizeof o)) { close(ls); return -1; }
+    net_flush(n, peer);
     for (int i = 0; i < k; i++) fds[i] = -1;
-    for (int i = 0; i < k; i++) {
-        int s = accept(ls, 0, 0);
-        uint32_t lane = 0;
-        if (s < 0 || io_all(s, &lane, sizeof lane, 0) || lane >= (uint32_t)k || fds[lane] >= 0) {
-            if (s >= 0) close(s);
-            for (int j = 0; j < k; j++) if (fds[j] >= 0) close(fds[j]);
-            close(ls);
-            return -1;
+    set_timeouts(ls, kLaneTimeoutSec);                   /* accept() honours SO_RCVTIMEO */
+    int got = 0, strays = 0;
+    while (got < k) {
+        struct sockaddr_in ca;
+        socklen_t cl = sizeof ca;
+        int s = accept(ls, (struct sockaddr *)&ca, &cl);
+        if (s < 0) break;                                /* timed out or failed */
+        lane_hello h;
+        set_timeouts(s, kLaneTimeoutSec);
+        unsigned char diff = 0;
+        int ok = ca.sin_family == AF_INET && ca.sin_addr.s_addr == pa.sin_addr.s_addr && !io_all(s, &h, sizeof h, 0);
+        if (ok) { for (size_t b = 0; b < sizeof o.cookie; b++) diff |= (unsigned char)(h.cookie[b] ^ o.cookie[b]); }
+        if (!ok || diff || h.lane >= (uint32_t)k || fds[h.lane] >= 0) {       /* not our peer: drop it and keep listening */
+            close(s);
+            if (++strays > 64) break;
+            continue;
         }
+        set_timeouts(s, 0);
         tune_socket(s);
-        fds[lane] = s;
+        fds[h.lane] = s;
+        got++;
     }
     close(ls);
+    if (got < k) {
+        for (int j = 0; j < k; j++) if (fds[j] >= 0) { close(fds[j]); fds[j] = -1; }
+        return -1;
+    }
     return 0;
 }
 int net_lanes_accept_offer(node *n, int peer, int max_k, int *k, int *fds) {
@@ -214,8 +244,11 @@ int net_lanes_accept_offer(node *n, int peer, int max_k, int *k, int *fds) {
     if (getpeername(n->fd[peer - 1], (struct sockaddr *)&sa, &sl) < 0 || sa.sin_family != AF_INET) return -1;
     sa.sin_port = htons((uint16_t)o.port);
     for (uint32_t i = 0; i < o.k; i++) {
+        lane_hello h;
+        h.lane = i;
+        memcpy(h.cookie, o.cookie, sizeof h.cookie);
         int s = socket(AF_INET, SOCK_STREAM, 0);
-        if (s < 0 || connect(s, (struct sockaddr *)&sa, sizeof sa) < 0 || io_all(s, &i, sizeof i, 1)) {
+        if (s < 0 || connect(s, (struct sockaddr *)&sa, sizeof sa) < 0 || io_all(s, &h, sizeof h, 1)) {
             if (s >= 0) close(s);
             for (uint32_t j = 0; j < i; j++) close(fds[j]);
             return -1;

@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/socket.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -284,8 +285,8 @@ static int table_pipe_start(table_pipe *t, void *(*fn)(void *), pthread_t *th, t
     for (int l = 0; l < workers; l++) {
         w[l].t = t; w[l].lane = l;
         if (pthread_create(&th[l], NULL, fn, &w[l])) {
-            table_pipe_fail(t);
-            for (int j = 0; j < l; j++) { pthread_cancel(th[j]); pthread_join(th[j], NULL); }
+            table_pipe_fail(t);                           /* the workers already running see `failed` and leave */
+            for (int j = 0; j < l; j++) pthread_join(th[j], NULL);
             return 1;
         }
     }
@@ -293,11 +294,14 @@ static int table_pipe_start(table_pipe *t, void *(*fn)(void *), pthread_t *th, t
 }
 static void table_pipe_stop(table_pipe *t, pthread_t *th) {
     const int workers = t->lanes > 0 ? t->lanes : 1;
-    const int failed = table_pipe_failed(t);
-    for (int l = 0; l < workers; l++) {
-        if (failed) pthread_cancel(th[l]);               /* a worker may sit in send() / recv() on a dead peer */
-        pthread_join(th[l], NULL);
+    /* No pthread_cancel: a worker cancelled inside pthread_cond_wait would die holding t->mu and hang everyone else.
+     * After a failure the condition variable has been broadcast (workers in table_pipe_take / _acquire see `failed` and
+     * leave); a worker inside send() / recv() on a dead peer is released by shutting its socket down. */
+    if (table_pipe_failed(t)) {
+        for (int l = 0; l < t->lanes; l++) if (t->fd[l] >= 0) shutdown(t->fd[l], SHUT_RDWR);
+        if (t->lanes == 0 && t->self && t->peer >= 1 && t->self->fd[t->peer - 1] >= 0) shutdown(t->self->fd[t->peer - 1], SHUT_RDWR);
     }
+    for (int l = 0; l < workers; l++) pthread_join(th[l], NULL);
 }
 
 /* ---- ring mode as a link: one (garbler block, evaluator block) pair, its hipIpc ring, and the byte channel that carries

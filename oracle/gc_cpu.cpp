@@ -131,9 +131,9 @@ struct CpuBackend {
         c1 = AND(a1, b1, act1);
         c2 = AND(a2, b2, act2);
     }
-    W AND_ool(const W &a, const W &b, uint64_t act) { return AND(a, b, act); }
     W load(uint32_t id) const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_loadu_si128(words + (size_t)id * 64 + i); return r; }
     W load2(uint32_t lo, uint32_t hi) const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_loadu_si128(words + (size_t)(i < 32 ? lo : hi) * 64 + (i & 31)); return r; }
+    W load2s(uint32_t lo, uint32_t hi, bool upper) const { return upper ? load2h(lo, hi) : load2(lo, hi); }
     W load2h(uint32_t lo, uint32_t hi) const { W r; for (int i = 0; i < 64; i++) r.l[i] = _mm_loadu_si128(words + (size_t)(i < 32 ? lo : hi) * 64 + 32 + (i & 31)); return r; }
     void store2(uint32_t lo, uint32_t hi, const W &v) { for (int i = 0; i < 64; i++) _mm_storeu_si128(words + (size_t)(i < 32 ? lo : hi) * 64 + (i & 31), v.l[i]); }
     void store(uint32_t id, const W &v) { for (int i = 0; i < 64; i++) _mm_storeu_si128(words + (size_t)id * 64 + i, v.l[i]); }

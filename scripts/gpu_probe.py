@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python"))
 import numpy as np
 import linreg_gc as lgc
 
+if os.environ.get("LGC_KARATSUBA") == "0":      # A/B: plain 64 x 64 array in the matrix-vector products
+    lgc.set_karatsuba(False)
 print("devices", lgc.device_count(), flush=True)
 for waves, bpl in ((4096, 64), (16384, 256), (65536, 256)):
     r, c = lgc.aes_bench(waves, bpl)

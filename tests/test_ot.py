@@ -135,3 +135,32 @@ def test_gpu_phase1_ot_mode_shares(lgc, oracle):
     for t, j in enumerate((0, 1)):
         assert (int(ss[4 + t]) + int(sr[4 + t])) & m == int(b[j])
     S.close(); R.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,p", [(64, 56), (32, 30)])
+def test_gpu_gilboa_mid_size_against_semantic_oracle(lgc, oracle, w, p):
+    """Gilboa inner products at n = 1000, 32 pairs (2.0e6 / 1.0e6 extended OTs in one batch, several trips of every
+    kernel loop, grid.y striding) against the SEMANTIC oracle -- the wrap-around inner products of the quantised
+    columns that src/phase1.c:43-96 shares -- not against the CPU mirror of the protocol: share_sender + share_receiver
+    == <a_q, b_q> mod 2^w for every pair, at both widths."""
+    rng = np.random.default_rng(1000 + w)
+    n, npairs, d = 1000, 32, 8
+    X = rng.standard_normal((n, d)); X /= np.abs(X).max(axis=0)
+    Xq = oracle.quantize(X, p, n, w).reshape(n, d)
+    mask = (1 << w) - 1
+    U = lambda v: (np.ascontiguousarray(v).astype(np.int64).view(np.uint64) & np.uint64(mask))
+    cols = [(int(rng.integers(0, d)), int(rng.integers(0, d))) for _ in range(npairs)]
+    a = np.stack([U(Xq[:, i]) for i, _ in cols]); b = np.stack([U(Xq[:, j]) for _, j in cols])
+    seeds0, seeds1, delta, seeds_s = _setup(rng)
+    S = lgc.OtSender(delta.tobytes(), seeds_s); R = lgc.OtReceiver(seeds0, seeds1)
+    for rep in range(2):                                   # a second batch on the same session: stream / tweak counters advance
+        u = R.gilboa_start(a, w)
+        y, ss = S.gilboa(b, w, u)
+        sr = R.gilboa_finish(y)
+        for q, (i, j) in enumerate(cols):
+            exp = oracle.inner_product_wrap(Xq[:, i], Xq[:, j], w) if hasattr(oracle, "inner_product_wrap") else \
+                (sum(int(x) * int(z) for x, z in zip(Xq[:, i].tolist(), Xq[:, j].tolist())) & mask)
+            assert (int(ss[q]) + int(sr[q])) & mask == exp, (w, rep, q)
+        assert len(set(int(v) for v in ss)) > npairs // 2     # the shares are masks, not the answers
+    S.close(); R.close()
