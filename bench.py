@@ -163,7 +163,7 @@ def two_process_ring(np, d, iters, p, Af, bf, gates, device_index):
     port = _free_ports(1)[0]
     env = dict(os.environ, LINREG_DEVICE=str(device_index))
     t0 = time.perf_counter()
-    procs = [subprocess.Popen([exe, str(port), str(k), path, "cgd", str(iters), str(p), "--host=127.0.0.1", "--table_ring=8"],
+    procs = [subprocess.Popen([exe, str(port), str(k), path, "cgd", str(iters), str(p), "--host=127.0.0.1", "--table_ring=4"],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for k in (1, 2)]
     outs = [q.communicate(timeout=900) for q in procs]
     wall = time.perf_counter() - t0
@@ -334,10 +334,9 @@ def main():
     # exclusive per-kernel durations (HIP events on the launching stream)
     solver.run(profile=True)
     stx = solver.stats()
-    # the table ring of this solver is its one large allocation (twice the largest launch: 113 GB at d = 500): gone
-    # before the sweep and the separate-process runs below bring their own
+    # the table ring of this solver is its one large allocation (largest launch + 8 GiB: 69 GB at d = 500).  close() parks
+    # it for the next solver on this device -- the sweep below takes it over instead of allocating its own
     solver.close()
-    lgc.release_cached_memory()
     gates = st["and_gates"]
     total_gates = gates * args.steps * world
     value = total_gates / elapsed
@@ -401,6 +400,7 @@ def main():
                          "sharding": "contiguous blocks of %d lambdas per rank; prefix (input labels + share-summation tables) garbled once on rank 0" % ((nl + world - 1) // world)}
             sweep_check = (stot, sT, sd, sit, lams, sres, nl)      # compared with the oracle in the cpu_baseline leg
 
+    lgc.release_cached_memory()          # the separate-process runs below bring their own rings
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel (garbling of the MAC launches), HIP events on its stream

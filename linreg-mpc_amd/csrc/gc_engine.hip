@@ -226,7 +226,7 @@ static int check_sweep(const lgc_system *sys, size_t count, const double *lambda
 // the merged program of `count` circuits; cap_steps as for build()
 static int build_sweep(Program &P, const lgc_system *sys, size_t count, const double *lambdas, size_t first, uint64_t cap_steps = 0) {
     Program base;
-    build(base, sys, cap_steps, count);
+    build(base, sys, cap_steps ? cap_steps : kSweepCapSteps, count);
     if ((uint64_t)base.n_words * count >= (1ull << 31)) return lgc_fail(LGC_EINVAL, "sweep too large: %zu circuits x %u words", count, base.n_words);
     std::vector<uint64_t> lf(count);
     for (size_t t = 0; t < count; t++) lf[t] = lambda_to_fixed(lambdas[t], sys->precision, sys->width);
@@ -460,8 +460,8 @@ static int solver_create(lgc_solver **out, int device, const lgc_system *sys, co
     TRY(hipEventCreate(&s->ev0));
     TRY(hipEventCreate(&s->ev1));
     TRY(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
-    // Table ring of twice the largest launch: the garbler of a large (MAC) launch overlaps the
-    // evaluator of the previous one, and runs many small (divider, reveal) launches ahead of it.
+    // Table ring: the largest launch plus up to 8 GiB for the small launches (dividers, merges, reveals) that the garbler
+    // runs ahead of the evaluator (plan_table_ring)
     s->ring_bytes = plan_table_ring(P, 0, s->tab_off, s->tab_wait);
     TRY(hipMalloc(&s->wordsG, wbytes));
     TRY(hipMalloc(&s->wordsE, wbytes));

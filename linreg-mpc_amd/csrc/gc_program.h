@@ -28,6 +28,10 @@ static const size_t kMinRecsPerLaunch = 8192;   // >= 2x the chip's resident wav
 // rounds for five rounds of work -- with 2^25 it is ONE launch of 15.3 / 20.3 rounds.  The table ring is twice the
 // largest launch: 113 GB of the 288 GB of an MI355X at d = 500.
 static const uint64_t kDefaultCapSteps = 1ull << 25;
+// ... a merged sweep program is cut into equal round-shaped pieces anyway (replicate_program): 2^24 there, so that the ring
+// of a sweep block (32 + 8 GiB) fits the one a d = 500 solver leaves parked (56 + 8 GiB) and need not be allocated afresh
+static const uint64_t kSweepCapSteps = 1ull << 24;
+static const size_t kRingSlackBytes = (size_t)8 << 30;
 
 struct Launch {
     uint32_t first_rec, nrec;   // slice of Program::recs
@@ -710,12 +714,15 @@ inline void replicate_program(Program &P, const Program &P0, size_t count, const
 // ring of `ring_bytes`, allocated in launch order with wrap-around; before the garbler overwrites the
 // range it waits for the evaluation of wait[i], the newest earlier launch whose range overlaps (the
 // evaluator runs in launch order, so every older overlapping launch is done by then too; -1: none).
-// ring_bytes == 0 picks twice the largest launch.  Returns the ring size.
+// ring_bytes == 0 picks the largest launch plus room for what runs ahead of its evaluation: as much again, at most
+// kRingSlackBytes (the large launches are the MAC launches, which alternate garble / evaluate anyway; what does run ahead
+// are the small launches between them -- merges, inner products, dividers, reveals: tens of MB per iteration).  Returns the
+// ring size.
 inline size_t plan_table_ring(const Program &P, size_t ring_bytes, std::vector<size_t> &off, std::vector<int64_t> &wait) {
     const size_t align = 4096, nl = P.launches.size();
     const size_t tbytes = (size_t)P.max_launch_steps * 2048;
     const size_t min_ring = (tbytes + align - 1) / align * align;
-    if (ring_bytes == 0) ring_bytes = 2 * min_ring + align;
+    if (ring_bytes == 0) ring_bytes = min_ring + (min_ring < kRingSlackBytes ? min_ring : kRingSlackBytes) + align;
     if (ring_bytes < min_ring) ring_bytes = min_ring;
     off.resize(nl);
     wait.assign(nl, -1);

@@ -154,7 +154,9 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
     const Program &P = p->P;
     size_t wbytes = (size_t)P.n_words * 64 * sizeof(Lbl);
     hipError_t e;
-    if ((e = hipMalloc(&p->words, wbytes)) != hipSuccess || (e = hipMalloc(&p->tab, P.max_launch_steps * 2048 + 16)) != hipSuccess ||
+    // (p->tab -- one launch of tables: socket mode, and the garbler's private stash in ring mode -- is allocated on first
+    // use: an evaluator that reads its tables from the ring never needs it)
+    if ((e = hipMalloc(&p->words, wbytes)) != hipSuccess ||
         (e = hipMalloc(&p->dec, (P.n_reveal + 1) * 8)) != hipSuccess || (e = hipMalloc(&p->recs, P.recs.size() * sizeof(Rec))) != hipSuccess) {
         lgc_party_destroy(p);
         return lgc_fail(LGC_ENOMEM, "hipMalloc: %s", hipGetErrorString(e));
@@ -245,8 +247,13 @@ extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint
 // memory the evaluator process maps (the hipIpc ring) keeps the zero-label stash of critical-path launches in its
 // PRIVATE buffer p->tab: only finished ciphertexts are ever stored to the shared slot (src/input.c:94-108 -- label
 // pairs never leave the CSP)
+static hipError_t party_need_tab(lgc_party *p) {
+    if (p->tab) return hipSuccess;
+    return hipMalloc(&p->tab, p->P.max_launch_steps * 2048 + 16);
+}
 template <bool G>
 static hipError_t party_launch(lgc_party *p, const Launch &L, Lbl *tab = 0, int stages = 3, bool *was_crit = 0) {
+    if (!tab || G) { hipError_t e = party_need_tab(p); if (e != hipSuccess) return e; }
     return gc_launch<G>(p->recs, L, p->words, p->dec, tab ? tab : p->tab, p->R, p->P.w, p->P.p, 0, (G && tab) ? p->tab : (Lbl *)0,
                         stages, was_crit);
 }
@@ -257,6 +264,7 @@ extern "C" int lgc_party_garble(lgc_party *p, size_t launch, uint8_t *tables_out
     if (launch >= p->P.launches.size()) return lgc_fail(LGC_EINVAL, "launch out of range");
     RCHK(hipSetDevice(p->device));
     const Launch &L = p->P.launches[launch];
+    RCHK(party_need_tab(p));
     if (L.steps) RCHK(hipMemset(p->tab, 0, (size_t)L.steps * 2048));   // inactive lanes: defined bytes on the wire
     RCHK(party_launch<true>(p, L));
     if (L.steps) RCHK(hipMemcpy(tables_out, p->tab, (size_t)L.steps * 2048, hipMemcpyDeviceToHost));
@@ -270,6 +278,7 @@ extern "C" int lgc_party_evaluate(lgc_party *p, size_t launch, const uint8_t *ta
     if (launch >= p->P.launches.size()) return lgc_fail(LGC_EINVAL, "launch out of range");
     RCHK(hipSetDevice(p->device));
     const Launch &L = p->P.launches[launch];
+    RCHK(party_need_tab(p));
     if (L.steps) RCHK(hipMemcpy(p->tab, tables_in, (size_t)L.steps * 2048, hipMemcpyHostToDevice));
     RCHK(party_launch<false>(p, L));
     RCHK(hipDeviceSynchronize());

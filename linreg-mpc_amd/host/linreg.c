@@ -118,7 +118,7 @@ int main(int argc, char **argv) {
             }
             check(n_devices > 0, "--devices wants at least one index");
         }
-        else if (!strcmp(argv[i], "--table_ring")) ring_slots = 8;
+        else if (!strcmp(argv[i], "--table_ring")) ring_slots = 4;
         else if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) {}
         else if (sscanf(argv[i], "--table_lanes=%i", &table_lanes) == 1) protocol_set_table_lanes(table_lanes);
         else if (sscanf(argv[i], "--width_phase1=%i", &w1) == 1) {}
@@ -167,7 +167,7 @@ int main(int argc, char **argv) {
     if (n_lambdas) { sys.reveal_inputs = 0; sys.trace = 0; }       /* merged program of n_lambdas circuits: results only */
     /* table bytes per launch: socket mode moves them through host buffers; ring mode keeps them
      * in HBM (CSP and Evaluator on one node), so launches can be as large as the fused solver's */
-    const size_t kTableChunk = ring_slots > 0 ? (size_t)1 << 30 : (size_t)64 << 20;
+    const size_t kTableChunk = ring_slots > 0 ? (size_t)16 << 30 : (size_t)64 << 20;
     /* the phase-2 object(s) of party 1 / 2: one, or with --devices one block of the sweep per entry (same seed: one set of
      * input labels, one label OT per data provider; block k starts at circuit lo_k, which keeps its gate ids disjoint) */
 #define CREATE_PARTY(role, seedp) do {                                                                                          \

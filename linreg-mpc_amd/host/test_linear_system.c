@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
     const char *host = "localhost";
     for (int i = 7; i < argc; i++) {
         if (sscanf(argv[i], "--width=%i", &w) == 1) continue;
-        if (!strcmp(argv[i], "--table_ring")) { ring_slots = 8; continue; }
+        if (!strcmp(argv[i], "--table_ring")) { ring_slots = 4; continue; }
         if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) continue;
         { int lanes = 0; if (sscanf(argv[i], "--table_lanes=%i", &lanes) == 1) { protocol_set_table_lanes(lanes); continue; } }
         if (!strncmp(argv[i], "--host=", 7)) host = argv[i] + 7;
@@ -88,7 +88,7 @@ int main(int argc, char **argv) {
     sys.d = d; sys.width = w; sys.precision = precision;
     sys.algorithm = !strcmp(algorithm, "cholesky") ? LGC_ALG_CHOLESKY : (!strcmp(algorithm, "ldlt") ? LGC_ALG_LDLT : LGC_ALG_CGD);
     sys.num_iterations = num_iterations; sys.nshares = 2; sys.normalize = 0; sys.trace = 1;
-    const size_t chunk = ring_slots > 0 ? (size_t)1 << 30 : (size_t)64 << 20;
+    const size_t chunk = ring_slots > 0 ? (size_t)16 << 30 : (size_t)64 << 20;
     if (party == 1) {
         uint8_t seed[16];
         check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
