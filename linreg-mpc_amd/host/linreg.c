@@ -180,6 +180,10 @@ int main(int argc, char **argv) {
             party_obj = blocks[0];                                                                                            \
         } else if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, role, seedp, kTableChunk, n_lambdas, lambdas)); \
         else LGC(lgc_party_create(&party_obj, device, &sys, role, seedp, kTableChunk));                                       \
+        if (role == LGC_ROLE_GARBLER && ring_slots > 0) {        /* the ring(s) now, not on the evaluator's clock */          \
+            if (n_devices) { for (int k_ = 0; k_ < n_devices; k_++) check(!tables_ring_prepare(blocks[k_], ring_slots), "could not create table ring %d", k_); } \
+            else check(!tables_ring_prepare(party_obj, ring_slots), "could not create the table ring");                       \
+        }                                                                                                                     \
     } while (0)
 
     if (party == 1) {

@@ -312,15 +312,43 @@ static int link_io(table_link *l, void *buf, size_t n, int wr) {
     if (l->fd < 0) return wr ? send_blob(l->self, l->peer, buf, n) : recv_blob(l->self, l->peer, buf, n);
     return net_io_all(l->fd, buf, n, wr);
 }
+/* The garbler may create its ring ahead of time (tables_ring_prepare: while the other parties are still in phase 1 or in
+ * the label OT): a device allocation of tens of GB takes from 0.1 s to seconds, and taken inside tables_send it is on the
+ * evaluator's clock.  A prepared ring is picked up by table_link_open. */
+enum { kMaxPrepared = 16 };
+static struct { lgc_party *po; ring_hello h; } g_prepared[kMaxPrepared];
+static pthread_mutex_t g_prepared_mu = PTHREAD_MUTEX_INITIALIZER;
+int tables_ring_prepare(lgc_party *po, int ring_slots) {
+    if (ring_slots <= 0) return 0;
+    ring_hello h;
+    size_t sb = 0;
+    memset(&h, 0, sizeof h);
+    TCHK(lgc_party_ring_create(po, ring_slots, h.handle, &sb));
+    h.nslots = (uint64_t)ring_slots; h.slot_bytes = sb;
+    pthread_mutex_lock(&g_prepared_mu);
+    int ok = 0;
+    for (int i = 0; i < kMaxPrepared && !ok; i++) if (!g_prepared[i].po) { g_prepared[i].po = po; g_prepared[i].h = h; ok = 1; }
+    pthread_mutex_unlock(&g_prepared_mu);
+    return ok ? 0 : 1;
+}
+static int take_prepared(lgc_party *po, ring_hello *h) {
+    int found = 0;
+    pthread_mutex_lock(&g_prepared_mu);
+    for (int i = 0; i < kMaxPrepared && !found; i++) if (g_prepared[i].po == po) { *h = g_prepared[i].h; g_prepared[i].po = NULL; found = 1; }
+    pthread_mutex_unlock(&g_prepared_mu);
+    return found;
+}
 int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, int sending, int ring_slots, size_t start) {
     memset(l, 0, sizeof *l);
     l->self = self; l->peer = peer; l->fd = fd; l->po = po; l->start = start; l->end = lgc_party_num_launches(po);
     ring_hello h;
     memset(&h, 0, sizeof h);
     if (sending) {
-        size_t sb = 0;
-        TCHK(lgc_party_ring_create(po, ring_slots, h.handle, &sb));
-        h.nslots = (uint64_t)ring_slots; h.slot_bytes = sb;
+        if (!take_prepared(po, &h)) {
+            size_t sb = 0;
+            TCHK(lgc_party_ring_create(po, ring_slots, h.handle, &sb));
+            h.nslots = (uint64_t)ring_slots; h.slot_bytes = sb;
+        }
         if (link_io(l, &h, sizeof h, 1)) return 1;
     } else {
         if (link_io(l, &h, sizeof h, 0)) return 1;

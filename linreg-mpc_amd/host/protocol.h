@@ -39,6 +39,7 @@ int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
                 void (*after_launch)(size_t launch, void *ctx), void *ctx);
 /* ring mode in pieces, for several blocks of a sweep side by side (bin/linreg --devices): see protocol.c */
 typedef struct { node *self; int peer, fd; lgc_party *po; size_t start, end, nslots; } table_link;
+int tables_ring_prepare(lgc_party *po, int ring_slots);   /* garbler, optional: create the ring before tables_send / table_link_open need it */
 int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, int sending, int ring_slots, size_t start);
 int table_link_send_range(table_link *l, size_t lo, size_t hi);
 int table_link_recv_range(table_link *l, size_t lo, size_t hi, void (*after_launch)(size_t launch, void *ctx), void *ctx);

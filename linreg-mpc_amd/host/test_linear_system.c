@@ -93,6 +93,7 @@ int main(int argc, char **argv) {
         uint8_t seed[16];
         check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
         LGC(lgc_party_create(&po, device, &sys, LGC_ROLE_GARBLER, seed, chunk));
+        check(!tables_ring_prepare(po, ring_slots), "could not create the table ring");   /* now: not on the evaluator's clock */
         size_t bits = lgc_party_input_bits(po);
         uint8_t *lab = malloc(bits * 16), *m0 = malloc(bits * 16), *m1 = malloc(bits * 16), *u = malloc(lgc_ot_u_bytes(bits)), *e = malloc(bits * 32);
         LGC(lgc_party_encode_inputs(po, 0, mine, lab));                         /* feedOblivLLong(.., 1) */

@@ -239,7 +239,7 @@ def test_test_linear_system_binary(tmp_path, oracle, alg, w, p, ring):
     assert rows[0] == "n d algorithm ot_time time error gate_count" + ("" if refg is None else " ref_gate_count")
     assert rows[1].split()[:3] == ["40", str(d), alg] and abs(float(rows[1].split()[5]) - err) < 1e-12
     if refg is not None:
-        assert int(rows[1].split()[7]) == refg and refg > run["gate_count"]
+        assert int(rows[1].split()[7]) == refg               # (not always the larger one: Kogge-Stone adders trade gates for depth)
     if alg == "cgd":
         assert rows[2] == "iter_i error_i obj_i time_i gate_count_i" and len(rows) == 3 + iters + 10
         assert int(rows[2 + iters].split()[4]) == run["gate_count"]
