@@ -224,33 +224,61 @@ struct Program {
     static double round_cost(size_t per, size_t quantum) {   // a workgroup is the unit: a partial round costs a round
         return (double)((per + quantum - 1) / quantum);
     }
+    // relative time of a batch of MAC records run as `launches` equal launches, longest records first: a round takes as
+    // long as its first (longest) record; garbler rounds of 4096 records weigh 64 (16 waves per CU, 4 AES per gate),
+    // evaluator rounds of 3072 weigh 24 (12 waves, 2 AES).  rep: every record stands for `rep` equal ones (the circuits
+    // of a merged sweep, replicate_program).
+    static double shaped_cost(const std::vector<uint64_t> &steps_desc, size_t rep, size_t launches) {
+        const size_t N = steps_desc.size() * rep, per = (N + launches - 1) / launches;
+        double t = 3e2 * (double)launches;
+        for (size_t lo = 0; lo < N; lo += per) {
+            const size_t hi = lo + per < N ? lo + per : N;
+            for (size_t i = lo; i < hi; i += 4096) t += 64.0 * (double)steps_desc[i / rep];
+            for (size_t i = lo; i < hi; i += 3072) t += 24.0 * (double)steps_desc[i / rep];
+        }
+        return t;
+    }
     void dots(const std::vector<DotJob> &jobs, uint32_t scratch, size_t target_waves) {
         size_t total = 0;
         for (size_t i = 0; i < jobs.size(); i++) total += jobs[i].len;
         if (total == 0) return;
         const size_t c0 = dots_chunk(total, target_waves), clo = dots_chunk_low(total, target_waves);
+        // chunk sizes from half to one and a half times the default (larger chunks: fewer, longer records -- and fewer
+        // partial sums to merge); the scratch for the partial sums is sized for the smallest chunk
+        size_t chi = c0 + c0 / 2;
+        {
+            uint64_t s1, g1;
+            cost(mk(OP_MAC, 0, 0, 0, 0, 1), s1, g1);
+            const size_t by_slot = (size_t)(cap_steps / ((uint64_t)kMinRecsPerLaunch * s1));
+            if (chi > by_slot) chi = by_slot > c0 ? by_slot : c0;
+        }
+        const size_t rep = merge_hint ? merge_hint : 1;
         std::vector<Rec> recs_best, recs_try;
         std::vector<std::pair<uint32_t, uint32_t>> parts, parts_try;
+        std::vector<uint64_t> sdesc;
         double best = -1.0;
         size_t best_launches = 1;
-        for (size_t c = c0; c >= clo; c--) {
+        for (size_t c = chi; c >= clo; c--) {
             dots_records(jobs, scratch, c, recs_try, parts_try);
             uint64_t steps = 0, smax = 0;
+            sdesc.resize(recs_try.size());
             for (size_t i = 0; i < recs_try.size(); i++) {
                 uint64_t s1, g1;
                 cost(recs_try[i], s1, g1);
                 steps += s1;
                 if (s1 > smax) smax = s1;
+                sdesc[i] = s1;
             }
+            std::sort(sdesc.begin(), sdesc.end(), [](uint64_t x, uint64_t y) { return x > y; });
             const size_t R = recs_try.size();
             const size_t lmin = (size_t)((steps + cap_steps - 1) / cap_steps);
             for (size_t L = lmin ? lmin : 1; L <= lmin + 3; L++) {
                 size_t per = (R + L - 1) / L;
                 if ((uint64_t)per * smax > cap_steps) continue;
-                // relative time of one launch: garbler rounds of 4096 records (16 waves/CU, 4 AES per gate)
-                // and evaluator rounds of 3072 (12 waves/CU, 2 AES)
-                double c_est = (double)L * ((double)smax * (64.0 * round_cost(per, 4096) + 24.0 * round_cost(per, 3072)) + 3e2);
+                // a merged sweep is ONE batch of rep x R records (replicate_program cuts it by the table cap afterwards)
+                const double c_est = shaped_cost(sdesc, rep, rep > 1 ? 1 : L);
                 if (best < 0 || c_est < best) { best = c_est; best_launches = L; recs_best = recs_try; parts = parts_try; }
+                if (rep > 1) break;
             }
             if (c == 1) break;
         }
@@ -676,9 +704,11 @@ inline void replicate_program(Program &P, const Program &P0, size_t count, const
                 if (soft < cap_keep) P.cap_steps = soft;
             }
         }
-        for (size_t t = 0; t < (prefix ? 1 : count); t++) {
-            const uint32_t wo = (uint32_t)t * P.word_stride, ro = (uint32_t)t * P.reveal_stride;
-            for (uint32_t k = 0; k < L.nrec; k++) {
+        // record-major: record k of every circuit, then record k + 1 ... -- the records of a launch are independent, and
+        // equal records side by side make the rounds of a MAC launch uniform (dots() sorts them by length)
+        for (uint32_t k = 0; k < L.nrec; k++) {
+            for (size_t t = 0; t < (prefix ? 1 : count); t++) {
+                const uint32_t wo = (uint32_t)t * P.word_stride, ro = (uint32_t)t * P.reveal_stride;
                 Rec r = P0.recs[L.first_rec + k];
                 auto mv = [wo, shared_end](uint32_t x) { return x >= shared_end ? x + wo : x; };
                 switch (r.op) {
