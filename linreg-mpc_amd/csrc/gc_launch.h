@@ -76,7 +76,7 @@ static constexpr uint32_t kCritMaxRecs = GC_CRIT_MAX_RECS;
 static constexpr uint32_t kNarrowMac = 1024;
 // MAC launches of at least two garbler rounds get the chip to themselves (GC_MAC_EXCLUSIVE)
 #ifndef GC_EXCLUSIVE_MAC_RECS
-#define GC_EXCLUSIVE_MAC_RECS 8192
+#define GC_EXCLUSIVE_MAC_RECS 4096   /* one full garbler round (the equal pieces of a merged sweep launch may be ~8000 records) */
 #endif
 static constexpr uint32_t kExclusiveMac = GC_EXCLUSIVE_MAC_RECS;
 static constexpr int kTpbTabfill = 1024;

@@ -176,7 +176,7 @@ struct Program {
     // MAC records of a batch of dot products for `chunk` products per record (two chunks per record
     // when w == 32); fills the partial-word bookkeeping of every job
     void dots_records(const std::vector<DotJob> &jobs, uint32_t scratch, size_t chunk, std::vector<Rec> &out,
-                      std::vector<std::pair<uint32_t, uint32_t>> &parts) const {
+                      std::vector<std::pair<uint32_t, uint32_t>> &parts, bool kara_ok = true) const {
         out.clear();
         parts.assign(jobs.size(), std::make_pair(0u, 0u));   // (first partial word, count of words)
         uint32_t cur = scratch;
@@ -198,7 +198,7 @@ struct Program {
                     // records of a launch run in lock step, round by round.  Karatsuba records take their products two
                     // at a time: even lengths (a single leftover product would be paired with the zero word)
                     const uint32_t nrec_job = (uint32_t)((left + chunk - 1) / chunk);      // (w == 32: `left` is the odd last product)
-                    const bool kara = J.kdelta && w == 64;
+                    const bool kara = J.kdelta && w == 64 && kara_ok;
                     const uint32_t unit = kara ? 2u : 1u, units = (left + unit - 1) / unit;
                     for (uint32_t q = 0; q < nrec_job && k0 < J.len; q++) {
                         uint32_t un = units / nrec_job + (q < units % nrec_job ? 1u : 0u);
@@ -253,13 +253,16 @@ struct Program {
             if (chi > by_slot) chi = by_slot > c0 ? by_slot : c0;
         }
         const size_t rep = merge_hint ? merge_hint : 1;
+        // Karatsuba records take their products in pairs: only where the batch is large enough for two products per record
+        // (the early and late columns of a factorisation are not: a lone product paired with the zero word costs 220 steps)
+        const bool kara_ok = c0 >= 2;
         std::vector<Rec> recs_best, recs_try;
         std::vector<std::pair<uint32_t, uint32_t>> parts, parts_try;
         std::vector<uint64_t> sdesc;
         double best = -1.0;
         size_t best_launches = 1;
         for (size_t c = chi; c >= clo; c--) {
-            dots_records(jobs, scratch, c, recs_try, parts_try);
+            dots_records(jobs, scratch, c, recs_try, parts_try, kara_ok);
             uint64_t steps = 0, smax = 0;
             sdesc.resize(recs_try.size());
             for (size_t i = 0; i < recs_try.size(); i++) {
@@ -283,7 +286,7 @@ struct Program {
             if (c == 1) break;
         }
         if (best < 0) {   // cannot happen (L = lmin + 3 always fits); keep the default shape
-            dots_records(jobs, scratch, c0, recs_best, parts);
+            dots_records(jobs, scratch, c0, recs_best, parts, kara_ok);
             best_launches = 0;
         }
         new_launch();
@@ -566,6 +569,12 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
     } else if (alg == ALG_CHOLESKY) {
         const uint32_t y = P.alloc(d), beta = P.alloc(d);
         const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d + d, d + 1, 4096) + 4 * d + 8);
+        // Karatsuba products in the factorisation (w = 64, large d): an entry L_kj -- and y_j -- is final once column j has
+        // been scaled, so its hdiff word (shadow of [M, y + d), kdelta words up) is formed in the launch that mirrors the
+        // column (independent of the copies: no launch is added to the chain); columns with fewer than two products per
+        // record keep the plain array (dots()).  The back substitution (one short dot product per step) is left as it is.
+        uint32_t kdelta = 0;
+        if (w == 64 && program_karatsuba() && (d / 2) * (d / 2 + 1) >= 2 * 4096) kdelta = P.alloc((size_t)(y + D - M)) - M;
         // cholesky.oc:51-65 (factorisation) and :68-76 (forward substitution) as ONE chain of launches: step j of
         // the forward substitution, y_j = (b_j - sum_{k<j} L_jk y_k) / L_jj, needs row j of L (complete once
         // column j - 1 has been scaled) and y_0..y_{j-1}, so its dot product joins the dot products of column
@@ -576,10 +585,10 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
             if (j > 0) {
                 std::vector<Program::DotJob> jobs;
                 for (size_t i = j; i < d; i++) {
-                    Program::DotJob J = {Mi(i, j), Mi(i, j), Mi(i, 0), Mi(j, 0), (uint32_t)j, true};
+                    Program::DotJob J = {Mi(i, j), Mi(i, j), Mi(i, 0), Mi(j, 0), (uint32_t)j, true, kdelta};
                     jobs.push_back(J);
                 }
-                Program::DotJob F = {bv + (uint32_t)j, bv + (uint32_t)j, Mi(j, 0), y, (uint32_t)j, true};   // :70-73
+                Program::DotJob F = {bv + (uint32_t)j, bv + (uint32_t)j, Mi(j, 0), y, (uint32_t)j, true, kdelta};   // :70-73
                 jobs.push_back(F);
                 P.dots(jobs, sc_dot, 4096);
             }
@@ -589,6 +598,10 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
             P.emit(Program::mk(OP_DIV, y + (uint32_t)j, bv + (uint32_t)j, Mi(j, j)));                       // :75
             P.new_launch();
             for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_COPY, Mi(j, k), Mi(k, j)));
+            if (kdelta) {
+                for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_HDIFF, Mi(k, j) + kdelta, Mi(k, j)));
+                P.emit(Program::mk(OP_HDIFF, y + (uint32_t)j + kdelta, y + (uint32_t)j));
+            }
             P.new_launch();
         }
         for (size_t ii = d; ii-- > 0;) {             // :79-87
@@ -608,25 +621,35 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
     } else {  // ALG_LDLT
         const uint32_t tv = P.alloc(d);
         const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d + d, d + 1, 4096) + 4 * d + 8);
+        // Karatsuba products as in the Cholesky lowering: hdiff of L_kj in the launch that mirrors column j, of b_j (final
+        // after step j of the forward substitution) and of the products t_k = L_jk D_k in a launch of their own per column
+        uint32_t kdelta = 0;
+        if (w == 64 && program_karatsuba() && (d / 2) * (d / 2 + 1) >= 2 * 4096) kdelta = P.alloc((size_t)(tv + D - M)) - M;
         for (size_t j = 0; j < d; j++) {             // ldlt.oc:50-64
             if (j > 0) {
                 for (size_t k = 0; k < j; k++) P.emit(Program::mk(OP_MUL, tv + (uint32_t)k, Mi(j, k), Mi(k, k)));
                 P.new_launch();
+                if (kdelta) {
+                    for (size_t k = 0; k < j; k++) P.emit(Program::mk(OP_HDIFF, tv + (uint32_t)k + kdelta, tv + (uint32_t)k));
+                    P.emit(Program::mk(OP_HDIFF, bv + (uint32_t)(j - 1) + kdelta, bv + (uint32_t)(j - 1)));
+                    P.new_launch();
+                }
                 std::vector<Program::DotJob> jobs;
                 for (size_t i = j; i < d; i++) {
-                    Program::DotJob J = {Mi(i, j), Mi(i, j), Mi(i, 0), tv, (uint32_t)j, true};
+                    Program::DotJob J = {Mi(i, j), Mi(i, j), Mi(i, 0), tv, (uint32_t)j, true, kdelta};
                     jobs.push_back(J);
                 }
                 // step j of the forward substitution (:67-73), b_j -= sum_{k<j} L_jk b_k, needs row j of L (complete once
                 // column j - 1 has been scaled) and b_0 .. b_{j-1}: it joins the dot products of column j instead of
                 // forming a chain of d - 1 launch pairs of its own after the factorisation (as in the Cholesky lowering)
-                Program::DotJob F = {bv + (uint32_t)j, bv + (uint32_t)j, Mi(j, 0), bv, (uint32_t)j, true};
+                Program::DotJob F = {bv + (uint32_t)j, bv + (uint32_t)j, Mi(j, 0), bv, (uint32_t)j, true, kdelta};
                 jobs.push_back(F);
                 P.dots(jobs, sc_dot, 4096);
             }
             for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_DIV, Mi(k, j), Mi(k, j), Mi(j, j)));
             P.new_launch();
             for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_COPY, Mi(j, k), Mi(k, j)));
+            if (kdelta) for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_HDIFF, Mi(k, j) + kdelta, Mi(k, j)));
             P.new_launch();
         }
         for (size_t i = 0; i < d; i++)               // :76-79

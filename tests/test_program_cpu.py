@@ -64,6 +64,33 @@ def test_program_plain_matches_oracle(lgc, gccpu, oracle, w, p, d, n, alg, norma
     assert got.tolist() == beta.tolist()
 
 
+@pytest.mark.parametrize("alg,d,iters", [("cgd", 132, 2), ("cholesky", 184, 0), ("ldlt", 184, 0)])
+def test_karatsuba_lowering_plain_matches_oracle(lgc, gccpu, oracle, alg, d, iters):
+    """the sizes from which the lowering uses Karatsuba records (two products per record: cgd from d = 130, the
+    factorisations from d = 182): OP_HDIFF shadow words, OP_MACK records with even lengths and the zero-word pairing,
+    through the plaintext run of the whole program, against the oracle -- and against the plain-array program, which
+    must give the same integers with more gates"""
+    rng = np.random.default_rng(d)
+    w, p = 64, 56
+    A, b = synth_system(oracle, rng, 2 * d, d, w, p)
+    shares = split_shares(rng, A, b, 2, w)
+    sysm = lgc.make_system(d, w, p, alg, iters, 0.0, 2, 0, 0, 0)
+    prog, dec = _plain(lgc, gccpu, sysm, shares)
+    recs = np.frombuffer(prog.records().tobytes(), dtype=REC)
+    assert (recs["op"] == 20).sum() > 100 and (recs["op"] == 21).sum() >= d          # OP_MACK, OP_HDIFF
+    exp, _, _ = oracle_solve(oracle, A, b, d, w, p, alg, iters, 0.0, 0)
+    got = sx(dec[prog.info.rv_beta:prog.info.rv_beta + d], w)
+    assert got.tolist() == exp.tolist()
+    try:
+        lgc.set_karatsuba(False)
+        plain, dec0 = _plain(lgc, gccpu, sysm, shares)
+    finally:
+        lgc.set_karatsuba(True)
+    assert sx(dec0[plain.info.rv_beta:plain.info.rv_beta + d], w).tolist() == exp.tolist()
+    assert plain.info.total_gates > prog.info.total_gates and plain.info.total_steps > prog.info.total_steps
+    assert not (np.frombuffer(plain.records().tobytes(), dtype=REC)["op"] >= 20).any()
+
+
 def test_program_readme_example(lgc, gccpu, oracle, golden_dir):
     """the reference's only known answer, through the lowered circuit (plaintext run)"""
     import json, os
