@@ -197,12 +197,14 @@ static uint64_t lambda_to_fixed(double lambda, int p, int w) {
     return (uint64_t)(int64_t)t;
 }
 
-static void build(Program &P, const lgc_system *sys, uint64_t cap_steps = 0, size_t merge_hint = 1) {
+static int build(Program &P, const lgc_system *sys, uint64_t cap_steps = 0, size_t merge_hint = 1) {
     if (cap_steps) P.cap_steps = cap_steps;
     P.merge_hint = merge_hint;
     int iters = sys->algorithm == LGC_ALG_CGD ? sys->num_iterations : 0;
     build_program(P, sys->algorithm, sys->d, sys->width, sys->precision, iters, sys->nshares, sys->normalize,
                   lambda_to_fixed(sys->lambda, sys->precision, sys->width), sys->reveal_inputs, sys->trace);
+    if (!P.ranges_ok()) return lgc_fail(LGC_EINVAL, "internal: a record of the lowered program lies outside its word file");
+    return LGC_OK;
 }
 
 extern "C" int lgc_program_build(lgc_program **out, const lgc_system *sys) {
@@ -210,7 +212,8 @@ extern "C" int lgc_program_build(lgc_program **out, const lgc_system *sys) {
     if (rc) return rc;
     if (!out) return lgc_fail(LGC_EINVAL, "null out");
     lgc_program *p = new lgc_program();
-    build(p->P, sys);
+    rc = build(p->P, sys);
+    if (rc) { delete p; return rc; }
     *out = p;
     return LGC_OK;
 }
@@ -226,11 +229,13 @@ static int check_sweep(const lgc_system *sys, size_t count, const double *lambda
 // the merged program of `count` circuits; cap_steps as for build()
 static int build_sweep(Program &P, const lgc_system *sys, size_t count, const double *lambdas, size_t first, uint64_t cap_steps = 0) {
     Program base;
-    build(base, sys, cap_steps ? cap_steps : kSweepCapSteps, count);
+    int rcb = build(base, sys, cap_steps ? cap_steps : kSweepCapSteps, count);
+    if (rcb) return rcb;
     if ((uint64_t)base.n_words * count >= (1ull << 31)) return lgc_fail(LGC_EINVAL, "sweep too large: %zu circuits x %u words", count, base.n_words);
     std::vector<uint64_t> lf(count);
     for (size_t t = 0; t < count; t++) lf[t] = lambda_to_fixed(lambdas[t], sys->precision, sys->width);
     replicate_program(P, base, count, lf.data(), first);
+    if (!P.ranges_ok()) return lgc_fail(LGC_EINVAL, "internal: a record of the merged program lies outside its word file");
     return LGC_OK;
 }
 extern "C" int lgc_program_build_sweep_at(lgc_program **out, const lgc_system *sys, size_t count, const double *lambdas, size_t first) {
@@ -438,7 +443,8 @@ static int solver_create(lgc_solver **out, int device, const lgc_system *sys, co
         rc = build_sweep(s->P, sys, count, lambdas, first);
         if (rc) { delete s; return rc; }
     } else {
-        build(s->P, sys);
+        rc = build(s->P, sys);
+        if (rc) { delete s; return rc; }
     }
     memcpy(&s->seed, seed, 16);
     s->R = derive_R(s->seed);

@@ -368,9 +368,39 @@ struct Program {
         size_t c = dots_chunk(total, target_waves) / 2;
         return c < 1 ? 1 : c;
     }
+    // Scratch words for the partial sums of ONE dots() call (two words per record, four per dual 32-bit record), whatever
+    // its batch: with c0 = ceil(total / target_waves) the smallest chunk tried is max(1, c0 / 2) >= c0 / 3, so a call makes
+    // at most 3 * target_waves + njobs records.  (Round 2 sized this from the total of the LARGEST call at ITS smallest
+    // chunk; a smaller call has its own, relatively smaller, smallest chunk -- c0 = 4 gives 2 -- and with the larger table
+    // cap of round 3 the 32-bit Cholesky at d = 250 ran 4 000 words past the end.  build_program now also verifies that
+    // every record stays inside the word file: Program::ranges_ok.)
     size_t dots_scratch(size_t total_products, size_t njobs, size_t target_waves) {
-        size_t chunk = dots_chunk_low(total_products, target_waves);
-        return 2 * (total_products / chunk + njobs + 2) + 4 * njobs + 16;   // + tails of dual 32-bit records
+        (void)total_products;
+        return 2 * (3 * target_waves + njobs + 2) + 4 * njobs + 16;   // + tails of dual 32-bit records
+    }
+    // every word a record touches lies inside the word file (checked once per built program)
+    bool ranges_ok() const {
+        for (size_t i = 0; i < recs.size(); i++) {
+            const Rec &r = recs[i];
+            uint64_t hi = 0;
+            auto upd = [&hi](uint64_t x) { if (x > hi) hi = x; };
+            const uint64_t n = r.cnt ? r.cnt : 1;
+            switch (r.op) {
+            case OP_MAC: upd(r.dst + 1); upd((uint64_t)((int64_t)r.a + (int64_t)(n - 1) * r.sa)); upd((uint64_t)((int64_t)r.b + (int64_t)(n - 1) * r.sb)); break;
+            case OP_MAC2: upd(r.dst + 3); upd((uint64_t)((int64_t)r.a + (int64_t)(2 * n - 1) * r.sa)); upd((uint64_t)((int64_t)r.b + (int64_t)(2 * n - 1) * r.sb)); break;
+            case OP_MACK: upd(r.dst + 1); upd((uint64_t)((int64_t)r.a + (int64_t)(n - 1) * r.sa) + r.c); upd((uint64_t)((int64_t)r.b + (int64_t)(n - 1) * r.sb) + r.c); break;
+            case OP_SUM: case OP_SUBSUM: case OP_MAX: upd(r.dst); upd(r.a); upd((uint64_t)((int64_t)r.a + (int64_t)(n - 1) * r.sa)); if (r.op == OP_SUBSUM) upd(r.c); break;
+            case OP_IPMAC: upd(r.dst + 3); upd(r.a + n - 1); upd(r.b + n - 1); break;
+            case OP_IPFIN: case OP_IPMERGE: upd(r.dst + (r.op == OP_IPMERGE ? 3 : 0)); upd(r.a + 4 * n - 1); break;
+            case OP_CONST: upd(r.dst); break;
+            case OP_REVEAL: upd(r.a); break;
+            case OP_IDIVC: case OP_COPY: case OP_ABS: case OP_SQRT: case OP_HDIFF: upd(r.dst); upd(r.a); break;
+            case OP_MULSUB: upd(r.dst); upd(r.a); upd(r.b); upd(r.c); break;
+            default: upd(r.dst); upd(r.a); upd(r.b); break;
+            }
+            if (hi >= n_words) return false;
+        }
+        return true;
     }
 
     // wide inner products (fixed.oc:124-147), several independent ones level-synchronously:

@@ -144,7 +144,8 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
         rc = build_sweep(p->P, sys, count, lambdas, first, cap);
         if (rc) { delete p; return rc; }
     } else {
-        build(p->P, sys, cap);
+        rc = build(p->P, sys, cap);
+        if (rc) { delete p; return rc; }
     }
     memset(&p->R, 0, sizeof(Lbl)); memset(&p->seed, 0, sizeof(Lbl));
     if (role == LGC_ROLE_GARBLER) {

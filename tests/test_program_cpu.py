@@ -91,6 +91,23 @@ def test_karatsuba_lowering_plain_matches_oracle(lgc, gccpu, oracle, alg, d, ite
     assert not (np.frombuffer(plain.records().tobytes(), dtype=REC)["op"] >= 20).any()
 
 
+@pytest.mark.parametrize("w,p,alg,d", [(32, 30, "cholesky", 250), (32, 30, "ldlt", 200), (64, 56, "cholesky", 150)])
+def test_mid_size_factorisations_plain_match_oracle(lgc, gccpu, oracle, w, p, alg, d):
+    """mid-size factorisations through the plaintext run (the small cases above never leave the first chunk size): the
+    partial-sum scratch of a dots() call is sized for ANY batch -- at d = 250, 32 bit, the round-2 sizing let the records
+    of the middle columns run past the end of the word file once the table cap grew (found on the GPU at d = 500) -- and
+    lgc_program_build refuses a program whose records leave the word file"""
+    rng = np.random.default_rng(d + w)
+    A, b = synth_system(oracle, rng, 3 * d, d, w, p)
+    shares = split_shares(rng, A, b, 2, w)
+    sysm = lgc.make_system(d, w, p, alg, 0, 1e-3, 2, 1, 0, 0)
+    prog, dec = _plain(lgc, gccpu, sysm, shares)
+    recs = np.frombuffer(prog.records().tobytes(), dtype=REC)
+    assert int(recs["dst"].max()) < prog.info.n_words
+    exp, _, _ = oracle_solve(oracle, A, b, d, w, p, alg, 0, 1e-3, 1)
+    assert sx(dec[prog.info.rv_beta:prog.info.rv_beta + d], w).tolist() == exp.tolist()
+
+
 def test_program_readme_example(lgc, gccpu, oracle, golden_dir):
     """the reference's only known answer, through the lowered circuit (plaintext run)"""
     import json, os
