@@ -370,13 +370,13 @@ struct Program {
     }
     // Scratch words for the partial sums of ONE dots() call (two words per record, four per dual 32-bit record), whatever
     // its batch: with c0 = ceil(total / target_waves) the smallest chunk tried is max(1, c0 / 2) >= c0 / 3, so a call makes
-    // at most 3 * target_waves + njobs records.  (Round 2 sized this from the total of the LARGEST call at ITS smallest
+    // at most 3 * target_waves + njobs records (total_products: an upper bound on the products of any one call).  (Round 2 sized this from the total of the LARGEST call at ITS smallest
     // chunk; a smaller call has its own, relatively smaller, smallest chunk -- c0 = 4 gives 2 -- and with the larger table
     // cap of round 3 the 32-bit Cholesky at d = 250 ran 4 000 words past the end.  build_program now also verifies that
     // every record stays inside the word file: Program::ranges_ok.)
     size_t dots_scratch(size_t total_products, size_t njobs, size_t target_waves) {
-        (void)total_products;
-        return 2 * (3 * target_waves + njobs + 2) + 4 * njobs + 16;   // + tails of dual 32-bit records
+        const size_t recs = 3 * target_waves < total_products ? 3 * target_waves : total_products;   // (never more records than products)
+        return 2 * (recs + njobs + 2) + 4 * njobs + 16;   // + tails of dual 32-bit records
     }
     // every word a record touches lies inside the word file (checked once per built program)
     bool ranges_ok() const {
