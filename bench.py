@@ -47,7 +47,7 @@ def cpu_info():
     return model, os.cpu_count()
 
 
-def measure_hbm_traffic(argv_tail, kernel_substr="gc_mac_kernel<true"):
+def measure_hbm_traffic(argv_tail, kernel_substr="gc_mack_kernel<true"):
     """HBM bytes per launch of the dominant kernel from the PMC counters, measured in THIS run:
     two child processes of this same script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
     (separate passes, counters only, the program directly after `--`; MI355X_MICROARCH.md, HBM
@@ -71,9 +71,12 @@ def measure_hbm_traffic(argv_tail, kernel_substr="gc_mac_kernel<true"):
             if r.returncode != 0 or not files:
                 return None, {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode()[-300:])}
             acc = []
-            for row in csv.DictReader(open(files[0])):
-                if kernel_substr in row["Kernel_Name"] and row.get("Counter_Name", counter) == counter:
-                    acc.append(float(row["Counter_Value"]))
+            rows = list(csv.DictReader(open(files[0])))
+            for sub in (kernel_substr, "gc_mac_kernel<true"):          # (plain-array MAC kernel: 32-bit and non-default workloads)
+                acc = [float(row["Counter_Value"]) for row in rows
+                       if sub in row["Kernel_Name"] and row.get("Counter_Name", counter) == counter]
+                if acc:
+                    break
             if not acc:
                 return None, {"error": "no %s rows for %s" % (counter, kernel_substr)}
             vals[counter] = sum(acc) / len(acc)
@@ -412,9 +415,12 @@ def main():
         mac_gates = sum(L["gates"] for L in macL)
         mac_products = int(sum(int(recs["cnt"][L["first_rec"]:L["first_rec"] + L["nrec"]].sum()) for L in macL))
         mac_recs = sum(L["nrec"] for L in macL)
-        # algorithmic HBM bytes of the garbling MAC kernel: 32 B of garbled table per AND gate written,
-        # 2 operand words (1 KiB each) read per product, 2 words written per record
-        alg_bytes_per_solve = 32 * mac_gates + 2048 * mac_products + 2048 * mac_recs
+        karatsuba = bool(macL) and int(recs["op"][macL[0]["first_rec"]]) == 20          # OP_MACK records (gc_mack_kernel)
+        # algorithmic HBM bytes of the garbling MAC kernel: 32 B of garbled table per AND gate written; operand words
+        # (1 KiB each) read per product: 2 for the plain array, 6 for a Karatsuba product (a pair reads both halves of
+        # a, b and of their half-difference words -- eight packed 1 KiB loads -- and a, b again for the sign
+        # corrections); 2 words written per record
+        alg_bytes_per_solve = 32 * mac_gates + (6144 if karatsuba else 2048) * mac_products + 2048 * mac_recs
         n_launch_per_solve = max(1, len(macL))
         avg_dur = mac_g / max(1, mac_launches)
         alg_bytes_per_launch = alg_bytes_per_solve / n_launch_per_solve
@@ -442,7 +448,7 @@ def main():
                                         "formula": "192 N_AND + 128 N_XOR over the whole solve / seconds per solve",
                                         "n_and": gates, "n_xor": n_xor,
                                         "n_xor_rule": "word-level XORs of two wire words x width (lane moves, public selects, inverters = wiring)"},
-                    "kernel": "gc_mac_kernel<garbler>", "avg_launch_ms": avg_dur * 1e3,
+                    "kernel": "gc_mack_kernel<garbler>" if karatsuba else "gc_mac_kernel<garbler>", "avg_launch_ms": avg_dur * 1e3,
                     "alg_bytes_per_launch": alg_bytes_per_launch,
                     "achieved_exclusive": achieved_excl, "avg_launch_ms_exclusive": xg / n_launch_per_solve * 1e3,
                     "timing": "achieved: HIP events on the garbler stream over the timed region (large MAC launches "

@@ -289,6 +289,12 @@ struct Program {
             dots_records(jobs, scratch, c0, recs_best, parts, kara_ok);
             best_launches = 0;
         }
+        {   // the partial sums of this call must fit the scratch its caller allocated
+            uint32_t end = scratch;
+            for (size_t i = 0; i < parts.size(); i++) if (parts[i].first + parts[i].second > end) end = parts[i].first + parts[i].second;
+            auto cap = dots_caps.find(scratch);
+            if (cap == dots_caps.end() || (size_t)(end - scratch) > cap->second) overflow = true;
+        }
         new_launch();
         // longest records first: a round of the chip then holds records of one length (the records of a launch are
         // independent, so their order is free)
@@ -375,11 +381,30 @@ struct Program {
     // cap of round 3 the 32-bit Cholesky at d = 250 ran 4 000 words past the end.  build_program now also verifies that
     // every record stays inside the word file: Program::ranges_ok.)
     size_t dots_scratch(size_t total_products, size_t njobs, size_t target_waves) {
-        const size_t recs = 3 * target_waves < total_products ? 3 * target_waves : total_products;   // (never more records than products)
+        // ... unless the table cap, not the target, bounds the chunk (dots_chunk: by_slot): then a call makes up to
+        // total / max(1, by_slot / 2) records
+        uint64_t s1, g1;
+        cost(mk(OP_MAC, 0, 0, 0, 0, 1), s1, g1);
+        const size_t by_slot = (size_t)(cap_steps / ((uint64_t)kMinRecsPerLaunch * s1));
+        const size_t lo = by_slot / 2 ? by_slot / 2 : 1;
+        size_t recs = 3 * target_waves;
+        if (total_products / lo + 1 > recs) recs = total_products / lo + 1;
+        if (recs > total_products) recs = total_products;                 // (never more records than products)
         return 2 * (recs + njobs + 2) + 4 * njobs + 16;   // + tails of dual 32-bit records
+    }
+    // allocate the scratch of a series of dots() calls and remember its size: dots() checks every call against it
+    // (a call that does not fit marks the program `overflow`, which the engine refuses to run)
+    std::map<uint32_t, size_t> dots_caps;
+    bool overflow = false;
+    uint32_t alloc_dots(size_t total_products, size_t njobs, size_t target_waves, size_t extra = 0) {
+        const size_t n = dots_scratch(total_products, njobs, target_waves) + extra;
+        const uint32_t base = alloc(n);
+        dots_caps[base] = n;
+        return base;
     }
     // every word a record touches lies inside the word file (checked once per built program)
     bool ranges_ok() const {
+        if (overflow) return false;
         for (size_t i = 0; i < recs.size(); i++) {
             const Rec &r = recs[i];
             uint64_t hi = 0;
@@ -524,7 +549,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         // records per matrix-vector product: enough to fill the chip -- together with the other circuits of a merged sweep
         size_t mv_waves = kTargetWaves / (P.merge_hint ? P.merge_hint : 1);
         if (mv_waves < 2 * d) mv_waves = 2 * d < kTargetWaves ? 2 * d : kTargetWaves;     // at least two records per row
-        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d, d, mv_waves));
+        const uint32_t sc_dot = P.alloc_dots(d * d, d, mv_waves);
         if (trace) P.rv_trace = P.alloc_reveal((size_t)iters * (d + 4));
         // Karatsuba products for A p (w = 64): the words hdiff(M[i][j]) -- once per solve -- and hdiff(p[k]) -- once per
         // iteration -- live in a shadow of the word range [M, pv + d), kdelta words above their operands
@@ -598,7 +623,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.new_launch();
     } else if (alg == ALG_CHOLESKY) {
         const uint32_t y = P.alloc(d), beta = P.alloc(d);
-        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d + d, d + 1, 4096) + 4 * d + 8);
+        const uint32_t sc_dot = P.alloc_dots(d * d + d, d + 1, 4096, 4 * d + 8);
         // Karatsuba products in the factorisation (w = 64, large d): an entry L_kj -- and y_j -- is final once column j has
         // been scaled, so its hdiff word (shadow of [M, y + d), kdelta words up) is formed in the launch that mirrors the
         // column (independent of the copies: no launch is added to the chain); columns with fewer than two products per
@@ -650,7 +675,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.new_launch();
     } else {  // ALG_LDLT
         const uint32_t tv = P.alloc(d);
-        const uint32_t sc_dot = P.alloc(P.dots_scratch(d * d + d, d + 1, 4096) + 4 * d + 8);
+        const uint32_t sc_dot = P.alloc_dots(d * d + d, d + 1, 4096, 4 * d + 8);
         // Karatsuba products as in the Cholesky lowering: hdiff of L_kj in the launch that mirrors column j, of b_j (final
         // after step j of the forward substitution) and of the products t_k = L_jk D_k in a launch of their own per column
         uint32_t kdelta = 0;

@@ -108,6 +108,34 @@ def test_mid_size_factorisations_plain_match_oracle(lgc, gccpu, oracle, w, p, al
     assert sx(dec[prog.info.rv_beta:prog.info.rv_beta + d], w).tolist() == exp.tolist()
 
 
+@pytest.mark.parametrize("d,nl", [(100, 64), (60, 32)])
+def test_merged_sweep_at_config5_size_plain_matches_oracle(lgc, gccpu, oracle, d, nl):
+    """BASELINE config 5's shape (d = 100, 64 lambdas; two CGD iterations here) through the plaintext run: the base
+    program of a sweep is built for the merged launch -- few long Karatsuba records per circuit, the chunk bounded by the
+    table cap, record-major replication, equal pieces -- a shape no small sweep reaches (an undersized partial-sum
+    scratch in exactly this corner passed every small test and failed config 5 on the GPU)"""
+    import sweep
+    rng = np.random.default_rng(d)
+    w, p, it = 64, 56, 2
+    A, b = synth_system(oracle, rng, 3 * d, d, w, p)
+    shares = split_shares(rng, A, b, 2, w)
+    lams = sweep.c5_lambdas(64)[:nl]
+    sysm = lgc.make_system(d, w, p, "cgd", it, 0.0, 2, 1, 0, 0)
+    prog = lgc.Program(sysm, lambdas=lams)
+    info = prog.info
+    words = np.zeros(info.n_words, dtype=np.uint64)
+    words[info.in_base:info.in_base + shares.size] = shares.ravel()
+    dec = np.zeros(info.n_reveal + 1, dtype=np.uint64)
+    steps, gates = gccpu.plain_run(prog.records(), info.n_records, w, p, words, dec)
+    assert steps == info.total_steps and gates == info.total_gates
+    recs = np.frombuffer(prog.records().tobytes(), dtype=REC)
+    assert (recs["op"] == 20).sum() > 1000                              # Karatsuba records in the merged matrix-vector products
+    for t_, lam in enumerate(lams):
+        exp, _, _ = oracle_solve(oracle, A, b, d, w, p, "cgd", it, lam, 1)
+        got = sx(dec[info.rv_beta + t_ * info.reveal_stride:info.rv_beta + t_ * info.reveal_stride + d], w)
+        assert got.tolist() == exp.tolist(), (t_, lam)
+
+
 def test_program_readme_example(lgc, gccpu, oracle, golden_dir):
     """the reference's only known answer, through the lowered circuit (plaintext run)"""
     import json, os
