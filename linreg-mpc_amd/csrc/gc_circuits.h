@@ -20,7 +20,7 @@
 //   ip        src/fixed.oc:124-147     wrap_w((sum a_i*b_i) >> p)
 //   div       src/fixed.oc:164-188     wrap_w(tdiv(a << p, b))
 //   sqrt      src/fixed.oc:217-248
-// The bit-level structure (carry-save array multiplier, Kogge-Stone adders,
+// The bit-level structure (carry-save array multiplier, Sklansky adders,
 // restoring divider) is this build's own; only the integer results are the
 // reference's.
 #pragma once
@@ -37,6 +37,13 @@
 namespace gc {
 
 GC_HD uint64_t lanes(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1)); }
+// lanes whose index has bit k set
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ static const uint64_t kBitMask[6] =
+#else
+static const uint64_t kBitMask[6] =
+#endif
+    {0xaaaaaaaaaaaaaaaaull, 0xccccccccccccccccull, 0xf0f0f0f0f0f0f0f0ull, 0xff00ff00ff00ff00ull, 0xffff0000ffff0000ull, 0xffffffff00000000ull};
 
 template <class B>
 struct Circ {
@@ -53,24 +60,29 @@ struct Circ {
     }
     template <class BB>
     static GC_HD W add_pick(BB &be, W x, W y, int n, W cinw, W *cout, long) { return add_generic(be, x, y, n, cinw, cout); }
+    // Sklansky prefix adder.  Level k merges, in every block of 2^(k+1) lanes, the upper half with the top node m of the
+    // lower half:  G_i ^= P_i & G_m,  P_i &= P_m  for the lanes i with bit k set.  That is n/2 nodes of two ANDs each --
+    // n gates, ONE 64-lane gate step per level: the G-gate of node i sits in lane i, its P-gate in lane i - 2^k (a lane
+    // of the lower half, idle at this level).  1 + ceil(log2 n) gate steps for an n-bit addition (64 bits: 7; the
+    // Kogge-Stone form of rounds 1-2 -- n nodes per level, two steps -- took 12), the same 1 + log2 n dependent levels,
+    // and every level is a SINGLE step (two hashes per gate on the critical path instead of four).  The fan-out of node m
+    // to its block is a lane move (B::bblk), free like every other wire permutation.  P_i is dropped once i's prefix
+    // reaches lane 0 (i < 2^(k+1)) and on the last level.
     static GC_HD W add_generic(B &be, W x, W y, int n, W cinw, W *cout) {
         const uint64_t act = lanes(n);
         W P = be.XOR(x, y);
         // lane 0: maj(x0, y0, cin) = ((x0^c)&(y0^c))^c ; other lanes: x&y
         W G = be.XOR(be.AND(be.XOR(x, cinw), be.XOR(y, cinw), act), cinw);
         W Pg = P;
-        for (int dist = 1; dist < n; dist <<= 1) {
-            const uint64_t hi = act & ~lanes(dist);
-            W Gs = be.shl(G, dist);
-            if ((dist << 1) < n) {
-                // the two ANDs of a prefix level are independent: one dual step
-                W t1, t2;
-                be.AND2(Pg, Gs, hi, Pg, be.shl(Pg, dist), hi, t1, t2);
-                G = be.XOR(G, t1);
-                Pg = t2;
-            } else {
-                G = be.XOR(G, be.AND(Pg, Gs, hi));
-            }
+        for (int k = 0; (1 << k) < n; k++) {
+            const int h = 1 << k;
+            const uint64_t bitk = kBitMask[k] & act;                               // nodes of this level
+            const uint64_t pn = ((2 * h) < n) ? (bitk & ~lanes(2 * h)) : 0ull;       // ... whose P is still needed
+            const uint64_t host = pn >> h;
+            W Gm = be.bblk(G, k), Pm = be.bblk(Pg, k);
+            W t = be.AND(be.sel(bitk, Pg, be.shr(Pg, h)), be.sel(bitk, Gm, Pm), bitk | host);
+            G = be.XOR(G, be.sel(bitk, t, be.zero()));
+            Pg = be.sel(pn, be.shl(t, h), Pg);
         }
         if (cout) *cout = be.bcast(G, n - 1);
         W carries = be.XOR(be.sel(act, be.shl(G, 1), be.zero()), cinw);
@@ -609,6 +621,14 @@ struct PlainBackend {
         return (((a >> r) & 1) ? 0xffffffffull : 0ull) | (((a >> (32 + r)) & 1) ? 0xffffffff00000000ull : 0ull);
     }
     GC_HD W sel(uint64_t m, W a, W b) const { return (a & m) | (b & ~m); }
+    // every lane <- the top lane of the LOWER half of its block of 2^(k+1) lanes: lane (l & ~(2^(k+1) - 1)) | (2^k - 1)
+    GC_HD W bblk(W a, int k) const {
+        const int h = 1 << k;
+        W r = 0;
+        for (int base = 0; base < 64; base += 2 * h)
+            if ((a >> (base + h - 1)) & 1ull) r |= (2 * h >= 64 ? ~0ull : (((1ull << (2 * h)) - 1) << base));
+        return r;
+    }
 };
 
 }  // namespace gc

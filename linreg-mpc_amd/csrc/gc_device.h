@@ -293,6 +293,11 @@ struct GpuBackend {
         r.x &= k; r.y &= k; r.z &= k; r.w &= k;
         return r;
     }
+    // every lane <- the top lane of the lower half of its block of 2^(k+1) lanes (Circ::add: the fan-out of a prefix node)
+    __device__ __forceinline__ W bblk(W a, int k) const {
+        const int h = 1 << k;
+        return pull(a, (lane & ~(2 * h - 1)) | (h - 1), true);
+    }
     // lane l <- lane l-k (zero fill)
     __device__ __forceinline__ W shl(W a, int k) const {
         if (k >= 64) return lzero();

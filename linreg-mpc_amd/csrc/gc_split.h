@@ -256,6 +256,7 @@ struct SplitBackend {
         uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((from & 63) << 2, (int)a);
         return ok ? v : 0u;
     }
+    __device__ __forceinline__ W bblk(W a, int k) const { const int h = 1 << k; return pull(a, (lane & ~(2 * h - 1)) | (h - 1), true); }
     __device__ __forceinline__ W shl(W a, int k) const { return k >= 64 ? 0u : pull(a, lane - k, lane >= k); }
     __device__ __forceinline__ W shr(W a, int k) const { return k >= 64 ? 0u : pull(a, lane + k, lane + k < 64); }
 
@@ -316,7 +317,7 @@ struct SplitBackend {
     }
     // x + y + carry-in over lanes [0, n) as one posted job (Circ::add picks this up): same gate steps as the generic
     // Kogge-Stone code, two barriers around the whole addition plus one per level instead of two per level
-    __device__ __forceinline__ W add_native(W x, W y, int n, W cinw, W *cout) {
+    __device__ __forceinline__ W add_native_ks(W x, W y, int n, W cinw, W *cout) {
         const uint64_t act = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
         SplitDesc d = {3u, act, 0ull, step};
         step += 1;

@@ -86,6 +86,7 @@ struct CpuBackend {
     W sel(uint64_t m, const W &a, const W &b) const { W r; for (int i = 0; i < 64; i++) r.l[i] = ((m >> i) & 1) ? a.l[i] : b.l[i]; return r; }
     W bcast(const W &a, int src) const { W r; for (int i = 0; i < 64; i++) r.l[i] = a.l[src]; return r; }
     W bcast2(const W &a, int r) const { W o; for (int i = 0; i < 64; i++) o.l[i] = a.l[(i < 32 ? 0 : 32) + r]; return o; }
+    W bblk(const W &a, int k) const { W o; const int h = 1 << k; for (int i = 0; i < 64; i++) o.l[i] = a.l[(i & ~(2 * h - 1)) | (h - 1)]; return o; }
     W shl(const W &a, int k) const { W r; for (int i = 0; i < 64; i++) r.l[i] = (i - k >= 0 && k < 64) ? a.l[i - k] : _mm_setzero_si128(); return r; }
     W shr(const W &a, int k) const { W r; for (int i = 0; i < 64; i++) r.l[i] = (i + k < 64 && k < 64) ? a.l[i + k] : _mm_setzero_si128(); return r; }
     W AND(const W &a, const W &b, uint64_t act) {
