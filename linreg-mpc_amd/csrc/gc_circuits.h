@@ -37,13 +37,11 @@
 namespace gc {
 
 GC_HD uint64_t lanes(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1)); }
-// lanes whose index has bit k set
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ static const uint64_t kBitMask[6] =
-#else
-static const uint64_t kBitMask[6] =
-#endif
-    {0xaaaaaaaaaaaaaaaaull, 0xccccccccccccccccull, 0xf0f0f0f0f0f0f0f0ull, 0xff00ff00ff00ff00ull, 0xffff0000ffff0000ull, 0xffffffff00000000ull};
+// lanes whose index has bit k set (a select chain: an indexed constant table would be a memory load per adder level)
+GC_HD uint64_t bit_lanes(int k) {
+    return k == 0 ? 0xaaaaaaaaaaaaaaaaull : k == 1 ? 0xccccccccccccccccull : k == 2 ? 0xf0f0f0f0f0f0f0f0ull
+         : k == 3 ? 0xff00ff00ff00ff00ull : k == 4 ? 0xffff0000ffff0000ull : 0xffffffff00000000ull;
+}
 
 template <class B>
 struct Circ {
@@ -76,7 +74,7 @@ struct Circ {
         W Pg = P;
         for (int k = 0; (1 << k) < n; k++) {
             const int h = 1 << k;
-            const uint64_t bitk = kBitMask[k] & act;                               // nodes of this level
+            const uint64_t bitk = bit_lanes(k) & act;                               // nodes of this level
             const uint64_t pn = ((2 * h) < n) ? (bitk & ~lanes(2 * h)) : 0ull;       // ... whose P is still needed
             const uint64_t host = pn >> h;
             W Gm = be.bblk(G, k), Pm = be.bblk(Pg, k);

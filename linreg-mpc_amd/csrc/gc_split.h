@@ -13,7 +13,7 @@
 //     q of the step: a1, b1, a2, b2) of gates 16r .. 16r + 15 in quad layout, writes its column of the result back,
 //     and the glue waves pick the results up: two workgroup barriers per posted gate step;
 //   * whole additions -- nearly all levels of a divider or square root -- are posted as ONE job and walked by the hash
-//     waves themselves with one barrier per Kogge-Stone level (split_ks_add).
+//     waves themselves with one barrier per prefix level (split_sk_add).
 //
 // Measured (scripts/exp/lat4.hip): 1484 cycles per 2-hash level against 2379, 2142 per 4-hash level against 2915.
 //
@@ -59,15 +59,15 @@ enum {
     kSplitWord = 4 * kSplitPlane,          // one operand / one hash result: 4 planes
     kSplitOp = 0,                          // operands a1, b1, a2, b2 (adder: x, y, carry-in)
     kSplitX = 4 * kSplitWord,              // results of hash 0..3 (adder: sum, final generate word)
-    kSplitKs = 8 * kSplitWord,             // adder levels: two buffers of four hash results (level parity)
-    kSplitGs = 16 * kSplitWord,            // adder levels: two snapshots of the generate word
-    kSplitDesc = 18 * kSplitWord,          // kind, act1 (2), act2 (2), step (2): two 16-byte stores
-    kSplitWords = 18 * kSplitWord + 8
+    kSplitKs = 8 * kSplitWord,             // adder levels: two buffers of hash results (level parity; words 0, 1 of each used)
+    kSplitGs = 16 * kSplitWord,            // adder levels: two published states (G, P), alternating
+    kSplitDesc = 20 * kSplitWord,          // kind, act1 (2), act2 (2), step (2): two 16-byte stores
+    kSplitWords = 20 * kSplitWord + 8
 };
 
 struct SplitDesc {
     uint32_t kind;          // 0: record finished, 1: one gate step (hashes 0, 1), 2: two gate steps (hashes 0..3),
-                            // 3: a whole Kogge-Stone addition over act1 = lanes(n) (split_ks_add)
+                            // 3: a whole addition over act1 = lanes(n) (split_sk_add)
     uint64_t act1, act2;    // active gates of the step(s)
     uint64_t step;          // global index of the (first) gate step
 };
@@ -141,93 +141,114 @@ __device__ __forceinline__ void split_hash_phase(const SplitHashCtx &hc, const S
     split_hash_core<GARBLER>(hc, q, (q < 2) ? d.act1 : d.act2, st, a_op, b_op, hc.sx + kSplitX + q * kSplitWord, tg);
 }
 
-// A whole Kogge-Stone addition (gc_circuits.h: Circ::add) run by the 16 waves in quad layout with ONE barrier per level.
-// Posted by the glue waves with x, y and the carry-in word in operand words 0..2; sum and final generate word come back
-// in result words 0 and 1.  The gate steps, their order and their activity masks are exactly those of Circ::add
-// (first AND; per distance a dual step (Pg & shl(G), Pg & shl(Pg)), the last distance a single step).
+// A whole addition (gc_circuits.h: Circ::add_generic, the Sklansky prefix adder) run by the hash waves in quad layout with
+// ONE barrier per level.  Posted by the glue waves with x, y and the carry-in word in operand words 0..2; sum and final
+// generate word come back in result words 0 and 1.  Gate steps, their order, lanes and activity masks are exactly those of
+// Circ::add_generic: the first AND, then one step per level k, in which lane i with bit k set holds the G-gate of node i
+// (P_i & G_m, m = the top lane of the lower half of i's block of 2^(k+1)) and lane i - 2^k the P-gate of node i (P_i & P_m).
 //
-// Why one barrier is enough: the operands of level L at gate g are (G, Pg)_{L-1} at g and at g - dist.  Pg_{L-1} at any
-// gate is the XOR of two hash results of level L-1, which lie in LDS for all 64 gates after that level's barrier; G_{L-1}
-// at any gate is G_{L-2} there -- published by its owner during level L-1, before that barrier -- XOR two hash results
-// of level L-1.  So a lane rebuilds the shifted operands itself from what the last barrier made visible; nothing has to
-// be shifted and re-published in between.  Hash results and generate snapshots alternate between two buffers.
+// A level is a single gate step: two hashes per gate, waves q = 0 (operand a) and q = 1 (operand b), eight of the sixteen
+// waves -- 1484 cycles in scripts/exp/lat4.hip against 2142 for the four-hash levels of the Kogge-Stone form this replaces
+// (round 2), and six levels after the first AND in both.  Wave q = 2 keeps the published state one level behind:
+//   state after level k - 1 at lane t:  G = G_pub(k-2)[t] ^ (bit k-1 of t ? X0 ^ X1 of level k-1 at t : 0)
+//                                       P = (t was a P-node of level k-1 ? X0 ^ X1 of level k-1 at t - 2^(k-1) : P_pub(k-2)[t])
+// (X0, X1: the two hash results of a gate; their XOR is the gate's output label).  Every hash lane rebuilds the two
+// states it needs -- its own node's and m's -- from what the last barrier made visible, the publisher writes state k - 1
+// for level k + 1; results and published states alternate between two buffers.
 template <bool GARBLER>
-__device__ __forceinline__ void split_ks_add(const SplitHashCtx &hc, const SplitDesc &d) {
-    const int q = hc.wave >> 2, r = hc.wave & 3, c = hc.lane & 3, gate = 16 * r + (hc.lane >> 2);
+__device__ __forceinline__ void split_sk_add(const SplitHashCtx &hc, const SplitDesc &d) {
+    const int q = hc.wave >> 2, r = hc.wave & 3, c = hc.lane & 3, g = 16 * r + (hc.lane >> 2);
     const int pl = c * kSplitPlane;
     const uint64_t act = d.act1;
     const int n = 64 - __builtin_clzll(act);                                    // act = lanes(n)
     const uint32_t *opx = hc.sx + kSplitOp + pl, *opy = opx + kSplitWord, *opc = opx + 2 * kSplitWord;
-    const uint32_t xg = ld_u32_lds(opx + gate), yg = ld_u32_lds(opy + gate), cg = ld_u32_lds(opc + gate);
-    const uint32_t P = xg ^ yg;
     uint64_t st = d.step;
-    int par = 0;                                                                 // buffer of the level being written
-    // evaluator: the ciphertext rows of a level are fetched one level ahead (every step index of the addition is known)
+    // evaluator: the ciphertext row of a level is fetched one level ahead (every step index of the addition is known)
     uint32_t tg = 0, tgn = 0;
-    if (!GARBLER) {
-        if (q < 2) tg = ld_u32_global(split_row(hc, q, st));
-        if (n > 1) {
-            if (q < 2) tgn = ld_u32_global(split_row(hc, q, st + 1));
-            else if (2 < n) tgn = ld_u32_global(split_row(hc, q, st + 2));
-        }
+    if (!GARBLER && q < 2) {
+        tg = ld_u32_global(split_row(hc, q, st));
+        if (n > 1) tgn = ld_u32_global(split_row(hc, q, st + 1));
     }
-    // level 0: G = ((x ^ cin) & (y ^ cin)) ^ cin
-    if (q < 2) split_hash_core<GARBLER>(hc, q, act, st, xg ^ cg, yg ^ cg, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord, tg);
+    // first AND: G = ((x ^ cin) & (y ^ cin)) ^ cin.  Results of level k go to buffer (k + 1) & 1; this step counts as level -1
+    if (q < 2) {
+        const uint32_t xg = ld_u32_lds(opx + g), yg = ld_u32_lds(opy + g), cg = ld_u32_lds(opc + g);
+        split_hash_core<GARBLER>(hc, q, act, st, xg ^ cg, yg ^ cg, hc.sx + kSplitKs + q * kSplitWord, tg);
+    }
     st += 1;
     lds_barrier();
-    uint32_t Gown = cg, Pown = P;                                                // (G, Pg) of the own gate, one level behind the hashes
-    bool prev_first = true, prev_dual = false;
-    for (int dist = 1; dist < n; dist <<= 1) {
-        const uint32_t *X = hc.sx + kSplitKs + par * 4 * kSplitWord + pl;        // results of the previous level
-        const uint32_t *Gs = hc.sx + kSplitGs + (par ^ 1) * kSplitWord + pl;     // G two levels back (written during the previous level)
-        const int gs = gate - dist;
-        const bool sv = gs >= 0;
-        const int gsc = sv ? gs : 0;
-        // own gate
-        Gown ^= ld_u32_lds(X + gate) ^ ld_u32_lds(X + kSplitWord + gate);
-        if (prev_dual) Pown = ld_u32_lds(X + 2 * kSplitWord + gate) ^ ld_u32_lds(X + 3 * kSplitWord + gate);
-        // shifted gate
-        uint32_t Gsh = ld_u32_lds(X + gsc) ^ ld_u32_lds(X + kSplitWord + gsc);
-        uint32_t Psh;
-        if (prev_first) {
-            Gsh ^= ld_u32_lds(opc + gsc);
-            Psh = ld_u32_lds(opx + gsc) ^ ld_u32_lds(opy + gsc);
-        } else {
-            Gsh ^= ld_u32_lds(Gs + gsc);
-            Psh = ld_u32_lds(X + 2 * kSplitWord + gsc) ^ ld_u32_lds(X + 3 * kSplitWord + gsc);
-        }
-        if (!sv) { Gsh = 0u; Psh = 0u; }
-        if (q == 0) st_u32_lds(hc.sx + kSplitGs + par * kSplitWord + pl + gate, Gown);      // snapshot for the level after this one
-        par ^= 1;
-        const uint64_t hi = act & ~((dist >= 64) ? ~0ull : ((1ull << dist) - 1ull));
-        const bool dual = (dist << 1) < n;
+    int k = 0;
+    for (int h = 1; h < n; h <<= 1, k++) {
+        const uint32_t *X0 = hc.sx + kSplitKs + ((k & 1) * 4) * kSplitWord + pl, *X1 = X0 + kSplitWord;   // results of level k - 1
+        const uint32_t *Gp = hc.sx + kSplitGs + (((k - 1) & 1) * 2) * kSplitWord + pl, *Pp = Gp + kSplitWord;   // published state k - 2
+        const int hp = h >> 1;
+        const uint64_t bitk = bit_lanes(k) & act;
+        const uint64_t pn = ((2 * h) < n) ? (bitk & ~(((2 * h) >= 64) ? ~0ull : ((1ull << (2 * h)) - 1ull))) : 0ull;
+        const uint64_t stepact = bitk | (pn >> h);
         tg = tgn;
-        if (!GARBLER && (dist << 1) < n) {                                        // rows of the next level
-            const uint64_t sn = st + (dual ? 2 : 1);
-            if (q < 2) tgn = ld_u32_global(split_row(hc, q, sn));
-            else if ((dist << 2) < n) tgn = ld_u32_global(split_row(hc, q, sn + 1));
+        if (!GARBLER && q < 2 && (2 * h) < n) tgn = ld_u32_global(split_row(hc, q, st + 1));     // row of the next level
+        // The state after level k - 1 at the two lanes this lane needs, WITHOUT branches (every load is issued before the
+        // first wait; a divergent if / else per role and per case cost two to four LDS round trips per level):
+        //   own node t = g (G-gate lane) or g + h (P-gate host):   P
+        //   m = top lane of the lower half of the block:           G (G-gate lane) or P (host)
+        // level 0 reads the first AND's results and the operand words; later levels the published state and the last results
+        if (q < 2) {
+            const bool up = (bitk >> g) & 1ull, host = ((pn >> h) >> g) & 1ull;
+            const int mb = (g & ~(2 * h - 1)) | (h - 1);
+            const int t = up ? g : ((g + h) & 63);
+            uint32_t a_op, b_op;
+            if (k == 0) {
+                const uint32_t px = ld_u32_lds(opx + t), py = ld_u32_lds(opy + t);
+                const uint32_t m0 = ld_u32_lds(X0 + mb), m1 = ld_u32_lds(X1 + mb), mc = ld_u32_lds(opc + mb);
+                const uint32_t mx = ld_u32_lds(opx + mb), my = ld_u32_lds(opy + mb);
+                a_op = px ^ py;
+                b_op = up ? (m0 ^ m1 ^ mc) : (mx ^ my);
+            } else {
+                const bool tp = ((t >> (k - 1)) & 1) && t >= h;                  // t was a P-node of level k - 1
+                const int ti = tp ? t - hp : t;
+                const uint32_t p1 = ld_u32_lds((tp ? X0 : Pp) + ti), p2 = ld_u32_lds(X1 + ti);
+                const int mi = up ? mb : ((mb - hp) & 63);                     // (m is a G-node and, for hosts, a P-node of level k - 1)
+                const uint32_t m0 = ld_u32_lds(X0 + mi), m1 = ld_u32_lds(X1 + mi), mg = ld_u32_lds(Gp + mb);
+                a_op = tp ? (p1 ^ p2) : p1;
+                b_op = m0 ^ m1 ^ (up ? mg : 0u);
+            }
+            if (!(up || host)) { a_op = 0u; b_op = 0u; }
+            split_hash_core<GARBLER>(hc, q, stepact, st, a_op, b_op, hc.sx + kSplitKs + (((k + 1) & 1) * 4 + q) * kSplitWord, tg);
+        } else if (q == 2) {
+            // publish state k - 1 of the own lane (read at level k + 1)
+            uint32_t *Go = hc.sx + kSplitGs + ((k & 1) * 2) * kSplitWord + pl;
+            const uint32_t x0 = ld_u32_lds(X0 + g), x1 = ld_u32_lds(X1 + g);
+            uint32_t Gs, Ps;
+            if (k == 0) {
+                Gs = x0 ^ x1 ^ ld_u32_lds(opc + g);
+                Ps = ld_u32_lds(opx + g) ^ ld_u32_lds(opy + g);
+            } else {
+                const bool gp = ((g >> (k - 1)) & 1) && g >= h;
+                const int gi = gp ? g - hp : g;
+                const uint32_t p1 = ld_u32_lds((gp ? X0 : Pp) + gi), p2 = ld_u32_lds(X1 + gi), go = ld_u32_lds(Gp + g);
+                Gs = go ^ (((g >> (k - 1)) & 1) ? (x0 ^ x1) : 0u);
+                Ps = gp ? (p1 ^ p2) : p1;
+            }
+            st_u32_lds(Go + g, Gs);
+            st_u32_lds(Go + kSplitWord + g, Ps);
         }
-        if (q < 2) split_hash_core<GARBLER>(hc, q, hi, st, Pown, Gsh, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord, tg);
-        else if (dual) split_hash_core<GARBLER>(hc, q, hi, st + 1, Pown, Psh, hc.sx + kSplitKs + (par * 4 + q) * kSplitWord, tg);
-        st += dual ? 2 : 1;
-        prev_first = false;
-        prev_dual = dual;
+        st += 1;
         lds_barrier();
     }
-    // carries = shl(G, 1) ^ cin on the active lanes; sum = P ^ carries; final G for the carry out
-    {
-        const uint32_t *X = hc.sx + kSplitKs + par * 4 * kSplitWord + pl;
-        const uint32_t *Gs = hc.sx + kSplitGs + (par ^ 1) * kSplitWord + pl;
-        Gown ^= ld_u32_lds(X + gate) ^ ld_u32_lds(X + kSplitWord + gate);
-        const int gs = gate - 1;
-        const int gsc = gs >= 0 ? gs : 0;
-        uint32_t Gsh = ld_u32_lds(X + gsc) ^ ld_u32_lds(X + kSplitWord + gsc);
-        Gsh ^= prev_first ? ld_u32_lds(opc + gsc) : ld_u32_lds(Gs + gsc);
-        if (gs < 0 || !((act >> gate) & 1ull)) Gsh = 0u;
-        if (q == 0) {
-            st_u32_lds(hc.sx + kSplitX + pl + gate, P ^ Gsh ^ cg);
-            st_u32_lds(hc.sx + kSplitX + kSplitWord + pl + gate, Gown);
-        }
+    // carries = shl(G, 1) ^ cin on the active lanes; sum = P ^ carries; the final generate word for the carry out.
+    // Final G at lane t: the state after the last level (k levels were run)
+    if (q == 0) {
+        const uint32_t *X0 = hc.sx + kSplitKs + ((k & 1) * 4) * kSplitWord + pl, *X1 = X0 + kSplitWord;
+        const uint32_t *Gp = hc.sx + kSplitGs + (((k - 1) & 1) * 2) * kSplitWord + pl;
+        auto G_fin = [&](int t) -> uint32_t {
+            const uint32_t xr = ld_u32_lds(X0 + t) ^ ld_u32_lds(X1 + t);
+            if (k == 0) return xr ^ ld_u32_lds(opc + t);
+            return ld_u32_lds(Gp + t) ^ (((t >> (k - 1)) & 1) ? xr : 0u);
+        };
+        const uint32_t P0 = ld_u32_lds(opx + g) ^ ld_u32_lds(opy + g), cg = ld_u32_lds(opc + g);
+        const bool in = g < n;
+        const uint32_t Gsh = (in && g > 0) ? G_fin(g - 1) : 0u;
+        st_u32_lds(hc.sx + kSplitX + pl + g, P0 ^ Gsh ^ cg);
+        st_u32_lds(hc.sx + kSplitX + kSplitWord + pl + g, in ? G_fin(g) : 0u);
     }
 }
 
@@ -315,19 +336,19 @@ struct SplitBackend {
         c1 = bit(act1) ? (result(0) ^ result(1)) : 0u;
         c2 = bit(act2) ? (result(2) ^ result(3)) : 0u;
     }
-    // x + y + carry-in over lanes [0, n) as one posted job (Circ::add picks this up): same gate steps as the generic
-    // Kogge-Stone code, two barriers around the whole addition plus one per level instead of two per level
-    __device__ __forceinline__ W add_native_ks(W x, W y, int n, W cinw, W *cout) {
+    // x + y + carry-in over lanes [0, n) as one posted job (Circ::add picks this up): same gate steps as Circ::add_generic,
+    // two barriers around the whole addition plus one per level instead of two per level
+    __device__ __forceinline__ W add_native(W x, W y, int n, W cinw, W *cout) {
         const uint64_t act = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
         SplitDesc d = {3u, act, 0ull, step};
         step += 1;
-        for (int dist = 1; dist < n; dist <<= 1) step += ((dist << 1) < n) ? 2 : 1;
+        for (int h = 1; h < n; h <<= 1) step += 1;
         publish(0, x);
         publish(1, y);
         publish(2, cinw);
         post(d);
         lds_barrier();
-        split_ks_add<GARBLER>(hc, d);
+        split_sk_add<GARBLER>(hc, d);
         lds_barrier();
         if (cout) *cout = bcast(result(1), n - 1);
         return result(0);
@@ -373,7 +394,7 @@ gc_split_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *
             d.act1 = ((uint64_t)rfl(lo.z) << 32) | rfl(lo.y);
             d.act2 = ((uint64_t)rfl(hi.x) << 32) | rfl(lo.w);
             d.step = ((uint64_t)rfl(hi.z) << 32) | rfl(hi.y);
-            if (d.kind == 3u) split_ks_add<GARBLER>(hc, d);
+            if (d.kind == 3u) split_sk_add<GARBLER>(hc, d);
             else split_hash_phase<GARBLER>(hc, d);
             lds_barrier();
         }
