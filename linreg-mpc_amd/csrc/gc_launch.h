@@ -35,7 +35,10 @@ static constexpr int kTpbMackG = GC_TPB_MACKG, kTpbMackE = GC_TPB_MACKE;
 // generic launches with at least this many records run one wave per record (throughput);
 // narrower ones run one 4-wave workgroup per record (latency)
 #ifndef GC_WIDE_LAUNCH
-#define GC_WIDE_LAUNCH 2048
+#define GC_WIDE_LAUNCH 520   /* beyond the 512 records that two 4-wave workgroups per CU hold at once (the 800 dividers of an
+                                8-lambda block would take two rounds there).  Round 2 had 2048: with Kogge-Stone adders a level
+                                was a dual step, which the 4-wave kernel splits over its waves; the levels of the Sklansky
+                                adder are single steps.  scripts/dbg/wide_ab.sh: 8-lambda block 0.861 -> 0.826 s */
 #endif
 #ifndef GC_WIDE_ADAPT
 #define GC_WIDE_ADAPT 1
