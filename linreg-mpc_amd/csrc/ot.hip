@@ -114,17 +114,37 @@ __device__ __forceinline__ uint64_t transpose64_lanes(uint64_t x, int lane) {
     }
     return x;
 }
+// One wave transposes EIGHT consecutive 64-OT groups: lane l then reads 64 contiguous bytes of column l (and of column
+// 64 + l) -- whole 64-byte sectors.  With one group per wave a lane read 8 bytes per column, each from a cache line of
+// its own (the columns are m / 8 bytes apart): an eighth of every sector fetched was used, and the transpose, not the
+// hashing, was the longest kernel of a batch (profiles/r3b_ot_kernel_stats.csv: 2 x 0.70 ms of 4.55 ms).
 __global__ void __launch_bounds__(256)
 ot_transpose_kernel(const uint64_t *cols, uint32_t m128, uint4 *rows, uint64_t m) {
     const int lane = threadIdx.x & 63;
     const uint64_t wv = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t i0 = wv * 64;
+    const uint64_t i0 = wv * 512;
     if (i0 >= m) return;
-    // lane l: bits i0..i0+63 of column l / column 64 + l
-    const uint64_t w0 = cols[((size_t)lane * m128) * 2 + (i0 >> 6)];
-    const uint64_t w1 = cols[((size_t)(64 + lane) * m128) * 2 + (i0 >> 6)];
-    const uint64_t r0 = transpose64_lanes(w0, lane), r1 = transpose64_lanes(w1, lane);
-    if (i0 + lane < m) rows[i0 + lane] = make_uint4((uint32_t)r0, (uint32_t)(r0 >> 32), (uint32_t)r1, (uint32_t)(r1 >> 32));
+    const uint64_t w64 = (uint64_t)m128 * 2;                       // 64-bit words per column
+    const uint64_t first = i0 >> 6;                                // multiple of 8: 64-byte aligned within a column
+    uint64_t a[8], b[8];
+    const uint64_t *c0 = cols + (uint64_t)lane * w64 + first, *c1 = cols + (uint64_t)(64 + lane) * w64 + first;
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) {
+        if (first + t + 1 < w64) {                                 // (w64 is even: pairs never straddle the end)
+            const uint4 u = *reinterpret_cast<const uint4 *>(c0 + t), v = *reinterpret_cast<const uint4 *>(c1 + t);
+            a[t] = (uint64_t)u.x | ((uint64_t)u.y << 32); a[t + 1] = (uint64_t)u.z | ((uint64_t)u.w << 32);
+            b[t] = (uint64_t)v.x | ((uint64_t)v.y << 32); b[t + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        } else {
+            a[t] = a[t + 1] = b[t] = b[t + 1] = 0;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const uint64_t i = i0 + 64 * (uint64_t)t + (uint64_t)lane;
+        if (i0 + 64 * (uint64_t)t >= m) break;                     // wave-uniform
+        const uint64_t r0 = transpose64_lanes(a[t], lane), r1 = transpose64_lanes(b[t], lane);
+        if (i < m) rows[i] = make_uint4((uint32_t)r0, (uint32_t)(r0 >> 32), (uint32_t)r1, (uint32_t)(r1 >> 32));
+    }
 }
 
 __device__ __forceinline__ Lbl u4_lbl(uint4 v) { Lbl l = {v.x, v.y, v.z, v.w}; return l; }
@@ -440,7 +460,7 @@ static int recv_extend(lgc_ot_receiver *r, lgc_ot_receiver::Slot *sl, uint64_t m
     OTLAUNCH();
     if (!r->dev_io) OTCHK(hipMemcpyAsync(u_out, U, cbytes, hipMemcpyDeviceToHost, r->st));   // overlaps the transpose
     const uint64_t mp = (uint64_t)m128 * 128;
-    hipLaunchKernelGGL(ot_transpose_kernel, dim3((unsigned)((mp / 64 + 3) / 4)), dim3(256), 0, r->st, (const uint64_t *)r->T0.p, m128,
+    hipLaunchKernelGGL(ot_transpose_kernel, dim3((unsigned)((mp / 512 + 4) / 4)), dim3(256), 0, r->st, (const uint64_t *)r->T0.p, m128,
                        (uint4 *)sl->rows.p, mp);
     OTLAUNCH();
     OTCHK(hipStreamSynchronize(r->st));
@@ -463,7 +483,7 @@ static int send_extend(lgc_ot_sender *s, uint64_t m, const uint8_t *u_in) {
                        (const uint4 *)0, U, s->delta, (uint4 *)s->Q.p, (uint4 *)0);
     OTLAUNCH();
     const uint64_t mp = (uint64_t)m128 * 128;
-    hipLaunchKernelGGL(ot_transpose_kernel, dim3((unsigned)((mp / 64 + 3) / 4)), dim3(256), 0, s->st, (const uint64_t *)s->Q.p, m128,
+    hipLaunchKernelGGL(ot_transpose_kernel, dim3((unsigned)((mp / 512 + 4) / 4)), dim3(256), 0, s->st, (const uint64_t *)s->Q.p, m128,
                        (uint4 *)s->rows.p, mp);
     OTLAUNCH();
     s->ctr += m128;
