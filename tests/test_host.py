@@ -444,3 +444,20 @@ def test_phase1_in_32_bits(tmp_path, oracle, extra):
     got = re.findall("-?[0-9]+\\.[0-9]+", outs[1].strip().splitlines()[-1])
     beta = oracle.linreg_file(path, 24, -1, 32, 32, 0, 0, 0.01)
     assert got == ["%.15f" % (int(v) / 2.0 ** 24) for v in beta]
+
+
+def test_host_parsers_under_address_sanitizer(tmp_path):
+    """pmsg.c (wire message from a peer) and config.c (input-file header) compiled with ASan + UBSan and fed round trips,
+    every truncation and mutated bytes, each input in a heap block of exactly its length (tests/tools/asan_host.c)"""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "asan_host")
+    cc = subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", HOST,
+                         os.path.join(ROOT, "tests", "tools", "asan_host.c"), os.path.join(HOST, "pmsg.c"), os.path.join(HOST, "config.c"),
+                         "-o", exe], capture_output=True, text=True)
+    if cc.returncode != 0 and "cannot find" in cc.stderr and "san" in cc.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and run.stdout.rstrip().endswith("all ok"), (run.stdout[-1500:], run.stderr[-3000:])

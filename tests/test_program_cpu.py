@@ -286,3 +286,21 @@ def test_table_ring_plan_never_overwrites_live_tables(lgc, alg, d, iters):
         if ring == 0:                                   # the default ring lets the garbler run ahead
             ahead = np.arange(len(L)) - wait - 1
             assert ahead.max() >= 2
+
+
+def test_lowering_under_address_sanitizer(tmp_path):
+    """the program builder and the record executor compiled with ASan + UBSan (CPU build: the GPU pool has no sanitizer
+    runs): every configuration's word file is a heap block of exactly n_words entries, so one word past the builder's
+    allocation is a report (tests/tools/asan_program.cpp; includes the sizes at which round 3's scratch overflow showed)"""
+    import os, shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = os.path.join(os.path.dirname(__file__), "tools", "asan_program.cpp")
+    exe = str(tmp_path / "asan_program")
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", src, "-o", exe],
+                        capture_output=True, text=True)
+    if cc.returncode != 0 and "sanitize" in cc.stderr + cc.stdout and "cannot find" in cc.stderr + cc.stdout:
+        pytest.skip("sanitizer runtime not installed")
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([exe, "full"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and run.stdout.rstrip().endswith("all ok"), (run.stdout[-1500:], run.stderr[-3000:])
