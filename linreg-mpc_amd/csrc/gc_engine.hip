@@ -34,7 +34,7 @@ int lgc_fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *lgc_last_error(void) { return g_err; }
-extern "C" const char *lgc_version(void) { return "linreg-mpc_amd gc engine r2 (gfx950, half-gates, LDS T-table AES)"; }
+extern "C" const char *lgc_version(void) { return "linreg-mpc_amd gc engine r3 (gfx950, half-gates, LDS T-table AES, Karatsuba MAC, Sklansky adders)"; }
 extern "C" int lgc_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
