@@ -52,6 +52,9 @@ if "chol" in args:     # latency-bound launches only (4-wave kernels)
         run(20, "cholesky", 0)
 if "trace" in args:
     run(100, "cgd", 2)
+if "trace500" in args:  # timeline of the two chains around the MAC launches (scripts/dbg/timeline.py reads the kernel trace)
+    run(500, "cgd", 3)
+    run(500, "cgd", 3)
 if "w32big" in args:
     run(500, "cgd", 20, w=32, p=30)
     run(500, "cgd", 20, w=32, p=30)
