@@ -160,6 +160,7 @@ typedef struct {
     uint64_t prefix_steps;                           /* the lambda-independent prefix (inputs, share sums) */
     uint64_t total_xors;                             /* XOR gates a flat gate list of this circuit would hold (word XORs x width): */
                                                      /* reporting only (bytes = 192 N_AND + 128 N_XOR)            */
+    int gate_hash;                                   /* the gate hash the program was built for (lgc_set_gate_hash) */
 } lgc_program_info;
 typedef struct lgc_program lgc_program;
 int lgc_program_build(lgc_program **out, const lgc_system *sys);
@@ -365,6 +366,24 @@ void lgc_set_split_kernels(int garbler, int evaluator);
  * plain 64 x 64 array everywhere.  Same integers either way.  Process-wide, takes effect for programs built
  * afterwards; the two roles of one solve must agree (as on every other parameter of the program). */
 void lgc_set_karatsuba(int on);
+
+/* The gate hash of the half-gates scheme, H(x, t) = pi(sigma(x) ^ t) ^ sigma(x) ^ t (this library's counterpart of the
+ * gate hash inside Obliv-C's Yao runtime, reached from execYaoProtocol, src/cmd/linreg.c:177):
+ *   0  pi = AES-128 under a fixed public key -- the reference's choice, and the default.  CDNA4 has no AES instruction:
+ *      160 LDS table lookups per block, which is what bounds every kernel of this engine on MI355X.
+ *   1  pi = the 12-round permutation of Chaskey (Mouha et al., SAC 2014; Chaskey-12 = ISO/IEC 29192-6): 4 x 32-bit
+ *      add / rotate / xor, no tables -- about 1.8x the garbling rate on MI355X.  The half-gates proof models pi as a
+ *      fixed random permutation; that is the same assumption the Chaskey MAC's own proof makes of this permutation,
+ *      but it is a DIFFERENT primitive from the reference's: an option for deployments that accept it, never a
+ *      silent default.  The circuits, gate numbering, table layout and every revealed integer are the same.
+ * Process-wide, takes effect for programs / solvers / parties created afterwards; garbler and evaluator of one solve
+ * must agree (a mismatch decodes to garbage, like any other disagreement about the program).  Returns LGC_EINVAL for an
+ * unknown kind.  lgc_gate_hash_eval computes H on n labels (16 bytes each, tweaks[i]) on the device: tests pin both
+ * kinds to the CPU checker with it. */
+int lgc_set_gate_hash(int kind);
+int lgc_gate_hash(void);
+const char *lgc_gate_hash_name(int kind);              /* "aes128", "chaskey12", NULL */
+int lgc_gate_hash_eval(int device, int kind, const uint8_t *labels, const uint64_t *tweaks, uint8_t *out, size_t n);
 
 /* Test hooks (tests/test_gpu_roles.py; not part of the drop-in surface).  lgc_test_party_garble_ring_stage
  * issues launch k as lgc_party_garble_ring does, in halves: stage 1 = the record kernel (stops before the table

@@ -218,6 +218,43 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4], con
     }
 }
 
+// ---- gate-hash option 1: the permutation of Chaskey-12 in the place of the fixed-key AES.
+// CDNA4 has no AES instruction, so the fixed-key AES above is 160 LDS lookups per block and the LDS sets the pace of
+// every kernel of this engine.  The half-gates hash only needs a fixed PUBLIC permutation pi that is modelled as random
+// (ZRE15; Guo-Katz-Wang-Yu 2020 for H(x, t) = pi(sigma(x) ^ t) ^ sigma(x) ^ t) -- which is also exactly what the security
+// proof of the Chaskey MAC asks of its 128-bit ARX permutation (Mouha, Mennink, Van Herrewege, Watanabe, Preneel,
+// Verbauwhede, SAC 2014; Chaskey-12 = ISO/IEC 29192-6).  Twelve rounds of four additions, four XORs and six rotations
+// on 4 x 32-bit words: 168 integer instructions per block, no table, no LDS.  It is an OPTION (lgc_set_gate_hash(1), both
+// roles of a solve; default 0 = the reference's fixed-key AES): same circuits, same integers, a different instantiation
+// of the random permutation.  State word i = block word i (little-endian, as in the Chaskey reference code).
+GC_HD void chaskey_round(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3) {
+    v0 += v1; v1 = rotl32(v1, 5); v1 ^= v0; v0 = rotl32(v0, 16);
+    v2 += v3; v3 = rotl32(v3, 8); v3 ^= v2;
+    v0 += v3; v3 = rotl32(v3, 13); v3 ^= v0;
+    v2 += v1; v1 = rotl32(v1, 7); v1 ^= v2; v2 = rotl32(v2, 16);
+}
+template <int N>
+GC_HD void chaskey12_permute_n(uint32_t s[N][4]) {
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+#pragma unroll
+        for (int b = 0; b < N; b++) chaskey_round(s[b][0], s[b][1], s[b][2], s[b][3]);
+    }
+}
+// the inverse round: tests only (the permutation is checked to be one, by a second piece of code)
+inline void chaskey_round_inverse(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3) {
+    auto rotr = [](uint32_t v, int k) { return (v >> k) | (v << (32 - k)); };
+    v2 = rotr(v2, 16); v1 ^= v2; v1 = rotr(v1, 7); v2 -= v1;
+    v3 ^= v0; v3 = rotr(v3, 13); v0 -= v3;
+    v3 ^= v2; v3 = rotr(v3, 8); v2 -= v3;
+    v0 = rotr(v0, 16); v1 ^= v0; v1 = rotr(v1, 5); v0 -= v1;
+}
+
+// The permutation is a property of the table accessor type T of hash_n (T::kHashKind): 0 = fixed-key AES-128 through
+// T's lookups (the reference's hash), 1 = Chaskey-12 (T carries no table).  Kernels are templates over T, so the two
+// hashes are different instantiations with different symbols.
+enum { GATE_HASH_AES = 0, GATE_HASH_CHASKEY12 = 1, GATE_HASH_KINDS = 2 };
+
 // K = sigma(x) ^ tweak, as 4 words
 GC_HD void hash_prep(Lbl x, uint64_t tweak, uint32_t k[4]) {
     k[0] = x.z ^ (uint32_t)tweak;
@@ -235,9 +272,13 @@ GC_HD void hash_n(const T &tab, const uint32_t *rk, const Lbl *x, const uint64_t
         hash_prep(x[b], tw[b], k[b]);
         s[b][0] = k[b][0]; s[b][1] = k[b][1]; s[b][2] = k[b][2]; s[b][3] = k[b][3];
     }
+    if constexpr (T::kHashKind == GATE_HASH_CHASKEY12) {
+        chaskey12_permute_n<N>(s);
+    } else {
 #ifndef GC_X_NOHASH          /* timing experiments only (scripts/exp): results are wrong with it */
-    aes_encrypt_n<N, T>(tab, rk, s, rk24);
+        aes_encrypt_n<N, T>(tab, rk, s, rk24);
 #endif
+    }
 #pragma unroll
     for (int b = 0; b < N; b++) {
         out[b].x = s[b][0] ^ k[b][0]; out[b].y = s[b][1] ^ k[b][1];
@@ -249,10 +290,21 @@ GC_HD void hash_n(const T &tab, const uint32_t *rk, const Lbl *x, const uint64_t
 struct HostTab {
     static const bool kTwoTables = false;
     static const bool kFourTables = false;
+    static const int kHashKind = 0;
     const uint32_t *te0;
     inline uint32_t lkt(int, uint32_t word, int k) const { return lk(word, k); }
     inline uint32_t lk(uint32_t word, int k) const { return te0[(word >> (8 * k)) & 0xffu]; }
     inline uint32_t lk2(uint32_t word, int k) const { return rotl32(lk(word, k), 16); }
+};
+
+// host accessor of the table-free hash (CPU checker)
+struct HostNoTab {
+    static const bool kTwoTables = false;
+    static const bool kFourTables = false;
+    static const int kHashKind = 1;
+    inline uint32_t lkt(int, uint32_t, int) const { return 0; }
+    inline uint32_t lk(uint32_t, int) const { return 0; }
+    inline uint32_t lk2(uint32_t, int) const { return 0; }
 };
 
 // ---- half-gates, one AND gate (lane-local).  gid: unique gate id.

@@ -9,6 +9,7 @@
 //   * lane moves are ds_bpermute / v_readlane; public lane masks are SGPRs
 //   * narrow launches run one record per 4-wave workgroup, the waves splitting the AES work
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -43,6 +44,7 @@ static constexpr int kLdsTabWords = 256 * 64;   // 64 KiB: entry x occupies the 
 struct LdsTab {
     static const bool kTwoTables = false;
     static const bool kFourTables = false;
+    static const int kHashKind = 0;
     const char *base;    // LDS byte address of the table
     uint32_t lane4;      // (lane << 2): fits one byte, merged into the address by v_perm_b32
     // Te0[byte k of word]: address = (byte << 8) | (lane << 2)
@@ -58,6 +60,7 @@ struct LdsTab {
 struct LdsTab2 {
     static const bool kTwoTables = true;
     static const bool kFourTables = false;
+    static const int kHashKind = 0;
     const char *base;
     uint32_t lane4;
     __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const {
@@ -94,6 +97,7 @@ __device__ __forceinline__ LdsTab2 lds_tab2_make(const uint32_t *lds) {
 struct LdsTab4 {
     static const bool kTwoTables = false;
     static const bool kFourTables = true;
+    static const int kHashKind = 0;
     const char *base;
     uint32_t c[4];       // per table: ((lane & 31) << 2) | (t & 1) << 7 | (t >> 1) << 16
     __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const { return lkt(0, word, k); }
@@ -136,6 +140,7 @@ __device__ __forceinline__ LdsTab lds_tab_make(const uint32_t *lds) {
 struct LdsTab2h {
     static const bool kTwoTables = true;
     static const bool kFourTables = false;
+    static const int kHashKind = 0;
     const char *base;
     uint32_t c0, c1;
     __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const {
@@ -163,8 +168,24 @@ __device__ __forceinline__ LdsTab2h lds_tab2h_make(const uint32_t *lds) {
     return t;
 }
 
-// table variant by number: 2 = LdsTab2h (64 KiB), 4 = LdsTab4 (128 KiB)
+// the accessor of the table-free gate hash (Chaskey-12 permutation, gc_aes.h): nothing to look up, no LDS
+struct NoTab {
+    static const bool kTwoTables = false;
+    static const bool kFourTables = false;
+    static const int kHashKind = 1;
+    __device__ __forceinline__ uint32_t lk(uint32_t, int) const { return 0u; }
+    __device__ __forceinline__ uint32_t lk2(uint32_t, int) const { return 0u; }
+    __device__ __forceinline__ uint32_t lkt(int, uint32_t, int) const { return 0u; }
+};
+
+// table variant by number: 2 = LdsTab2h (64 KiB), 4 = LdsTab4 (128 KiB), 0 = none (gate hash 1)
 template <int TABV> struct TabSel;
+template <> struct TabSel<0> {
+    typedef NoTab T;
+    static constexpr int kWords = 1;
+    static __device__ __forceinline__ void fill(uint32_t *) {}
+    static __device__ __forceinline__ T make(const uint32_t *) { return NoTab(); }
+};
 template <> struct TabSel<2> {
     typedef LdsTab2h T;
     static constexpr int kWords = kLdsTabWords;
@@ -527,20 +548,23 @@ struct GpuBackend {
 #define GC_MAC_PERSIST 0
 #endif
 // MAC launches: one wavefront per record; the TPB/64 waves of a workgroup share the LDS table
-template <bool GARBLER, int TPB>
+template <bool GARBLER, int TPB, int HK = 0>
 __global__ void __launch_bounds__(TPB)
 gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
-    __shared__ uint32_t lds_te0[2 * kLdsTabWords];   // Te0 | Te2: 128 KiB, one workgroup per CU
+    // HK = 0: Te0 | Te2 or the four rotated tables: 128 KiB, one workgroup per CU.  HK = 1 (table-free gate hash): no LDS
+    __shared__ uint32_t lds_te0[HK == 1 ? 1 : 2 * kLdsTabWords];
+    if constexpr (HK == 0) {
 #if GC_AES_TAB4
-    lds_tab4_fill(lds_te0);
+        lds_tab4_fill(lds_te0);
 #else
-    lds_tab2_fill(lds_te0);
+        lds_tab2_fill(lds_te0);
 #endif
+    }
     const int lane = threadIdx.x & 63;
 #if GC_AES_TAB4
-    typedef GpuBackend<GARBLER, MODE_MAC, LdsTab4> B;
+    typedef GpuBackend<GARBLER, MODE_MAC, typename std::conditional<HK == 1, NoTab, LdsTab4>::type> B;
 #else
-    typedef GpuBackend<GARBLER, MODE_MAC, LdsTab2> B;
+    typedef GpuBackend<GARBLER, MODE_MAC, typename std::conditional<HK == 1, NoTab, LdsTab2>::type> B;
 #endif
     B be;
     be.R = R;
@@ -552,11 +576,13 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
     be.lane = lane;
     be.wave = 0;
     be.xch = 0;
+    if constexpr (HK == 0) {
 #if GC_AES_TAB4
-    be.lt = lds_tab4_make(lds_te0);
+        be.lt = lds_tab4_make(lds_te0);
 #else
-    be.lt = lds_tab2_make(lds_te0);
+        be.lt = lds_tab2_make(lds_te0);
 #endif
+    }
     typedef Circ<B> C;
     // GC_MAC_PERSIST: a grid of one workgroup per CU whose waves walk the records round-robin with the WORKGROUP index
     // running fastest, so that a partly filled last round is spread over all CUs.  Measured: the garbler's MAC launches
@@ -599,12 +625,12 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
 // each of the two recombination loops; the nine sub-product words of a pair wait in scratch memory meanwhile.
 // (Out-of-line gates for the recombination, or one kernel for OP_MAC and OP_MACK together, measured no faster / slower:
 // the combined kernel spilled 175 VGPRs.)
-template <bool GARBLER, int TPB>
+template <bool GARBLER, int TPB, int HK = 0>
 __global__ void __launch_bounds__(TPB)
 gc_mack_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
-    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
-    lds_tab4_fill(lds_te0);
-    typedef GpuBackend<GARBLER, MODE_MAC, LdsTab4> B;
+    __shared__ uint32_t lds_te0[HK == 1 ? 1 : 2 * kLdsTabWords];
+    if constexpr (HK == 0) lds_tab4_fill(lds_te0);
+    typedef GpuBackend<GARBLER, MODE_MAC, typename std::conditional<HK == 1, NoTab, LdsTab4>::type> B;
     B be;
     be.R = R;
     be.words = words;
@@ -615,7 +641,7 @@ gc_mack_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t la
     be.lane = threadIdx.x & 63;
     be.wave = 0;
     be.xch = 0;
-    be.lt = lds_tab4_make(lds_te0);
+    if constexpr (HK == 0) be.lt = lds_tab4_make(lds_te0);
     const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wid >= nrec) return;
     Rec r = recs[wid];

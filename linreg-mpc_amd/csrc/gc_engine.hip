@@ -168,6 +168,26 @@ gc_aes_encrypt_kernel(const uint4 *in, uint4 *out, uint32_t n) {
     out[i] = (i & 1) ? make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]) : make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
 }
 
+// the gate hash H(x, t) of kind `kind` (gc_aes.h) on n labels: what the record kernels compute per half gate; pins the
+// device code of both kinds to the host code (tests)
+__global__ void __launch_bounds__(256)
+gc_gate_hash_kernel(const uint4 *in, const uint64_t *tweak, uint4 *out, uint32_t n, int kind) {
+    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint4 v = i < n ? in[i] : make_uint4(0, 0, 0, 0);
+    Lbl x = {v.x, v.y, v.z, v.w}, h = lzero();
+    uint64_t tw = i < n ? tweak[i] : 0;
+    if (kind == GATE_HASH_CHASKEY12) {
+        NoTab nt;
+        hash_n<1, NoTab>(nt, c_rk, &x, &tw, &h);
+    } else {
+        lds_tab4_fill(lds_te0);
+        LdsTab4 l4 = lds_tab4_make(lds_te0);
+        hash_n<1, LdsTab4>(l4, c_rk, &x, &tw, &h, c_rk24);
+    }
+    if (i < n) out[i] = make_uint4(h.x, h.y, h.z, h.w);
+}
+
 // ------------------------------------------------------------------ program
 struct lgc_program {
     Program P;
@@ -282,6 +302,7 @@ extern "C" int lgc_program_info_get(const lgc_program *p, lgc_program_info *info
     info->prefix_launches = P.prefix_launches;
     info->prefix_steps = P.prefix_steps;
     info->total_xors = P.total_xors;
+    info->gate_hash = P.gate_hash;
     return LGC_OK;
 }
 static_assert(sizeof(lgc_record) == sizeof(Rec), "record layout");
@@ -573,19 +594,19 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
             HIPCHK(hipStreamWaitEvent(sG, s->evE[i - 1], 0));
 #endif
         if (timed) HIPCHK(hipEventRecord(s->evs[3 * i], sG));
-        const LaunchMode modeG = gc_launch_mode(L, true);      // read once: record kernel and table pass agree
+        const LaunchMode modeG = gc_launch_mode(L, true, P.gate_hash);      // read once: record kernel and table pass agree
         if (pre && i < P.prefix_launches) {          // tables already in the ring
             if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
             if (!profile) HIPCHK(hipEventRecord(s->evG[i], sG));
         } else if (profile || !gc_mode_is_crit(modeG, L)) {
-            HIPCHK(gc_launch_records<true>(modeG, s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
+            HIPCHK(gc_launch_records<true>(modeG, P.gate_hash, s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
             if (gc_mode_is_crit(modeG, L)) HIPCHK(gc_launch_tabfill(L, tab, tab, s->R, sG));
             if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
             if (!profile) HIPCHK(hipEventRecord(s->evG[i], sG));
         } else {
             // critical path on the garbler chain, table pass on the side stream: only the evaluation waits for it.
             // The stash is the launch's own ring region (in place): this ring is private to the process
-            HIPCHK(gc_launch_records<true>(modeG, s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
+            HIPCHK(gc_launch_records<true>(modeG, P.gate_hash, s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
             if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
             HIPCHK(hipEventRecord(s->evC[i], sG));
             HIPCHK(hipStreamWaitEvent(s->streamT, s->evC[i], 0));
@@ -594,11 +615,11 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
         }
         if (!profile) HIPCHK(hipStreamWaitEvent(sE, s->evG[i], 0));
         if (profile) {
-            HIPCHK(gc_launch<false>(s->recs, L, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
+            HIPCHK(gc_launch<false>(s->recs, L, P.gate_hash, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
             HIPCHK(hipEventRecord(s->evs[3 * i + 2], sE));
         } else {
             if (L.mac_only) HIPCHK(hipEventRecord(s->evs[3 * i + 2], sE));   // start of the evaluate kernel
-            HIPCHK(gc_launch<false>(s->recs, L, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
+            HIPCHK(gc_launch<false>(s->recs, L, P.gate_hash, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
             HIPCHK(hipEventRecord(s->evE[i], sE));
         }
         while (next_iter < P.iter_launch.size() && P.iter_launch[next_iter] == i)
@@ -674,7 +695,7 @@ extern "C" int lgc_solver_prefix_garble(lgc_solver *s) {
     HIPCHK(hipGetLastError());
     for (uint32_t i = 0; i < P.prefix_launches; i++) {
         Lbl *tab = reinterpret_cast<Lbl *>(reinterpret_cast<char *>(s->tab) + s->tab_off[i]);
-        HIPCHK(gc_launch<true>(s->recs, P.launches[i], s->wordsG, s->decG, tab, s->R, P.w, P.p, s->stream));
+        HIPCHK(gc_launch<true>(s->recs, P.launches[i], P.gate_hash, s->wordsG, s->decG, tab, s->R, P.w, P.p, s->stream));
     }
     HIPCHK(hipStreamSynchronize(s->stream));
     s->prefix_ready = true;
@@ -816,6 +837,34 @@ extern "C" int lgc_reference_gate_count(int algorithm, int width, size_t d, int 
 }
 
 extern "C" void lgc_set_karatsuba(int on) { program_karatsuba() = on != 0; }
+extern "C" int lgc_set_gate_hash(int kind) {
+    if (kind < 0 || kind >= GATE_HASH_KINDS) return lgc_fail(LGC_EINVAL, "gate hash %d: 0 (fixed-key AES-128) or 1 (Chaskey-12 permutation)", kind);
+    program_gate_hash() = kind;
+    return LGC_OK;
+}
+extern "C" int lgc_gate_hash(void) { return program_gate_hash(); }
+extern "C" const char *lgc_gate_hash_name(int kind) {
+    return kind == GATE_HASH_AES ? "aes128" : (kind == GATE_HASH_CHASKEY12 ? "chaskey12" : (const char *)0);
+}
+extern "C" int lgc_gate_hash_eval(int device, int kind, const uint8_t *labels, const uint64_t *tweaks, uint8_t *out, size_t n) {
+    if (kind < 0 || kind >= GATE_HASH_KINDS || !labels || !tweaks || !out) return lgc_fail(LGC_EINVAL, "gate hash kind / null argument");
+    DevFree dev_guard;
+    int rc = lgc_need_device(device);
+    if (rc) return rc;
+    rc = lgc_upload_constants();
+    if (rc) return rc;
+    uint4 *di = 0, *dout = 0;
+    uint64_t *dt = 0;
+    HIPCHK(hipMalloc(&di, n * 16 + 16)); dev_guard.add(di);
+    HIPCHK(hipMalloc(&dout, n * 16 + 16)); dev_guard.add(dout);
+    HIPCHK(hipMalloc(&dt, n * 8 + 8)); dev_guard.add(dt);
+    HIPCHK(hipMemcpy(di, labels, n * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dt, tweaks, n * 8, hipMemcpyHostToDevice));
+    if (n) hipLaunchKernelGGL(gc_gate_hash_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, di, dt, dout, (uint32_t)n, kind);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dout, n * 16, hipMemcpyDeviceToHost));
+    return LGC_OK;
+}
 extern "C" void lgc_set_split_kernels(int garbler, int evaluator) {
     gc_split_enabled(true).store(garbler != 0);
     gc_split_enabled(false).store(evaluator != 0);

@@ -1,6 +1,6 @@
-// gc_kernels.h -- the kernel dispatch of a launch: included by gc_kern.hip only, which is compiled eight times (role x
-// kernel family, csrc/Makefile) and exports the pieces as plain functions (declared in gc_launch.h).  Everything else
-// in the library calls those.
+// gc_kernels.h -- the kernel dispatch of a launch: included by gc_kern.hip only, which is compiled once per (role, kernel
+// family, gate hash) (csrc/Makefile) and exports the pieces as plain functions (declared in gc_launch.h).  Everything
+// else in the library calls those.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,7 +21,9 @@ static inline hipError_t gc_launch_tabfill_impl(const Launch &L, const Lbl *stas
 
 // the record kernel of a launch in mode `m` (garbler in a critical-path mode: `tab` is the stash)
 // PART: which kernels this translation unit instantiates (gc_kern.hip): 0 = MAC, 1 = generic one wave per record (wide), 2 = column-split, 3 = generic 4 waves per record
-template <bool G, int PART>
+// HK: the gate hash (gc_aes.h): 0 = fixed-key AES (tables in LDS), 1 = Chaskey-12 permutation (no tables; the
+// column-split and critical-path kernels hash in their own AES layouts and exist for HK = 0 only)
+template <bool G, int PART, int HK = 0>
 static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R, int w,
                                     int p, hipStream_t st) {
     switch (m) {
@@ -38,9 +40,9 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
         const uint32_t round = gc_num_cus() * per, full = L.nrec / round * round, rest = L.nrec - full;
         if (!GC_MAC_ADAPT && full && rest && rest < round - round / 8) {
             unsigned wv = (rest + gc_num_cus() - 1) / gc_num_cus();
-            hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3(full / per), dim3(per * 64), 0, st, recs + L.first_rec, full, words,
+            hipLaunchKernelGGL((gc_mac_kernel<G, TPB, HK>), dim3(full / per), dim3(per * 64), 0, st, recs + L.first_rec, full, words,
                                tab, L.step0, R, w, p);
-            hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((rest + wv - 1) / wv), dim3(wv * 64), 0, st, recs + L.first_rec + full, rest,
+            hipLaunchKernelGGL((gc_mac_kernel<G, TPB, HK>), dim3((rest + wv - 1) / wv), dim3(wv * 64), 0, st, recs + L.first_rec + full, rest,
                                words, tab, L.step0, R, w, p);
             return hipGetLastError();
         }
@@ -49,12 +51,12 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
 #if GC_MAC_PERSIST      /* one workgroup per CU: the waves walk the records themselves (gc_device.h) */
         if (G && wgs > gc_num_cus() && wgs <= GC_MAC_PERSIST_MAX_ROUNDS * gc_num_cus()) wgs = gc_num_cus();
 #endif
-        hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3(wgs), dim3(per * 64), 0, st, recs + L.first_rec, L.nrec, words, tab,
+        hipLaunchKernelGGL((gc_mac_kernel<G, TPB, HK>), dim3(wgs), dim3(per * 64), 0, st, recs + L.first_rec, L.nrec, words, tab,
                            L.step0, R, w, p);
     } break;
     case LM_MACK: if constexpr (PART == 0) {
         constexpr int TPB = G ? kTpbMackG : kTpbMackE;
-        hipLaunchKernelGGL((gc_mack_kernel<G, TPB>), dim3((L.nrec + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, st, recs + L.first_rec,
+        hipLaunchKernelGGL((gc_mack_kernel<G, TPB, HK>), dim3((L.nrec + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, st, recs + L.first_rec,
                            L.nrec, words, tab, L.step0, R, w, p);
     } break;
     case LM_WIDE: if constexpr (PART == 1) {
@@ -63,11 +65,11 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
         unsigned per = (L.nrec + gc_num_cus() - 1) / gc_num_cus();
         if (per > (unsigned)kTpbWide / 64) per = kTpbWide / 64;
         if (!GC_WIDE_ADAPT) per = kTpbWide / 64;
-        hipLaunchKernelGGL((gc_exec_kernel<G, false, 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(per * 64), 0, st,
+        hipLaunchKernelGGL((gc_exec_kernel<G, false, HK == 1 ? 0 : 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(per * 64), 0, st,
                            recs + L.first_rec, L.nrec, words, tab, dec, L.step0, R, w, p);
     } break;
     case LM_SPLIT:
-        if constexpr (PART == 2)
+        if constexpr (PART == 2 && HK == 0)
             hipLaunchKernelGGL((gc_split_kernel<G>), dim3(L.nrec), dim3(1024), 0, st, recs + L.first_rec, L.nrec, words, tab, dec,
                                L.step0, R, w, p);
         break;
@@ -75,14 +77,14 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
 #if GC_QUAD4          /* (PART 3) the 4-wave kernels with the four-table image (garbler: critical-path garbling): what ran these launches
                          before the column-split kernel; with 0 (default, 45 s less to compile) a role whose split kernel is
                          switched off runs them in the two-table 4-wave kernel below */
-        if constexpr (PART == 3)
+        if constexpr (PART == 3 && HK == 0)
             hipLaunchKernelGGL((gc_exec_kernel<G, true, 4, 256, G && GC_CRIT>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec,
                                L.nrec, words, tab, dec, L.step0, R, w, p);
         break;
 #endif
     case LM_QUAD2:
         if constexpr (PART == 3)
-            hipLaunchKernelGGL((gc_exec_kernel<G, true, 2, 256>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec, L.nrec, words,
+            hipLaunchKernelGGL((gc_exec_kernel<G, true, HK == 1 ? 0 : 2, 256>), dim3(L.nrec), dim3(256), 0, st, recs + L.first_rec, L.nrec, words,
                                tab, dec, L.step0, R, w, p);
         break;
     }

@@ -159,10 +159,13 @@ enum LaunchMode {
     LM_QUAD4,        // GC_QUAD4 builds only: 4 waves per record on the four-table image (garbler: critical path + table pass)
     LM_QUAD2         // 4 waves per record on the two-table image, two workgroups per CU
 };
-static inline LaunchMode gc_launch_mode(const Launch &L, bool garbler) {
+// hash: the program's gate hash (Program::gate_hash).  The column-split and the critical-path kernels hash in AES layouts
+// of their own: with the table-free hash (1) the narrow launches run in the plain 4-wave kernel
+static inline LaunchMode gc_launch_mode(const Launch &L, bool garbler, int hash) {
     if (L.nrec == 0) return LM_NONE;
     if (L.mac_only && L.nrec >= kNarrowMac) return L.mack ? LM_MACK : LM_MAC;
     if (L.nrec >= kWideLaunch && L.steps < (uint64_t)L.nrec * kWideMaxSteps) return LM_WIDE;
+    if (hash != GATE_HASH_AES) return LM_QUAD2;
     if (GC_SPLIT && L.nrec <= kSplitMaxRecs && gc_split_enabled(garbler).load(std::memory_order_relaxed)) return LM_SPLIT;
     if (GC_QUAD4 && L.nrec <= kQuadOnePerCu) return LM_QUAD4;
     return LM_QUAD2;
@@ -185,6 +188,7 @@ hipError_t gc_launch_tabfill(const Launch &L, const Lbl *stash, Lbl *tab, Lbl R,
                                        int p, hipStream_t st);                                                                         \
     hipError_t gc_kern_upload_##tag(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24);
 GC_KERN_DECL(g_0) GC_KERN_DECL(g_1) GC_KERN_DECL(g_2) GC_KERN_DECL(g_3) GC_KERN_DECL(e_0) GC_KERN_DECL(e_1) GC_KERN_DECL(e_2) GC_KERN_DECL(e_3)
+GC_KERN_DECL(g_0h) GC_KERN_DECL(g_1h) GC_KERN_DECL(g_3h) GC_KERN_DECL(e_0h) GC_KERN_DECL(e_1h) GC_KERN_DECL(e_3h)      // gate hash 1 (no tables: nothing to upload)
 #undef GC_KERN_DECL
 static inline hipError_t gc_kern_upload_all(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24) {
     hipError_t e = gc_kern_upload_g_0(rk, te0, rk24);
@@ -199,8 +203,17 @@ static inline hipError_t gc_kern_upload_all(const uint32_t *rk, const uint32_t *
 }
 // the record kernel of a launch in mode `m` (garbler in a critical-path mode: `tab` is the stash)
 template <bool G>
-static inline hipError_t gc_launch_records(LaunchMode m, const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R,
+static inline hipError_t gc_launch_records(LaunchMode m, int hash, const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R,
                                           int w, int p, hipStream_t st) {
+    if (hash == GATE_HASH_CHASKEY12) {
+        switch (m) {
+        case LM_NONE: return hipSuccess;
+        case LM_MAC: case LM_MACK: return G ? gc_launch_records_g_0h(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_0h(m, recs, L, words, dec, tab, R, w, p, st);
+        case LM_WIDE: return G ? gc_launch_records_g_1h(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_1h(m, recs, L, words, dec, tab, R, w, p, st);
+        case LM_QUAD2: return G ? gc_launch_records_g_3h(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_3h(m, recs, L, words, dec, tab, R, w, p, st);
+        default: return hipErrorInvalidValue;      // gc_launch_mode never picks an AES-only kernel for this hash
+        }
+    }
     switch (m) {
     case LM_NONE: return hipSuccess;
     case LM_MAC: case LM_MACK: return G ? gc_launch_records_g_0(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_0(m, recs, L, words, dec, tab, R, w, p, st);
@@ -214,14 +227,14 @@ static inline hipError_t gc_launch_records(LaunchMode m, const Rec *recs, const 
 // table pass; 0 = in the launch's own table rows (the co-located solver, whose ring no other process maps).
 // stages (test hook only): 1 = record kernel, 2 = table pass, 3 = both; *was_crit reports whether the launch has a table pass.
 template <bool G>
-static hipError_t gc_launch(const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R, int w, int p,
+static hipError_t gc_launch(const Rec *recs, const Launch &L, int hash, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R, int w, int p,
                             hipStream_t st, Lbl *stash = 0, int stages = 3, bool *was_crit = 0) {
-    const LaunchMode m = gc_launch_mode(L, G);
+    const LaunchMode m = gc_launch_mode(L, G, hash);
     const bool crit = G && gc_mode_is_crit(m, L);
     if (was_crit) *was_crit = crit;
     Lbl *rec_tab = (crit && stash) ? stash : tab;
     hipError_t e = hipSuccess;
-    if (stages & 1) e = gc_launch_records<G>(m, recs, L, words, dec, rec_tab, R, w, p, st);
+    if (stages & 1) e = gc_launch_records<G>(m, hash, recs, L, words, dec, rec_tab, R, w, p, st);
     if (e == hipSuccess && crit && (stages & 2)) e = gc_launch_tabfill(L, rec_tab, tab, R, st);
     return e;
 }

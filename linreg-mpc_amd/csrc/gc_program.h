@@ -70,6 +70,9 @@ struct Program {
     // for every lambda (lambda enters after them, linear.oc:52-57): garbled once, shared by all circuits
     uint32_t shared_end, prefix_launches;
     uint64_t prefix_steps;
+    // the gate hash both roles run this program with (gc_aes.h: 0 = fixed-key AES, 1 = Chaskey-12 permutation): fixed when
+    // the program is built (program_gate_hash), like everything else the two roles must agree on
+    int gate_hash = 0;
 
     // ---- builder state
     size_t merge_hint = 1;       // this program will be replicated this many times (replicate_program): the dot products of
@@ -483,10 +486,13 @@ static const size_t kTargetWaves = 12288;
 // Karatsuba products in the matrix-vector launches of CGD (64-bit; Circ::mack2).  Process-wide switch for A/B runs
 // (lgc_set_karatsuba); garbler and evaluator must agree, as on everything else that shapes the program.
 inline int &program_karatsuba() { static int on = 1; return on; }
+// Gate hash of the programs built from now on (lgc_set_gate_hash): process-wide, the two roles of a solve must agree.
+inline int &program_gate_hash() { static int kind = 0; return kind; }
 
 inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters, size_t nshares,
                           int normalize, uint64_t lambda_fixed, int reveal_ab, int trace) {
     P.w = w; P.p = p; P.d = d; P.nshares = nshares;
+    P.gate_hash = program_gate_hash();
     const size_t T = d * (d + 1) / 2;
     P.T = T;
     const uint32_t D = (uint32_t)d;
@@ -738,6 +744,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
 // owns the gate steps [prefix + k * per_circuit, prefix + (k + 1) * per_circuit) on whichever rank it runs.
 inline void replicate_program(Program &P, const Program &P0, size_t count, const uint64_t *lambda_fixed, size_t first_copy = 0) {
     P.w = P0.w; P.p = P0.p; P.d = P0.d; P.T = P0.T; P.nshares = P0.nshares;
+    P.gate_hash = P0.gate_hash;
     P.cap_steps = P0.cap_steps;
     P.shared_end = P0.shared_end;
     P.word_stride = P0.n_words - P0.shared_end;

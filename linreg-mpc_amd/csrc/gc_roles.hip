@@ -255,7 +255,7 @@ static hipError_t party_need_tab(lgc_party *p) {
 template <bool G>
 static hipError_t party_launch(lgc_party *p, const Launch &L, Lbl *tab = 0, int stages = 3, bool *was_crit = 0) {
     if (!tab || G) { hipError_t e = party_need_tab(p); if (e != hipSuccess) return e; }
-    return gc_launch<G>(p->recs, L, p->words, p->dec, tab ? tab : p->tab, p->R, p->P.w, p->P.p, 0, (G && tab) ? p->tab : (Lbl *)0,
+    return gc_launch<G>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab ? tab : p->tab, p->R, p->P.w, p->P.p, 0, (G && tab) ? p->tab : (Lbl *)0,
                         stages, was_crit);
 }
 

@@ -47,6 +47,19 @@ static inline void aesni_n(__m128i s[N]) {
         for (int b = 0; b < N; b++) s[b] = _mm_aesenc_si128(s[b], g_rk[r]);
     for (int b = 0; b < N; b++) s[b] = _mm_aesenclast_si128(s[b], g_rk[10]);
 }
+// the permutation of the gate hash (gc_aes.h): kind 0 = fixed-key AES (AES-NI), 1 = Chaskey-12 (the checker of
+// lgc_set_gate_hash(1); word i of the block = state word i)
+static int g_gate_hash = 0;
+template <int N>
+static inline void gate_perm_n(__m128i s[N]) {
+    if (g_gate_hash == 0) { aesni_n<N>(s); return; }
+    for (int b = 0; b < N; b++) {
+        uint32_t v[1][4];
+        _mm_storeu_si128((__m128i *)v[0], s[b]);
+        chaskey12_permute_n<1>(v);
+        s[b] = _mm_loadu_si128((const __m128i *)v[0]);
+    }
+}
 // sigma(x) ^ tweak  (gc_aes.h: hash_prep)
 static inline __m128i hprep(__m128i x, uint64_t tw) {
     __m128i sw = _mm_shuffle_epi32(x, 0x4E);                          // (x2,x3,x0,x1)
@@ -101,7 +114,7 @@ struct CpuBackend {
                 __m128i k[4] = {hprep(a0, 2 * gid), hprep(_mm_xor_si128(a0, R), 2 * gid),
                                 hprep(b0, 2 * gid + 1), hprep(_mm_xor_si128(b0, R), 2 * gid + 1)};
                 __m128i h[4] = {k[0], k[1], k[2], k[3]};
-                aesni_n<4>(h);
+                gate_perm_n<4>(h);
                 for (int i = 0; i < 4; i++) h[i] = _mm_xor_si128(h[i], k[i]);
                 const int pa = _mm_cvtsi128_si32(a0) & 1, pb = _mm_cvtsi128_si32(b0) & 1;
                 __m128i TG = _mm_xor_si128(_mm_xor_si128(h[0], h[1]), pb ? R : _mm_setzero_si128());
@@ -116,7 +129,7 @@ struct CpuBackend {
                 __m128i TG = _mm_loadu_si128(slot + lane), TE = _mm_loadu_si128(slot + 64 + lane);
                 __m128i k[2] = {hprep(av, 2 * gid), hprep(bv, 2 * gid + 1)};
                 __m128i h[2] = {k[0], k[1]};
-                aesni_n<2>(h);
+                gate_perm_n<2>(h);
                 h[0] = _mm_xor_si128(h[0], k[0]);
                 h[1] = _mm_xor_si128(h[1], k[1]);
                 const int sa = _mm_cvtsi128_si32(av) & 1, sb = _mm_cvtsi128_si32(bv) & 1;
@@ -382,6 +395,42 @@ void gcc_aes_encrypt_ttable(const uint8_t *in, uint8_t *out, size_t n) {
         aes_encrypt_n<1, HostTab>(ht, g_t.rk, s);
         memcpy(out + 16 * i, s[0], 16);
     }
+}
+// which permutation gcc_garble_run / gcc_eval_run hash with (0: fixed-key AES, 1: Chaskey-12); returns the previous kind
+int gcc_set_gate_hash(int kind) {
+    int old = g_gate_hash;
+    if (kind == 0 || kind == 1) g_gate_hash = kind;
+    return old;
+}
+// H(x, t) of the given kind through the shared scalar code of gc_aes.h (hash_n)
+void gcc_gate_hash(int kind, const uint8_t *x, const uint64_t *tweak, uint8_t *out, size_t n) {
+    init();
+    for (size_t i = 0; i < n; i++) {
+        Lbl l, o;
+        memcpy(&l, x + 16 * i, 16);
+        if (kind == 1) {
+            HostNoTab nt;
+            hash_n<1, HostNoTab>(nt, g_t.rk, &l, &tweak[i], &o);
+        } else {
+            HostTab ht = {g_t.te0};
+            hash_n<1, HostTab>(ht, g_t.rk, &l, &tweak[i], &o);
+        }
+        memcpy(out + 16 * i, &o, 16);
+    }
+}
+// `rounds` applications of the Chaskey round (gc_aes.h: chaskey_round; 12 = the permutation of gate hash 1) and of its
+// inverse (a second piece of code): tests pin the round to the published Chaskey test vectors (8 rounds) through these
+void gcc_chaskey(const uint8_t in[16], uint8_t out[16], int rounds) {
+    uint32_t v[4];
+    memcpy(v, in, 16);
+    for (int r = 0; r < rounds; r++) chaskey_round(v[0], v[1], v[2], v[3]);
+    memcpy(out, v, 16);
+}
+void gcc_chaskey_inverse(const uint8_t in[16], uint8_t out[16], int rounds) {
+    uint32_t v[4];
+    memcpy(v, in, 16);
+    for (int r = 0; r < rounds; r++) chaskey_round_inverse(v[0], v[1], v[2], v[3]);
+    memcpy(out, v, 16);
 }
 void gcc_hash(const uint8_t x[16], uint64_t tweak, uint8_t out[16]) {
     init();
