@@ -220,6 +220,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the phase-1+2 bin/linreg runs and the two-process ring run")
     ap.add_argument("--child", action="store_true", help="(internal) one bare solve, for the PMC passes")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 64-lambda sweep (BASELINE config 5)")
+    ap.add_argument("--no-alt-hash", action="store_true", help="skip the extra solves over gate hash 1 (Chaskey-12 permutation)")
     ap.add_argument("--sweep-d", type=int, default=100)
     ap.add_argument("--sweep-iters", type=int, default=15)
     ap.add_argument("--sweep-lambdas", type=int, default=64)
@@ -343,6 +344,44 @@ def main():
     gates = st["and_gates"]
     total_gates = gates * args.steps * world
     value = total_gates / elapsed
+
+    # ---- the same solve over gate hash 1 (lgc_set_gate_hash: the table-free Chaskey-12 permutation in the place of the
+    # fixed-key AES; include/linreg_gc.h).  Reported beside the headline, never as `value`: the headline runs the
+    # reference's primitive.  Same program, same integers (compared below); the parked table ring is taken over.
+    alt_hash = None
+    if not args.no_alt_hash and world == 1:
+        lgc.set_gate_hash("chaskey12")
+        try:
+            s2 = lgc.Solver(sysm, seed=bytes((rank + i) & 0xff for i in range(16)), device=device_index)
+            s2.set_shares(shares)
+            s2.run()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                s2.run()
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t2) / args.steps
+            st2 = s2.stats()
+            beta2 = s2.beta()
+            s2.run(profile=True)
+            stx2 = s2.stats()
+            s2.close()
+            # 168 integer instructions per block (12 rounds x (4 add + 4 xor + 6 rotate)), one wave64 instruction per
+            # clock and CU (4 SIMDs x 16 lanes): the issue roof of the hash alone
+            valu_roof = 256 * 64 * 2.4e9 / 168
+            alt_hash = {"gate_hash": "chaskey12", "seconds_per_solve": dt2, "and_gates_per_s": st2["and_gates"] / dt2,
+                        "speedup_vs_headline": (elapsed / args.steps) / dt2,
+                        "same_integers_as_headline": [int(v) for v in beta2] == [int(v) for v in beta_fixed],
+                        "seconds_exclusive_per_solve": {"mac_garble": stx2["seconds_mac_garble"], "mac_eval": stx2["seconds_mac_eval"],
+                                                        "all_garble": stx2["seconds_garble"], "all_eval": stx2["seconds_eval"]},
+                        "hash_roofline": {"bound": "valu", "unit": "permutations/s", "peak": valu_roof,
+                                          "achieved_garbler_mac": 4.0 * stx2["mac_gates"] / stx2["seconds_mac_garble"] if stx2["seconds_mac_garble"] > 0 else None,
+                                          "achieved_evaluator_mac": 2.0 * stx2["mac_gates"] / stx2["seconds_mac_eval"] if stx2["seconds_mac_eval"] > 0 else None,
+                                          "peak_source": "256 CUs x 64 lanes/clk x 2.4 GHz / 168 integer instructions per permutation"},
+                        "note": "option (lgc_set_gate_hash(1) / bin/linreg --gate_hash=chaskey12), not the default: a different "
+                                "instantiation of the random permutation than the reference's fixed-key AES"}
+        finally:
+            lgc.set_gate_hash("aes128")
 
     # ---- BASELINE config 5: the 64-lambda sweep of the d=100 CGD-15 circuit, sharded over the ranks.  The
     # lambda-independent prefix (input labels + garbled share summation) is garbled on rank 0 and broadcast
@@ -544,6 +583,7 @@ def main():
             "seconds_exclusive_per_solve": {"mac_garble": xg, "mac_eval": xe, "all_garble": stx["seconds_garble"],
                                             "all_eval": stx["seconds_eval"]},
             "roofline": roofline, "aes_roofline": aes_roofline, "cpu_baseline": cpu,
+            "alt_gate_hash": alt_hash,
             "phase12": e2e, "two_process_ring": ring, "sweep64": sweep_res,
             "beta0": float(int(beta_fixed[0]) / scale),
         }

@@ -318,12 +318,15 @@ GC_HD Lbl garble_and(const T &tab, const uint32_t *rk, Lbl R, Lbl a0, Lbl b0, ui
 #ifndef GC_GARBLE_SPLIT22
 #define GC_GARBLE_SPLIT22 1   /* two pairs of interleaved blocks: fewer live registers, 4 waves/SIMD */
 #endif
-#if GC_GARBLE_SPLIT22
-    hash_n<2, T>(tab, rk, in, tw, h, rk24);
-    hash_n<2, T>(tab, rk, in + 2, tw + 2, h + 2, rk24);
-#else
-    hash_n<4, T>(tab, rk, in, tw, h, rk24);
+#ifndef GC_GARBLE_H1_SPLIT22
+#define GC_GARBLE_H1_SPLIT22 1
 #endif
+    if (T::kHashKind == GATE_HASH_CHASKEY12 ? (GC_GARBLE_H1_SPLIT22 != 0) : (GC_GARBLE_SPLIT22 != 0)) {
+        hash_n<2, T>(tab, rk, in, tw, h, rk24);
+        hash_n<2, T>(tab, rk, in + 2, tw + 2, h + 2, rk24);
+    } else {
+        hash_n<4, T>(tab, rk, in, tw, h, rk24);
+    }
     uint32_t pa = a0.x & 1u, pb = b0.x & 1u;
     TG = lxor(lxor(h[0], h[1]), lmask(R, pb));
     Lbl WG = lxor(h[0], lmask(TG, pa));

@@ -30,7 +30,7 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
     case LM_NONE:
         return hipSuccess;
     case LM_MAC: if constexpr (PART == 0) {
-        constexpr int TPB = G ? kTpbMacG : kTpbMacE;       // upper bound (register budget of the kernel)
+        constexpr int TPB = HK == 1 ? (G ? kTpbMacGH : kTpbMacEH) : (G ? kTpbMacG : kTpbMacE);       // upper bound (register budget of the kernel)
         const unsigned per = gc_mac_waves(L.nrec, G ? GC_MAC_ADAPT_LO_G : GC_MAC_ADAPT_LO_E, TPB / 64);
 #if GC_MAC_TAIL_SPLIT
         // One workgroup per CU, every record the same length: the launch runs in rounds of (CUs x waves) records and
@@ -55,7 +55,7 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
                            L.step0, R, w, p);
     } break;
     case LM_MACK: if constexpr (PART == 0) {
-        constexpr int TPB = G ? kTpbMackG : kTpbMackE;
+        constexpr int TPB = HK == 1 ? (G ? kTpbMackGH : kTpbMackEH) : (G ? kTpbMackG : kTpbMackE);
         hipLaunchKernelGGL((gc_mack_kernel<G, TPB, HK>), dim3((L.nrec + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, st, recs + L.first_rec,
                            L.nrec, words, tab, L.step0, R, w, p);
     } break;

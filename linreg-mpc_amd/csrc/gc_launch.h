@@ -29,6 +29,21 @@ static constexpr int kTpbMacG = GC_TPB_MACG, kTpbMacE = GC_TPB_MACE;
 #define GC_TPB_MACKE 768
 #endif
 static constexpr int kTpbMackG = GC_TPB_MACKG, kTpbMackE = GC_TPB_MACKE;
+// ... and over the table-free gate hash (lgc_set_gate_hash(1)): no 128 KiB table image ties a workgroup to a CU, the
+// register budget alone sets the occupancy
+#ifndef GC_TPB_MACG_H1
+#define GC_TPB_MACG_H1 1024
+#endif
+#ifndef GC_TPB_MACE_H1
+#define GC_TPB_MACE_H1 768
+#endif
+#ifndef GC_TPB_MACKG_H1
+#define GC_TPB_MACKG_H1 512    /* scripts/exp/hash_ab.sh: 512 / 512 d=500 CGD-15 0.923 s, 1024 / 768 0.940 s, 256 / 256 0.921 s */
+#endif
+#ifndef GC_TPB_MACKE_H1
+#define GC_TPB_MACKE_H1 512
+#endif
+static constexpr int kTpbMacGH = GC_TPB_MACG_H1, kTpbMacEH = GC_TPB_MACE_H1, kTpbMackGH = GC_TPB_MACKG_H1, kTpbMackEH = GC_TPB_MACKE_H1;
 #ifndef GC_MAC_EXCLUSIVE
 #define GC_MAC_EXCLUSIVE 1
 #endif
