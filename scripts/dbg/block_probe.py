@@ -7,12 +7,15 @@ import torch
 import linreg_gc as lgc
 import sweep
 d, it = 100, 15
+if len(sys.argv) > 1:
+    lgc.set_gate_hash(sys.argv[1])
+print("gate hash:", lgc.gate_hash(), flush=True)
 rng = np.random.default_rng(5)
 T = d * (d + 1) // 2
 shares = rng.integers(0, 2**62, size=(2, T + d), dtype=np.uint64)
 lams = sweep.c5_lambdas(64)
 sysm = lgc.make_system(d, 64, 56, "cgd", it, 0.0, 2, 1, 0, 0)
-for block in (8, 8, 16, 32, 64):
+for block in (8, 8, 64):
     t0 = time.perf_counter()
     s = lgc.Solver(sysm, seed=bytes(range(16)), lambdas=lams[:block])
     t1 = time.perf_counter()

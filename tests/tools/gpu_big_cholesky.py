@@ -1,4 +1,5 @@
-"""one-off: d=500 Cholesky / LDL^T (64-bit) and d=500 Cholesky 32-bit vs the oracle, with timing"""
+"""one-off: d=500 Cholesky / LDL^T (64-bit) and d=500 Cholesky 32-bit vs the oracle, with timing
+   python tests/tools/gpu_big_cholesky.py [aes128|chaskey12]   (the gate hash, lgc_set_gate_hash)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -6,6 +7,9 @@ import numpy as np
 import linreg_gc as lgc, orc
 from helpers import oracle_solve, split_shares, synth_system
 oracle = orc.load()
+if len(sys.argv) > 1:
+    lgc.set_gate_hash(sys.argv[1])
+print("gate hash:", lgc.gate_hash(), flush=True)
 for (d, w, p, alg) in ((500, 64, 56, "cholesky"), (500, 64, 56, "ldlt"), (500, 32, 30, "cholesky")):
     rng = np.random.default_rng(d + w)
     A, b = synth_system(oracle, rng, 3 * d, d, w, p)

@@ -21,7 +21,9 @@ ap.add_argument("--lambdas", type=int, default=64)
 ap.add_argument("--d", type=int, default=100)
 ap.add_argument("--n", type=int, default=10000)
 ap.add_argument("--check", type=int, default=2, help="compare this many circuits with the CPU oracle")
+ap.add_argument("--gate_hash", default="aes128", help="aes128 (default, the reference's) or chaskey12 (lgc_set_gate_hash)")
 args = ap.parse_args()
+lgc.set_gate_hash(args.gate_hash)
 
 world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
