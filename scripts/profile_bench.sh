@@ -27,5 +27,11 @@ python3 scripts/gpu_launch_profile.py 100 cgd 15 > $O/launch_profile_d100_cgd15.
 python3 scripts/gpu_launch_profile.py 20 cholesky 0 > $O/launch_profile_d20_cholesky.txt 2>&1
 python3 scripts/gpu_launch_profile.py 500 cgd 20 32 30 > $O/launch_profile_d500_cgd20_w32.txt 2>&1
 python3 scripts/gpu_probe.py mid big > $O/probe.txt 2>&1
+# the same over gate hash 1 (Chaskey-12 permutation; lgc_set_gate_hash)
+python3 scripts/gpu_launch_profile.py 500 cgd 15 64 chaskey12 > $O/launch_profile_d500_cgd15_chaskey12.txt 2>&1
+python3 scripts/gpu_launch_profile.py 20 cholesky 0 64 chaskey12 > $O/launch_profile_d20_cholesky_chaskey12.txt 2>&1
+python3 scripts/gpu_probe.py mid big hash=chaskey12 > $O/probe_chaskey12.txt 2>&1
+(cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq1_h1 -- python3 $R/scripts/gpu_probe.py big hash=chaskey12 > /dev/null 2> $O/pmc_sq1_h1.err)
+(cd /tmp && rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2_h1 -- python3 $R/scripts/gpu_probe.py big hash=chaskey12 > /dev/null 2> $O/pmc_sq2_h1.err)
 python3 tests/tools/gpu_phase1_baseline.py > $O/phase1_baseline.jsonl 2>&1
 cat $O/bench_line.json | cut -c1-600
