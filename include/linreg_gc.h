@@ -223,6 +223,11 @@ size_t lgc_party_table_bytes(const lgc_party *p, size_t launch);
 size_t lgc_party_input_bits(const lgc_party *p);      /* (T + d) * width, per share */
 size_t lgc_party_num_reveal(const lgc_party *p);
 uint64_t lgc_party_and_gates(const lgc_party *p);
+/* 32 bytes over everything the two roles of a solve must have in common (records incl. lambda and gate-step numbers, launch
+ * boundaries, width, precision, gate hash).  The host binaries exchange and compare it before the first table moves, so that
+ * an option given to one party only (--gate_hash, --lambdas, --prec_phase2 ...) is an error message instead of a wrong
+ * result.  A check against misconfiguration, not an authentication of the peer. */
+int lgc_party_program_fingerprint(const lgc_party *p, uint8_t out[32]);
 /* cgd only, n = num_iterations: the launch that completes iteration t and the AND gates emitted up
  * to and including it (cgd.oc:190-194 prints both per iteration).  Either pointer may be NULL. */
 int lgc_party_iteration_marks(const lgc_party *p, uint32_t *launch, uint64_t *and_gates, size_t n);

@@ -184,6 +184,28 @@ extern "C" size_t lgc_party_table_bytes(const lgc_party *p, size_t launch) {
 extern "C" size_t lgc_party_input_bits(const lgc_party *p) { return p ? (p->P.T + p->P.d) * (size_t)p->P.w : 0; }
 extern "C" size_t lgc_party_num_reveal(const lgc_party *p) { return p ? p->P.n_reveal : 0; }
 extern "C" uint64_t lgc_party_and_gates(const lgc_party *p) { return p ? p->P.total_gates : 0; }
+// 32 bytes that two parties compare before the first table moves: everything the two roles of a solve must agree on -- the
+// records (operands, constants such as lambda, gate-step numbers), the launch boundaries, width, precision, gate hash.
+// Four multiplicative word hashes; a check against MISCONFIGURATION (a flag given to one party only), not against a cheating peer.
+extern "C" int lgc_party_program_fingerprint(const lgc_party *p, uint8_t out[32]) {
+    if (!p || !out) return lgc_fail(LGC_EINVAL, "null argument");
+    const Program &P = p->P;
+    uint64_t h[4] = {0xcbf29ce484222325ull, 0x84222325cbf29ce4ull, 0x9e3779b97f4a7c15ull, 0xd6e8feb86659fd93ull};
+    const uint64_t mul[4] = {0x100000001b3ull, 0xff51afd7ed558ccdull, 0xc4ceb9fe1a85ec53ull, 0x9fb21c651e98df25ull};
+    auto mix = [&](uint64_t v) {
+        for (int k = 0; k < 4; k++) { h[k] = (h[k] ^ v) * mul[k]; h[k] ^= h[k] >> 29; }
+    };
+    const uint64_t head[] = {(uint64_t)P.w, (uint64_t)P.p, (uint64_t)P.d, (uint64_t)P.nshares, (uint64_t)P.gate_hash, P.n_words, P.n_reveal,
+                             P.in_base, P.rv_beta, P.replicas, P.shared_end, P.prefix_launches, P.total_steps, P.total_gates,
+                             (uint64_t)P.recs.size(), (uint64_t)P.launches.size()};
+    for (uint64_t v : head) mix(v);
+    static_assert(sizeof(Rec) % 8 == 0, "records are hashed as 64-bit words");
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(P.recs.data());
+    for (size_t i = 0, n = P.recs.size() * (sizeof(Rec) / 8); i < n; i++) mix(w[i]);
+    for (const Launch &L : P.launches) { mix(((uint64_t)L.first_rec << 32) | L.nrec); mix(L.step0); mix(L.steps); }
+    memcpy(out, h, 32);
+    return LGC_OK;
+}
 extern "C" int lgc_party_iteration_marks(const lgc_party *p, uint32_t *launch, uint64_t *and_gates, size_t n) {
     if (!p) return lgc_fail(LGC_EINVAL, "null party");
     if (n != p->P.iter_launch.size())

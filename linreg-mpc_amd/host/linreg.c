@@ -264,6 +264,7 @@ int main(int argc, char **argv) {
             int fds[kMaxDevices];
             block_job jb[kMaxDevices];
             memset(jb, 0, sizeof jb);
+            for (int k = 0; k < n_devices; k++) check(!programs_agree(self, 2, blocks[k], 1), "program check failed (block %d)", k);
             check(!net_lanes_offer(self, 2, n_devices, fds), "could not open %d token connections to the Evaluator", n_devices);
             const size_t pre = lgc_party_prefix_launches(blocks[0]);
             for (int k = 0; k < n_devices; k++)
@@ -289,6 +290,7 @@ int main(int argc, char **argv) {
             for (int k = 0; k < n_devices; k++) close(fds[k]);
             goto done;
         }
+        check(!programs_agree(self, 2, party_obj, 1), "program check failed");
         check(!tables_send(self, 2, party_obj, ring_slots, kTableChunk), "could not stream the garbled tables");
         TRACE("tables sent");
         size_t nr = lgc_party_num_reveal(party_obj);
@@ -325,6 +327,7 @@ int main(int argc, char **argv) {
             int fds[kMaxDevices], got = 0;
             block_job jb[kMaxDevices];
             memset(jb, 0, sizeof jb);
+            for (int k = 0; k < n_devices; k++) check(!programs_agree(self, 1, blocks[k], 0), "program check failed (block %d)", k);
             check(!net_lanes_accept_offer(self, 1, kMaxDevices, &got, fds) && got == n_devices, "the CSP offered %d table links, expected %d (same --devices on both?)", got, n_devices);
             const size_t pre = lgc_party_prefix_launches(blocks[0]);
             for (int k = 0; k < n_devices; k++)
@@ -352,6 +355,7 @@ int main(int argc, char **argv) {
                 close(fds[k]);
             }
         } else {
+            check(!programs_agree(self, 1, party_obj, 0), "program check failed");
             check(!tables_recv(self, 1, party_obj, ring_slots, kTableChunk, note_launch, &marks), "could not receive garbled tables");
             TRACE("tables evaluated");
             size_t nr = lgc_party_num_reveal(party_obj);

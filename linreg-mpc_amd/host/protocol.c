@@ -379,6 +379,22 @@ int table_link_recv_range(table_link *l, size_t lo, size_t hi, void (*after_laun
     return 0;
 }
 
+int programs_agree(node *self, int peer, lgc_party *po, int sending) {
+    uint8_t mine[32], theirs[32], ok = 0;
+    if (lgc_party_program_fingerprint(po, mine) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); return 1; }
+    if (sending) {
+        if (send_blob(self, peer, mine, sizeof mine) || recv_blob(self, peer, &ok, 1)) return 1;
+    } else {
+        if (recv_blob(self, peer, theirs, sizeof theirs)) return 1;
+        ok = memcmp(mine, theirs, sizeof mine) == 0;
+        if (send_blob(self, peer, &ok, 1)) return 1;
+    }
+    if (!ok)
+        fprintf(stderr, "the CSP and the Evaluator built different programs: algorithm, iterations, precision, widths, --lambdas, "
+                        "--gate_hash and --devices must be the same on parties 1 and 2\n");
+    return ok ? 0 : 1;
+}
+
 int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk) {
     const size_t nl = lgc_party_num_launches(po);
     if (ring_slots > 0) {

@@ -25,6 +25,9 @@ int send_pmsg(node *self, int to, const uint64_t *vec, size_t n, uint64_t value)
 int recv_pmsg(node *self, int from, uint64_t **vec, size_t *n, uint64_t *value);
 int send_blob(node *self, int to, const void *buf, uint64_t len);
 int recv_blob(node *self, int from, void *buf, uint64_t len);
+/* CSP (sending = 1) and Evaluator (0) compare the fingerprints of their programs (lgc_party_program_fingerprint) before the
+ * table stream starts; both sides report a mismatch.  0 = the programs agree */
+int programs_agree(node *self, int peer, lgc_party *po, int sending);
 void pmsg_set_limit(size_t n_elements);
 void protocol_set_ti_ring(int on);        /* TI mode with all parties on one node: vectors through device rings */   /* bound on the length prefix recv_pmsg accepts */
 

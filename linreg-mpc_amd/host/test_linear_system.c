@@ -114,6 +114,7 @@ int main(int argc, char **argv) {
         check(!send_blob(self, 2, e, bits * 32), "OT: could not send");
         lgc_ot_sender_destroy(S);
         free(lab); free(m0); free(m1); free(u); free(e);
+        check(!programs_agree(self, 2, po, 1), "program check failed");
         check(!tables_send(self, 2, po, ring_slots, chunk), "could not stream the garbled tables");
         size_t nr = lgc_party_num_reveal(po);
         uint64_t *dec = malloc((nr + 1) * 8);
@@ -149,6 +150,7 @@ int main(int argc, char **argv) {
         if (is_cgd) LGC(lgc_party_iteration_marks(po, mark_launch, mark_gates, n_marks));
         double t_iters = wall_clock();                                          /* cgd.oc: time_start */
         iter_marks marks = {n_marks, 0, mark_launch, mark_time, t_iters};
+        check(!programs_agree(self, 1, po, 0), "program check failed");
         check(!tables_recv(self, 1, po, ring_slots, chunk, note_launch, &marks), "could not receive garbled tables");
         size_t nr = lgc_party_num_reveal(po);
         uint64_t *dec = malloc((nr + 1) * 8);

@@ -386,6 +386,14 @@ class Party:
     def table_bytes(self, k):
         return lib().lgc_party_table_bytes(self._h, k)
 
+    def program_fingerprint(self):
+        """32 bytes over everything the two roles must agree on (lgc_party_program_fingerprint)"""
+        out = np.zeros(32, dtype=np.uint8)
+        L = lib()
+        L.lgc_party_program_fingerprint.argtypes = [C.c_void_p, C.c_void_p]; L.lgc_party_program_fingerprint.restype = C.c_int
+        _chk(L.lgc_party_program_fingerprint(self._h, _vp(out)))
+        return out.tobytes()
+
     def input_pairs(self, share):
         m0 = np.zeros((self.input_bits, 16), dtype=np.uint8); m1 = np.zeros((self.input_bits, 16), dtype=np.uint8)
         _chk(lib().lgc_party_input_pairs(self._h, share, _vp(m0), _vp(m1)))

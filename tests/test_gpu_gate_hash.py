@@ -134,9 +134,17 @@ def test_a_role_with_the_other_hash_does_not_decode(lgc, oracle):
     lgc.set_gate_hash("chaskey12")
     try:
         G = lgc.Party(sysm, lgc.GARBLER, seed=bytes(range(16)))
+        E1 = lgc.Party(sysm, lgc.EVALUATOR)
     finally:
         lgc.set_gate_hash("aes128")
     E = lgc.Party(sysm, lgc.EVALUATOR)
+    # what the host binaries compare before the first table moves (host/protocol.c: programs_agree)
+    assert G.program_fingerprint() == E1.program_fingerprint() != E.program_fingerprint()
+    E1.close()
+    E2 = lgc.Party(lgc.make_system(d, w, p, "cholesky", 0, 0.5, 2, 1, 0, 0), lgc.EVALUATOR)     # another lambda
+    E3 = lgc.Party(lgc.make_system(d, w, p, "cholesky", 0, 0.25, 2, 1, 0, 0), lgc.EVALUATOR)
+    assert E2.program_fingerprint() != E3.program_fingerprint()
+    E2.close(); E3.close()
     ok = True
     try:
         for k in range(2):

@@ -138,6 +138,25 @@ def test_five_process_readme_example(tmp_path, golden_dir, extra):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("odd", [["--gate_hash=chaskey12"], ["--prec_phase2=50"]], ids=["gate-hash", "precision"])
+def test_an_option_given_to_one_party_only_is_an_error_not_a_wrong_result(tmp_path, golden_dir, odd):
+    """the CSP and the Evaluator compare the fingerprints of their programs before the first table moves
+    (host/protocol.c: programs_agree): party 1 alone gets the extra option"""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    infile = str(tmp_path / "readme.in")
+    P = _rewrite_ports(os.path.join(golden_dir, "readme_example.in"), infile)
+    exe = os.path.join(HOST, "bin", "linreg")
+    procs = []
+    for party in range(1, P + 3):
+        cmd = [exe, infile, "56", str(party), "cholesky", "0", "0.001"] + (odd if party == 1 else [])
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [q.communicate(timeout=120) for q in procs]
+    assert procs[0].returncode != 0 and procs[1].returncode != 0
+    assert b"built different programs" in outs[0][1] and b"built different programs" in outs[1][1]
+    assert b"Result:" not in outs[1][0]
+
+
+@pytest.mark.gpu
 def test_five_process_cholesky_matches_oracle(tmp_path, golden_dir, oracle):
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     infile = str(tmp_path / "readme.in")
