@@ -56,8 +56,9 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
     } break;
     case LM_MACK: if constexpr (PART == 0) {
         constexpr int TPB = HK == 1 ? (G ? kTpbMackGH : kTpbMackEH) : (G ? kTpbMackG : kTpbMackE);
-        hipLaunchKernelGGL((gc_mack_kernel<G, TPB, HK>), dim3((L.nrec + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, st, recs + L.first_rec,
-                           L.nrec, words, tab, L.step0, R, w, p);
+        // HK = 1: no table image limits the workgroups of a CU; kMackPadH1 bytes of unused dynamic LDS per workgroup do (see gc_launch.h)
+        hipLaunchKernelGGL((gc_mack_kernel<G, TPB, HK>), dim3((L.nrec + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), HK == 1 ? kMackPadH1 : 0, st,
+                           recs + L.first_rec, L.nrec, words, tab, L.step0, R, w, p);
     } break;
     case LM_WIDE: if constexpr (PART == 1) {
         // records (waves) per workgroup: as few as keep the launch within one workgroup per CU, at most TPB / 64 --

@@ -43,6 +43,14 @@ static constexpr int kTpbMackG = GC_TPB_MACKG, kTpbMackE = GC_TPB_MACKE;
 #ifndef GC_TPB_MACKE_H1
 #define GC_TPB_MACKE_H1 512
 #endif
+// Unused dynamic LDS per workgroup of the table-free MACK kernels: caps their occupancy so that the other role's small
+// launches find registers on every CU.  Measured (scripts/exp/hash_ab.sh, d=500 CGD-15 over gate hash 1): 96 KiB with 512
+// threads (8 waves per CU) MACK +7 %, solve 0.938 s against 0.927-0.932 s -- what the small launches gain the MACK loses;
+// 4 waves per CU: MACK +12 %.  0 = off.
+#ifndef GC_MACK_PAD_H1
+#define GC_MACK_PAD_H1 0
+#endif
+static constexpr unsigned kMackPadH1 = GC_MACK_PAD_H1;
 static constexpr int kTpbMacGH = GC_TPB_MACG_H1, kTpbMacEH = GC_TPB_MACE_H1, kTpbMackGH = GC_TPB_MACKG_H1, kTpbMackEH = GC_TPB_MACKE_H1;
 #ifndef GC_MAC_EXCLUSIVE
 #define GC_MAC_EXCLUSIVE 1
