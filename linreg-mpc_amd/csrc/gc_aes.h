@@ -272,13 +272,10 @@ GC_HD void hash_n(const T &tab, const uint32_t *rk, const Lbl *x, const uint64_t
         hash_prep(x[b], tw[b], k[b]);
         s[b][0] = k[b][0]; s[b][1] = k[b][1]; s[b][2] = k[b][2]; s[b][3] = k[b][3];
     }
-    if constexpr (T::kHashKind == GATE_HASH_CHASKEY12) {
-        chaskey12_permute_n<N>(s);
-    } else {
 #ifndef GC_X_NOHASH          /* timing experiments only (scripts/exp): results are wrong with it */
-        aes_encrypt_n<N, T>(tab, rk, s, rk24);
+    if constexpr (T::kHashKind == GATE_HASH_CHASKEY12) chaskey12_permute_n<N>(s);
+    else aes_encrypt_n<N, T>(tab, rk, s, rk24);
 #endif
-    }
 #pragma unroll
     for (int b = 0; b < N; b++) {
         out[b].x = s[b][0] ^ k[b][0]; out[b].y = s[b][1] ^ k[b][1];
