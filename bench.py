@@ -424,6 +424,18 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             sdt = float(tmax[0].item())
             phases = [float(v) for v in tmax[1:].tolist()]
+        if alt_hash is not None:                                   # the same sweep over gate hash 1 (world == 1 here)
+            lgc.set_gate_hash("chaskey12")
+            try:
+                sweep.shared_prefix_sweep(sshares, lams[:2], sd, make, dist=None, tensor_device="cuda")
+                torch.cuda.synchronize()
+                ts2 = time.perf_counter()
+                sres2 = sweep.shared_prefix_sweep(sshares, lams, sd, make, dist=None, tensor_device="cuda")
+                torch.cuda.synchronize()
+                alt_hash["sweep64_seconds"] = time.perf_counter() - ts2
+                alt_hash["sweep64_same_integers"] = bool((np.asarray(sres2) == np.asarray(sres)).all())
+            finally:
+                lgc.set_gate_hash("aes128")
         dump = os.environ.get("LGC_BENCH_DUMP")
         if dump:                                                   # tests: what every rank holds after the gather
             json.dump({"rank": rank, "lambdas": lams, "beta": sres.tolist(), "shares": sshares.tolist(), "d": sd, "iters": sit,
