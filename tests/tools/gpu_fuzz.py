@@ -1,7 +1,8 @@
 """Randomised parity sweep on the GPU (not part of the pytest suite; run through gpurun):
 random dimension, algorithm, width, precision, share count, input path, lambda and seed; every
 result (beta, trace, revealed inputs) is compared bit for bit with the CPU oracle.
-    python tests/tools/gpu_fuzz.py [cases] [seed] [big]     (big: dimensions that reach the MAC and wide kernels)"""
+    python tests/tools/gpu_fuzz.py [cases] [seed] [big|small] [aes128|chaskey12]     (big: dimensions that reach the MAC and wide
+    kernels; last argument: the gate hash, lgc_set_gate_hash)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,6 +14,8 @@ oracle = orc.load()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+if len(sys.argv) > 4:
+    lgc.set_gate_hash(sys.argv[4])
 t0 = time.time()
 bad = 0
 for c in range(cases):
