@@ -1,7 +1,11 @@
 #!/bin/bash
-# build_variant.sh NAME -DFOO=1 ... : product library with experiment macros -> scripts/exp/libs/lib_NAME.so
+# build_variant.sh NAME -DFOO=1 ... : the whole product library (all translation units) with experiment macros
+# -> scripts/exp/libs/lib_NAME.so  (run with LGC_LIB=... ; scripts/exp/mac_ab.sh)
 R=$(cd "$(dirname "$0")/../.." && pwd)
 n=$1; shift
-mkdir -p $R/scripts/exp/libs
-hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -shared -o $R/scripts/exp/libs/lib_$n.so $R/linreg-mpc_amd/csrc/liblinreg_gc.hip 2>&1 | grep -E " error" 
-exit 0
+D=/tmp/lgc_var/a/$n
+mkdir -p $R/scripts/exp/libs $D /tmp/lgc_var/include
+cp $R/include/linreg_gc.h /tmp/lgc_var/include/
+cp $R/linreg-mpc_amd/csrc/*.h $R/linreg-mpc_amd/csrc/*.hip $R/linreg-mpc_amd/csrc/Makefile $D/
+(cd $D && make -s JOBS=${JOBS:-8} EXTRA="$*" 2>&1 | grep -E "error|Error" )
+cp $D/liblinreg_gc.so $R/scripts/exp/libs/lib_$n.so && echo "built lib_$n.so"

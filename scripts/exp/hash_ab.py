@@ -1,5 +1,5 @@
 """A/B timing of the engine over gate hash 1 (Chaskey-12): d=500 CGD-15 and the latency-bound shapes; LGC_LIB selects a
-variant library (scripts/exp/build_variant2.sh)"""
+variant library (scripts/exp/build_variant.sh)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python"))
