@@ -88,6 +88,12 @@ def run(name, n, d, starts, alg, iters, lam, extra, w2=64, p1=56, p2=None, seed=
                           and_gates=gates, exact_vs_oracle=exact, max_abs_err_vs_float_solve=err)), flush=True)
 
 which = sys.argv[1:] or ["c2", "c3"]
+# the same runs over gate hash 1 (bin/linreg --gate_hash=chaskey12): names get the suffix "-chaskey12"
+HASH = ["--gate_hash=chaskey12"]
+if "c2rh" in which: run("c2-ring-chaskey12", 1000, 20, [0, 10], "cholesky", 0, 0.001, ["--table_ring"] + HASH)
+if "c3titrh" in which: run("c3ti-ti-ring-chaskey12", 10000, 100, [0, 50], "cgd", 15, 0.001, ["--table_ring", "--ti_ring"] + HASH)
+if "c4trh" in which: run("c4-ti-ring-chaskey12", 50000, 500, [0, 100, 200, 300, 400], "cgd", 20, 0.001,
+                         ["--width_phase2=32", "--prec_phase2=30", "--table_ring", "--ti_ring"] + HASH, w2=32)
 subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
 if "c2" in which: run("c2", 1000, 20, [0, 10], "cholesky", 0, 0.001, [])
 if "c3ti" in which: run("c3ti", 10000, 100, [0, 50], "cgd", 15, 0.001, [])
