@@ -147,7 +147,7 @@ def phase12_wall(np, name, n, d, starts, alg, iters, extra, device_index):
     return res
 
 
-def two_process_ring(np, d, iters, p, Af, bf, gates, device_index):
+def two_process_ring(np, d, iters, p, Af, bf, gates, device_index, extra=()):
     """the deployment-shaped figure: CSP and Evaluator as two processes (bin/test_linear_system), garbled
     tables handed over through the device-resident hipIpc ring; rate = gates / (time of the last iteration)"""
     import re, subprocess, tempfile
@@ -166,7 +166,7 @@ def two_process_ring(np, d, iters, p, Af, bf, gates, device_index):
     port = _free_ports(1)[0]
     env = dict(os.environ, LINREG_DEVICE=str(device_index))
     t0 = time.perf_counter()
-    procs = [subprocess.Popen([exe, str(port), str(k), path, "cgd", str(iters), str(p), "--host=127.0.0.1", "--table_ring=4"],
+    procs = [subprocess.Popen([exe, str(port), str(k), path, "cgd", str(iters), str(p), "--host=127.0.0.1", "--table_ring=4"] + list(extra),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for k in (1, 2)]
     outs = [q.communicate(timeout=900) for q in procs]
     wall = time.perf_counter() - t0
@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--child", action="store_true", help="(internal) one bare solve, for the PMC passes")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 64-lambda sweep (BASELINE config 5)")
     ap.add_argument("--no-alt-hash", action="store_true", help="skip the extra solves over gate hash 1 (Chaskey-12 permutation)")
+    ap.add_argument("--gate-hash", default="aes128", choices=["aes128", "chaskey12"],
+                    help="the gate hash of EVERY run of this invocation (lgc_set_gate_hash; default: fixed-key AES, the reference's). "
+                         "With chaskey12 the line reports that option's figures as value / roofline and says so in `gate_hash`")
     ap.add_argument("--sweep-d", type=int, default=100)
     ap.add_argument("--sweep-iters", type=int, default=15)
     ap.add_argument("--sweep-lambdas", type=int, default=64)
@@ -242,7 +245,7 @@ def main():
     traffic, traffic_detail = None, {"source": "not measured (--no-traffic, N > 1, or a non-default workload)"}
     if rank == 0 and world == 1 and not args.child and not args.no_traffic:
         traffic, traffic_detail = measure_hbm_traffic(["--d", str(args.d), "--iters", str(args.iters), "--width", str(args.width),
-                                                       "--precision", str(args.precision)])
+                                                       "--precision", str(args.precision), "--gate-hash", args.gate_hash])
 
     import numpy as np
     import torch                       # first: one HIP runtime per process (shared SONAME)
@@ -303,6 +306,8 @@ def main():
     if w == 32:
         shares &= np.uint64(0xffffffff)
 
+    lgc.set_gate_hash(args.gate_hash)
+    hash_opt = ["--gate_hash=%s" % args.gate_hash] if args.gate_hash != "aes128" else []
     sysm = lgc.make_system(d, w, p, "cgd", iters, 0.0, 2, 0, 0, 0)
     solver = lgc.Solver(sysm, seed=bytes((rank + i) & 0xff for i in range(16)), device=device_index)
     solver.set_shares(shares)
@@ -349,7 +354,7 @@ def main():
     # fixed-key AES; include/linreg_gc.h).  Reported beside the headline, never as `value`: the headline runs the
     # reference's primitive.  Same program, same integers (compared below); the parked table ring is taken over.
     alt_hash = None
-    if not args.no_alt_hash and world == 1:
+    if not args.no_alt_hash and world == 1 and args.gate_hash == "aes128":
         lgc.set_gate_hash("chaskey12")
         try:
             s2 = lgc.Solver(sysm, seed=bytes((rank + i) & 0xff for i in range(16)), device=device_index)
@@ -506,6 +511,13 @@ def main():
                               "alternate with their evaluator launches; small launches of the two chains overlap); "
                               "*_exclusive: the same kernels in a fully serialised pass",
                     "note": "integer/bitwise kernel bound by LDS T-table AES issue, not HBM: see aes_roofline"}
+        if args.gate_hash == "chaskey12":        # the run was asked to use the table-free hash throughout: its own roof
+            valu_roof = 256 * 64 * 2.4e9 / 168
+            roofline["binding"] = "valu_chaskey12"
+            roofline["note"] = "integer kernel bound by vector-instruction issue of the Chaskey-12 permutation (168 per block), not HBM: see hash_roofline"
+            roofline["hash_roofline"] = {"bound": "valu", "unit": "permutations/s", "peak": valu_roof, "achieved": aes_achieved,
+                                         "achieved_eval_kernel": aes_achieved_eval, "frac": aes_achieved / valu_roof,
+                                         "peak_source": "256 CUs x 64 lanes/clk x 2.4 GHz / 168 integer instructions per permutation"}
         aes_roofline = {"achieved": aes_achieved, "achieved_eval_kernel": aes_achieved_eval,
                         "peak": lds_roof, "unit": "AES-128 blocks/s", "frac": aes_achieved / lds_roof,
                         "peak_source": "LDS lookup roof: 256 CUs x 64 lanes x 2.4 GHz / (160 ds_read_b32 x 2 LDS cycles)",
@@ -515,16 +527,16 @@ def main():
         e2e, ring = None, None
         if world == 1 and not args.no_e2e:
             import shutil as _sh
-            warm = phase12_wall(np, "warm-up", 200, 4, [0, 2], "cholesky", 0, ["--table_ring"], device_index)   # untimed: pages the binaries in
+            warm = phase12_wall(np, "warm-up", 200, 4, [0, 2], "cholesky", 0, ["--table_ring"] + hash_opt, device_index)   # untimed: pages the binaries in
             if warm.get("_check"):
                 _sh.rmtree(warm["_check"]["tmp"], ignore_errors=True)
-            e2e = [phase12_wall(np, "c2", 1000, 20, [0, 10], "cholesky", 0, ["--table_ring"], device_index),
-                   phase12_wall(np, "c3-ti", 10000, 100, [0, 50], "cgd", 15, ["--ti_ring", "--table_ring"], device_index),
+            e2e = [phase12_wall(np, "c2", 1000, 20, [0, 10], "cholesky", 0, ["--table_ring"] + hash_opt, device_index),
+                   phase12_wall(np, "c3-ti", 10000, 100, [0, 50], "cgd", 15, ["--ti_ring", "--table_ring"] + hash_opt, device_index),
                    # BASELINE config 3 proper: --use_ot phase 1 (1.6e9 extended OTs); all parties are on this node,
                    # so the bulk messages of both phases stay in HBM (--ot_ring = --use_ot through device rings)
-                   phase12_wall(np, "c3-ot", 10000, 100, [0, 50], "cgd", 15, ["--ot_ring", "--table_ring"], device_index)]
+                   phase12_wall(np, "c3-ot", 10000, 100, [0, 50], "cgd", 15, ["--ot_ring", "--table_ring"] + hash_opt, device_index)]
             if (w, p) == (64, 56):
-                ring = two_process_ring(np, d, iters, p, Af, bf, gates, device_index)
+                ring = two_process_ring(np, d, iters, p, Af, bf, gates, device_index, hash_opt)
         # ---- cpu_baseline leg: the only part of this script that imports, links or runs anything under oracle/.
         # (1) the baseline itself: the CPU mirror of the garbling protocol, timed on a bounded sample;
         # (2) the oracle as CHECKER of what the runs above produced (never of anything that is timed).
@@ -581,7 +593,7 @@ def main():
             "barrier_backend": (backend if dist is not None else None),
             "rccl_ranks": rccl_ranks, "devices": devices,
             "vs_baseline": value / REF_RATE if (d == 500 and iters == 15 and w == 64) else None,
-            "dtype": "u32", "data": "synthetic",
+            "dtype": "u32", "data": "synthetic", "gate_hash": args.gate_hash,
             "config": {"workload": "phase-2 CGD solve, d=%d, %d iterations, %d-bit fixed point, precision %d, "
                                    "two-party masked input (test_linear_system path), garbler+evaluator co-located; "
                                    "one independent system per GPU" % (d, iters, w, p),
@@ -594,7 +606,7 @@ def main():
             "seconds_mac_garble_per_solve": mac_g / args.steps,
             "seconds_exclusive_per_solve": {"mac_garble": xg, "mac_eval": xe, "all_garble": stx["seconds_garble"],
                                             "all_eval": stx["seconds_eval"]},
-            "roofline": roofline, "aes_roofline": aes_roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "aes_roofline": aes_roofline if args.gate_hash == "aes128" else None, "cpu_baseline": cpu,
             "alt_gate_hash": alt_hash,
             "phase12": e2e, "two_process_ring": ring, "sweep64": sweep_res,
             "beta0": float(int(beta_fixed[0]) / scale),
