@@ -49,6 +49,16 @@ const char *lgc_last_error(void);
 int lgc_device_count(void);
 /* version / build string */
 const char *lgc_version(void);
+/* LINREG_TRACE=1 in the environment: wall-clock marks on stderr, one line each, "LGCT <tag> <CLOCK_MONOTONIC seconds> <what>"
+ * -- the library marks its own start-up steps (HIP runtime, device context, program lowered, buffers, table ring), a host
+ * adds its protocol steps with the same call, and since the clock is system-wide the marks of all parties of a run line up
+ * (bench.py: `phase12[].timeline`).  Replaces nothing in the reference; it is how the start-up of src/cmd/linreg.c:100-199
+ * is broken down here.  Without the variable both calls do nothing. */
+/* Brings the HIP runtime and the context of `device` up (60-150 ms when several parties start together); both are
+ * process-wide, so a host may call this from a thread while it parses its input and connects (bin/linreg does). */
+int lgc_device_warm(int device);
+void lgc_trace_set_tag(const char *tag);
+void lgc_trace_mark(const char *what);
 
 /* ------------------------------------------------------------------ phase 2 */
 
@@ -252,6 +262,16 @@ int lgc_party_encode_inputs(lgc_party *p, size_t share, const uint64_t *values, 
  * slot with its previous contents. */
 int lgc_party_ring_create(lgc_party *p, int nslots, uint8_t handle_out[64], size_t *slot_bytes);
 int lgc_party_ring_open(lgc_party *p, const uint8_t handle[64], int nslots, size_t slot_bytes);
+/* The same hand-off through a BYTE ring (bin/linreg --table_ring; the default since round 4): `ring_bytes` of HBM (0 = the
+ * library's choice: the largest launch plus half as much again, the extra between 64 MiB and 4 GiB) in which launch k owns a
+ * contiguous range, laid out identically in both processes (lgc_program_ring_plan: same program, same size, same offsets).
+ * Before lgc_party_garble_ring(k) the garbler's host waits until the evaluator has finished launch
+ * lgc_party_ring_wait_for(p, k) (-1: nothing to wait for) -- the newest earlier launch whose range launch k overwrites.
+ * A slot ring of 4 x the largest launch was 10.5 GB at d = 100 (config 3) and 33 GB for config 4; fresh device memory costs
+ * tens of ms per GB to allocate, map in the peer and release, which made it the largest start-up item of those runs. */
+int lgc_party_ring_create_bytes(lgc_party *p, size_t ring_bytes, uint8_t handle_out[64], size_t *ring_bytes_out);
+int lgc_party_ring_open_bytes(lgc_party *p, const uint8_t handle[64], size_t ring_bytes);
+int64_t lgc_party_ring_wait_for(const lgc_party *p, size_t launch);
 int lgc_party_garble_ring(lgc_party *p, size_t launch);
 int lgc_party_evaluate_ring(lgc_party *p, size_t launch);
 /* evaluator: the labels a data provider forwarded (dcsSendIntArray -> orecv, input.c:46, 84-92) */

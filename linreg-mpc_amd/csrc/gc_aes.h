@@ -49,11 +49,14 @@ struct AesTables {
     uint32_t rk[44];
 };
 
-inline uint8_t aes_xtime(uint8_t v) { return (uint8_t)((v << 1) ^ ((v >> 7) * 0x1b)); }
+constexpr uint8_t aes_xtime(uint8_t v) { return (uint8_t)((v << 1) ^ ((v >> 7) * 0x1b)); }
 
-// S-box from first principles (multiplicative inverse in GF(2^8) + affine map)
-inline void aes_build_tables(AesTables &t, const uint8_t key[16]) {
-    uint8_t pw[256], lg[256];
+// S-box from first principles (multiplicative inverse in GF(2^8) + affine map).  constexpr: the device constants of the
+// fixed-key hash are COMPILE-TIME data (gc_device.h c_aes) -- nothing is uploaded when a process starts, and a code
+// object is loaded when its first kernel is launched, not because its constants had to be written.
+constexpr AesTables aes_make_tables(const uint8_t *key) {
+    AesTables t{};
+    uint8_t pw[256] = {}, lg[256] = {};
     uint8_t g = 1;
     for (int i = 0; i < 255; i++) { pw[i] = g; lg[g] = (uint8_t)i; g = (uint8_t)(g ^ aes_xtime(g)); }  // generator 3
     for (int x = 0; x < 256; x++) {
@@ -81,11 +84,27 @@ inline void aes_build_tables(AesTables &t, const uint8_t key[16]) {
         }
         t.rk[i] = t.rk[i - 4] ^ v;
     }
+    return t;
 }
+inline void aes_build_tables(AesTables &t, const uint8_t key[16]) { t = aes_make_tables(key); }
 
 // the fixed public key of this build (FIPS-197 Appendix B example key)
-static const uint8_t kFixedKey[16] = {0x2b, 0x7e, 0x15, 0x16, 0x28, 0xae, 0xd2, 0xa6,
-                                      0xab, 0xf7, 0x15, 0x88, 0x09, 0xcf, 0x4f, 0x3c};
+static constexpr uint8_t kFixedKey[16] = {0x2b, 0x7e, 0x15, 0x16, 0x28, 0xae, 0xd2, 0xa6,
+                                          0xab, 0xf7, 0x15, 0x88, 0x09, 0xcf, 0x4f, 0x3c};
+
+// what the device kernels read: round keys, Te0, and rotl24 of the round keys (two-table AES rounds)
+struct DevAesConst {
+    uint32_t rk[44];
+    uint32_t te0[256];
+    uint32_t rk24[44];
+};
+constexpr DevAesConst aes_make_dev_const() {
+    AesTables t = aes_make_tables(kFixedKey);
+    DevAesConst c{};
+    for (int i = 0; i < 44; i++) { c.rk[i] = t.rk[i]; c.rk24[i] = (t.rk[i] << 24) | (t.rk[i] >> 8); }
+    for (int i = 0; i < 256; i++) c.te0[i] = t.te0[i];
+    return c;
+}
 
 GC_HD uint32_t rotl32(uint32_t v, int k) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -18,19 +18,12 @@
 
 namespace gc {
 
-// Device constants of the fixed-key AES.  `static`: every translation unit of the library (the garbler kernels, the
-// evaluator kernels, the engine, phase 1, OT -- compiled in parallel, csrc/Makefile) has its own copy, which its
-// gc_tu_upload() fills; lgc_upload_constants() (gc_engine.hip) calls them all for the current device.
-static __constant__ uint32_t c_rk[44];
-static __constant__ uint32_t c_te0[256];
-static __constant__ uint32_t c_rk24[44];
-// c_rk24: rotl24 of the round keys (two-table AES rounds)
-static inline hipError_t gc_tu_upload(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24) {
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_rk), rk, 44 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_te0), te0, 256 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_rk24), rk24, 44 * sizeof(uint32_t));
-    return e;
-}
+// Device constants of the fixed-key AES: compile-time data (gc_aes.h aes_make_dev_const).  `static`: every translation
+// unit of the library (the garbler kernels, the evaluator kernels, the engine, phase 1, OT -- compiled in parallel,
+// csrc/Makefile) has its own copy in its own code object.  Rounds 1-3 filled them with hipMemcpyToSymbol when a process
+// touched the device for the first time, which loaded ALL code objects of the library into every process -- a data
+// provider that runs four phase-1 kernels paid for the garbler's and the evaluator's MAC kernels.
+static __constant__ DevAesConst c_aes = aes_make_dev_const();
 
 #ifndef GC_SOLO_INLINE
 #define GC_SOLO_INLINE 1   /* wide generic kernel: gate bodies inlined at every AND site (0: one out-of-line body; the call ABI
@@ -77,7 +70,7 @@ struct LdsTab2 {
 };
 __device__ __forceinline__ void lds_tab2_fill(uint32_t *lds) {
     for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) {
-        uint32_t v = c_te0[i >> 6];
+        uint32_t v = c_aes.te0[i >> 6];
         lds[i] = v;
         lds[kLdsTabWords + i] = (v << 16) | (v >> 16);
     }
@@ -109,7 +102,7 @@ struct LdsTab4 {
 };
 __device__ __forceinline__ void lds_tab4_fill(uint32_t *lds) {
     for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) {
-        uint32_t v = c_te0[i >> 6];
+        uint32_t v = c_aes.te0[i >> 6];
         const bool odd = (i >> 5) & 1;
         lds[i] = odd ? ((v << 8) | (v >> 24)) : v;
         lds[kLdsTabWords + i] = odd ? ((v << 24) | (v >> 8)) : ((v << 16) | (v >> 16));
@@ -125,7 +118,7 @@ __device__ __forceinline__ LdsTab4 lds_tab4_make(const uint32_t *lds) {
 }
 
 __device__ __forceinline__ void lds_tab_fill(uint32_t *lds) {
-    for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) lds[i] = c_te0[i >> 6];
+    for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) lds[i] = c_aes.te0[i >> 6];
     __syncthreads();
 }
 __device__ __forceinline__ LdsTab lds_tab_make(const uint32_t *lds) {
@@ -155,7 +148,7 @@ struct LdsTab2h {
 };
 __device__ __forceinline__ void lds_tab2h_fill(uint32_t *lds) {
     for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) {
-        uint32_t v = c_te0[i >> 6];
+        uint32_t v = c_aes.te0[i >> 6];
         lds[i] = ((i >> 5) & 1) ? ((v << 16) | (v >> 16)) : v;
     }
     __syncthreads();
@@ -357,12 +350,12 @@ struct GpuBackend {
         if (on) {
             if (GARBLER) {
                 Lbl TG, TE;
-                c = garble_and(lt, c_rk, R, a, b, gid, TG, TE, c_rk24);
+                c = garble_and(lt, c_aes.rk, R, a, b, gid, TG, TE, c_aes.rk24);
                 st_lbl_global(slot, TG);
                 st_lbl_global(slot + 64, TE);
             } else {
                 Lbl TG = ld_lbl_global(slot), TE = ld_lbl_global(slot + 64);
-                c = eval_and(lt, c_rk, a, b, gid, TG, TE, c_rk24);
+                c = eval_and(lt, c_aes.rk, a, b, gid, TG, TE, c_aes.rk24);
             }
         }
         return c;
@@ -384,7 +377,7 @@ struct GpuBackend {
                 if (on) {
                     Lbl x = (wave == 0) ? lxor(a, lmask(R, pa)) : lxor(b, lmask(R, pb));
                     uint64_t tw = 2 * gid + (uint64_t)wave;
-                    hash_n<1, TAB>(lt, c_rk, &x, &tw, &h, c_rk24);
+                    hash_n<1, TAB>(lt, c_aes.rk, &x, &tw, &h, c_aes.rk24);
                 }
                 st_lbl_lds(xbuf + wave * 64 + lane, h);
             } else {
@@ -407,7 +400,7 @@ struct GpuBackend {
                 Lbl x = (wave < (nh >> 1)) ? a : b;
                 if (GARBLER && (wave & 1)) x = lxor(x, R);
                 uint64_t tw = 2 * gid + (uint64_t)(wave >= (nh >> 1));
-                hash_n<1, TAB>(lt, c_rk, &x, &tw, &h, c_rk24);
+                hash_n<1, TAB>(lt, c_aes.rk, &x, &tw, &h, c_aes.rk24);
             }
             xbuf[wave * 64 + lane] = h;
         }
@@ -450,7 +443,7 @@ struct GpuBackend {
             if (on) {
                 Lbl x = lxor(src, lmask(R, src.x & 1u));
                 uint64_t tw = 2 * (g2 ? gid2 : gid) + (uint64_t)(wave & 1);
-                hash_n<1, TAB>(lt, c_rk, &x, &tw, &h, c_rk24);
+                hash_n<1, TAB>(lt, c_aes.rk, &x, &tw, &h, c_aes.rk24);
             }
             st_lbl_lds(xbuf + wave * 64 + lane, h);
 #ifndef GC_X_NOSTASH
@@ -474,7 +467,7 @@ struct GpuBackend {
             if (wave & 1) { x[0] = lxor(x[0], R); x[1] = lxor(x[1], R); }
             uint64_t tw[2] = {2 * gid + (uint64_t)(wave >= 2), 2 * gid2 + (uint64_t)(wave >= 2)};
             Lbl h[2] = {lzero(), lzero()};
-            if (on1 || on2) hash_n<2, TAB>(lt, c_rk, x, tw, h, c_rk24);
+            if (on1 || on2) hash_n<2, TAB>(lt, c_aes.rk, x, tw, h, c_aes.rk24);
             xbuf[wave * 64 + lane] = h[0];
             xbuf[256 + wave * 64 + lane] = h[1];
         } else {
@@ -482,7 +475,7 @@ struct GpuBackend {
             Lbl x = (wave & 1) ? ((wave < 2) ? b1 : b2) : ((wave < 2) ? a1 : a2);
             uint64_t tw = 2 * ((wave < 2) ? gid : gid2) + (uint64_t)(wave & 1);
             Lbl h = lzero();
-            if ((wave < 2) ? on1 : on2) hash_n<1, TAB>(lt, c_rk, &x, &tw, &h, c_rk24);
+            if ((wave < 2) ? on1 : on2) hash_n<1, TAB>(lt, c_aes.rk, &x, &tw, &h, c_aes.rk24);
             xbuf[(wave >> 1) * 256 + (wave & 1) * 64 + lane] = h;
         }
         lds_barrier();
@@ -721,7 +714,7 @@ gc_tabfill_kernel(const Lbl *stash, Lbl *tab, uint32_t nsteps, uint64_t launch_s
         Lbl TG = lzero(), TE = lzero();
         if ((a0.x | a0.y | a0.z | a0.w | b0.x | b0.y | b0.z | b0.w) != 0u) {
             const uint64_t gid = (launch_step0 + row) * 64 + (uint64_t)lane;
-            (void)garble_and(lt, c_rk, R, a0, b0, gid, TG, TE, c_rk24);
+            (void)garble_and(lt, c_aes.rk, R, a0, b0, gid, TG, TE, c_aes.rk24);
         }
         st_lbl(slot, TG);
         st_lbl(slot + 64, TE);

@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <mutex>
 #include <string>
@@ -34,6 +36,24 @@ int lgc_fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *lgc_last_error(void) { return g_err; }
+
+// LINREG_TRACE=1: where a run spends its start-up.  One line per mark on stderr, "LGCT <tag> <seconds> <what>", the time
+// being CLOCK_MONOTONIC so that the marks of all processes of a run -- and of whoever spawned them -- share one base
+// (bench.py builds the `timeline` of its phase12 entries from these lines).  Off: one getenv at the first mark.
+static char g_trace_tag[32] = "lgc";
+static int trace_on() {
+    static const int on = getenv("LINREG_TRACE") != NULL;
+    return on;
+}
+extern "C" void lgc_trace_set_tag(const char *tag) {
+    if (tag) snprintf(g_trace_tag, sizeof g_trace_tag, "%s", tag);
+}
+extern "C" void lgc_trace_mark(const char *what) {
+    if (!trace_on()) return;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    fprintf(stderr, "LGCT %s %.6f %s\n", g_trace_tag, (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec, what ? what : "");
+}
 extern "C" const char *lgc_version(void) { return "linreg-mpc_amd gc engine r3 (gfx950, half-gates, LDS T-table AES, Karatsuba MAC, Sklansky adders)"; }
 extern "C" int lgc_device_count(void) {
     int n = 0;
@@ -42,11 +62,35 @@ extern "C" int lgc_device_count(void) {
 }
 
 int lgc_need_device(int device) {
+    static std::once_flag enter;
+    std::call_once(enter, [] { lgc_trace_mark("lib: first device call"); });
     int n = lgc_device_count();
     if (n <= 0) return lgc_fail(LGC_ENODEVICE, "no HIP device visible: the garbled-circuit engine has no CPU fallback");
     if (device < 0 || device >= n) return lgc_fail(LGC_EINVAL, "device %d out of range (%d visible)", device, n);
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return lgc_fail(LGC_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+    static std::once_flag first;
+    std::call_once(first, [] {
+        lgc_trace_mark("lib: hip runtime up (device count, hipSetDevice)");
+        (void)hipFree(0);                                // the device context itself
+        lgc_trace_mark("lib: device context up");
+    });
+    return LGC_OK;
+}
+
+// brings the HIP runtime and the device's context up (any thread: both are process-wide); a host calls it from a thread
+// at start-up so that the 60-150 ms overlap its own parsing and connecting
+extern "C" int lgc_device_warm(int device) {
+    int rc = lgc_need_device(device);
+    if (rc) return rc;
+    // the first dispatch of a process creates its hardware queue and loads the runtime's own fill / copy kernels: ~20 ms
+    void *p = 0;
+    if (hipMalloc(&p, 4096) == hipSuccess) {
+        (void)hipMemset(p, 0, 4096);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(p);
+    }
+    lgc_trace_mark("lib: first dispatch done (warm-up thread)");
     return LGC_OK;
 }
 
@@ -58,21 +102,6 @@ static const AesTables &tables() {
     std::call_once(once, [] { aes_build_tables(g_tabs, kFixedKey); g_tabs_built = true; });
     return g_tabs;
 }
-// every translation unit with device code has its own copy of the AES constants (gc_device.h): fill them all, on the
-// CURRENT device (callers have just selected it: lgc_need_device)
-hipError_t p1_tu_upload(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24);
-hipError_t ot_tu_upload(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24);
-int lgc_upload_constants() {
-    const AesTables &t = tables();
-    uint32_t rk24[44];
-    for (int i = 0; i < 44; i++) rk24[i] = (t.rk[i] << 24) | (t.rk[i] >> 8);
-    HIPCHK(gc_tu_upload(t.rk, t.te0, rk24));
-    HIPCHK(gc_kern_upload_all(t.rk, t.te0, rk24));
-    HIPCHK(p1_tu_upload(t.rk, t.te0, rk24));
-    HIPCHK(ot_tu_upload(t.rk, t.te0, rk24));
-    return LGC_OK;
-}
-
 // Garbler randomness.  The global offset R and the zero-labels of the input wires are AES-128 in counter mode
 // KEYED BY THE SEED (its own key schedule, as the OT column PRG and the TI generator do) -- not the public
 // fixed-key gate hash evaluated at seed-dependent points, which would let one guess of the seed be tested
@@ -137,7 +166,7 @@ gc_aes_bench_kernel(uint32_t *out, int blocks_per_lane) {
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s[4][4];
     for (int b = 0; b < 4; b++) { s[b][0] = gid; s[b][1] = b; s[b][2] = gid * 2654435761u; s[b][3] = 0x9e3779b9u ^ b; }
-    for (int i = 0; i < blocks_per_lane; i += 4) aes_encrypt_n<4, TabT>(lt, c_rk, s, c_rk24);
+    for (int i = 0; i < blocks_per_lane; i += 4) aes_encrypt_n<4, TabT>(lt, c_aes.rk, s, c_aes.rk24);
     uint32_t acc = 0;
     for (int b = 0; b < 4; b++) acc ^= s[b][0] ^ s[b][1] ^ s[b][2] ^ s[b][3];
     out[gid] = acc;
@@ -154,16 +183,16 @@ gc_aes_encrypt_kernel(const uint4 *in, uint4 *out, uint32_t n) {
 #if GC_AES_TAB4
     lds_tab4_fill(lds_te0);
     LdsTab4 l4 = lds_tab4_make(lds_te0);
-    aes_encrypt_n<1, LdsTab4>(l4, c_rk, s, c_rk24);
+    aes_encrypt_n<1, LdsTab4>(l4, c_aes.rk, s, c_aes.rk24);
 #else
     lds_tab2_fill(lds_te0);
     LdsTab2 l2 = lds_tab2_make(lds_te0);
-    aes_encrypt_n<1, LdsTab2>(l2, c_rk, s, c_rk24);
+    aes_encrypt_n<1, LdsTab2>(l2, c_aes.rk, s, c_aes.rk24);
 #endif
     __syncthreads();
     lds_tab_fill(lds_te0);
     LdsTab lt = lds_tab_make(lds_te0);
-    aes_encrypt_n<1, LdsTab>(lt, c_rk, s1);
+    aes_encrypt_n<1, LdsTab>(lt, c_aes.rk, s1);
     if (i >= n) return;
     out[i] = (i & 1) ? make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]) : make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
 }
@@ -179,11 +208,11 @@ gc_gate_hash_kernel(const uint4 *in, const uint64_t *tweak, uint4 *out, uint32_t
     uint64_t tw = i < n ? tweak[i] : 0;
     if (kind == GATE_HASH_CHASKEY12) {
         NoTab nt;
-        hash_n<1, NoTab>(nt, c_rk, &x, &tw, &h);
+        hash_n<1, NoTab>(nt, c_aes.rk, &x, &tw, &h);
     } else {
         lds_tab4_fill(lds_te0);
         LdsTab4 l4 = lds_tab4_make(lds_te0);
-        hash_n<1, LdsTab4>(l4, c_rk, &x, &tw, &h, c_rk24);
+        hash_n<1, LdsTab4>(l4, c_aes.rk, &x, &tw, &h, c_aes.rk24);
     }
     if (i < n) out[i] = make_uint4(h.x, h.y, h.z, h.w);
 }
@@ -254,7 +283,9 @@ static int build_sweep(Program &P, const lgc_system *sys, size_t count, const do
     if ((uint64_t)base.n_words * count >= (1ull << 31)) return lgc_fail(LGC_EINVAL, "sweep too large: %zu circuits x %u words", count, base.n_words);
     std::vector<uint64_t> lf(count);
     for (size_t t = 0; t < count; t++) lf[t] = lambda_to_fixed(lambdas[t], sys->precision, sys->width);
-    replicate_program(P, base, count, lf.data(), first);
+    if (!replicate_program(P, base, count, lf.data(), first))
+        return lgc_fail(LGC_EINVAL, "sweep too large: a circuit of %llu gate steps (or circuit index %zu) does not fit the gate-id stride of a sweep",
+                        (unsigned long long)(base.total_steps - base.prefix_steps), first + count);
     if (!P.ranges_ok()) return lgc_fail(LGC_EINVAL, "internal: a record of the merged program lies outside its word file");
     return LGC_OK;
 }
@@ -454,8 +485,6 @@ static int solver_create(lgc_solver **out, int device, const lgc_system *sys, co
     if (rc) return rc;
     if (!out || !seed) return lgc_fail(LGC_EINVAL, "null argument");
     rc = lgc_need_device(device);
-    if (rc) return rc;
-    rc = lgc_upload_constants();
     if (rc) return rc;
     lgc_solver *s = new lgc_solver();
     s->sys = *sys;
@@ -851,8 +880,6 @@ extern "C" int lgc_gate_hash_eval(int device, int kind, const uint8_t *labels, c
     DevFree dev_guard;
     int rc = lgc_need_device(device);
     if (rc) return rc;
-    rc = lgc_upload_constants();
-    if (rc) return rc;
     uint4 *di = 0, *dout = 0;
     uint64_t *dt = 0;
     HIPCHK(hipMalloc(&di, n * 16 + 16)); dev_guard.add(di);
@@ -874,8 +901,6 @@ extern "C" void lgc_set_split_kernels(int garbler, int evaluator) {
 extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double *rate, uint32_t *check) {
     DevFree dev_guard;   // temporary device buffers are released on every return path
     int rc = lgc_need_device(device);
-    if (rc) return rc;
-    rc = lgc_upload_constants();
     if (rc) return rc;
     if (waves < 16 || blocks_per_lane < 4) return lgc_fail(LGC_EINVAL, "waves >= 16 and blocks_per_lane >= 4 required");
     blocks_per_lane &= ~3;
@@ -907,8 +932,6 @@ extern "C" int lgc_aes_bench(int device, int waves, int blocks_per_lane, double 
 extern "C" int lgc_aes_encrypt(int device, const uint8_t *in, uint8_t *out, size_t n) {
     DevFree dev_guard;   // temporary device buffers are released on every return path
     int rc = lgc_need_device(device);
-    if (rc) return rc;
-    rc = lgc_upload_constants();
     if (rc) return rc;
     uint4 *di = 0, *dout = 0;
     HIPCHK(hipMalloc(&di, n * 16)); dev_guard.add(di);

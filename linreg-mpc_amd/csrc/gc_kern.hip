@@ -24,9 +24,6 @@ hipError_t GC_CAT3(gc_launch_records_, GC_ROLE_TAG, GC_KERN_PART)(LaunchMode m, 
                                                                    Lbl *tab, Lbl R, int w, int p, hipStream_t st) {
     return gc_launch_records_impl<GC_KERN_G != 0, GC_KERN_PART, GC_KERN_HASH>(m, recs, L, words, dec, tab, R, w, p, st);
 }
-hipError_t GC_CAT3(gc_kern_upload_, GC_ROLE_TAG, GC_KERN_PART)(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24) {
-    return gc_tu_upload(rk, te0, rk24);
-}
 #if GC_KERN_G && GC_KERN_PART == 2 && !GC_KERN_HASH
 hipError_t gc_launch_tabfill(const Launch &L, const Lbl *stash, Lbl *tab, Lbl R, hipStream_t st) {
     return gc_launch_tabfill_impl(L, stash, tab, R, st);

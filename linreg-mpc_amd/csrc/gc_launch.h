@@ -208,22 +208,10 @@ static inline bool gc_mode_is_crit(LaunchMode m, const Launch &L) {
 hipError_t gc_launch_tabfill(const Launch &L, const Lbl *stash, Lbl *tab, Lbl R, hipStream_t st);
 #define GC_KERN_DECL(tag)                                                                                                              \
     hipError_t gc_launch_records_##tag(LaunchMode m, const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R, int w, \
-                                       int p, hipStream_t st);                                                                         \
-    hipError_t gc_kern_upload_##tag(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24);
+                                       int p, hipStream_t st);
 GC_KERN_DECL(g_0) GC_KERN_DECL(g_1) GC_KERN_DECL(g_2) GC_KERN_DECL(g_3) GC_KERN_DECL(e_0) GC_KERN_DECL(e_1) GC_KERN_DECL(e_2) GC_KERN_DECL(e_3)
-GC_KERN_DECL(g_0h) GC_KERN_DECL(g_1h) GC_KERN_DECL(g_3h) GC_KERN_DECL(e_0h) GC_KERN_DECL(e_1h) GC_KERN_DECL(e_3h)      // gate hash 1 (no tables: nothing to upload)
+GC_KERN_DECL(g_0h) GC_KERN_DECL(g_1h) GC_KERN_DECL(g_3h) GC_KERN_DECL(e_0h) GC_KERN_DECL(e_1h) GC_KERN_DECL(e_3h)      // gate hash 1
 #undef GC_KERN_DECL
-static inline hipError_t gc_kern_upload_all(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24) {
-    hipError_t e = gc_kern_upload_g_0(rk, te0, rk24);
-    if (e == hipSuccess) e = gc_kern_upload_g_1(rk, te0, rk24);
-    if (e == hipSuccess) e = gc_kern_upload_g_2(rk, te0, rk24);
-    if (e == hipSuccess) e = gc_kern_upload_e_0(rk, te0, rk24);
-    if (e == hipSuccess) e = gc_kern_upload_e_1(rk, te0, rk24);
-    if (e == hipSuccess) e = gc_kern_upload_e_2(rk, te0, rk24);
-    if (e == hipSuccess) e = gc_kern_upload_g_3(rk, te0, rk24);
-    if (e == hipSuccess) e = gc_kern_upload_e_3(rk, te0, rk24);
-    return e;
-}
 // the record kernel of a launch in mode `m` (garbler in a critical-path mode: `tab` is the stash)
 template <bool G>
 static inline hipError_t gc_launch_records(LaunchMode m, int hash, const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R,

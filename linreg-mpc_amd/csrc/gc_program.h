@@ -740,9 +740,16 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
 // holds lambda.  The records of all circuits of one launch of P0 share a launch, so the dependent chains
 // (dividers, reveals) of different circuits fill the GPU together.
 // first_copy: index of this program's first circuit in the whole sweep.  Ranks of a multi-GPU sweep share
-// the prefix -- hence the garbler's offset R -- so their gate ids must not collide: circuit k of the sweep
-// owns the gate steps [prefix + k * per_circuit, prefix + (k + 1) * per_circuit) on whichever rank it runs.
-inline void replicate_program(Program &P, const Program &P0, size_t count, const uint64_t *lambda_fixed, size_t first_copy = 0) {
+// the prefix -- hence the garbler's offset R -- so their gate ids must not collide.  The number of gate steps a
+// circuit lowers to depends on the size of the block it is merged into (merge_hint shapes the dot-product
+// records), so the ranges are laid out on a CANONICAL stride that no lowering reaches: circuit k of the sweep
+// owns gate steps inside [prefix + k * kSweepCircuitStride, prefix + (k + 1) * kSweepCircuitStride) on whichever
+// rank and in whichever block it runs -- blocks of different sizes cannot overlap (round 3 used the block's own
+// per-circuit count as the stride; two blocks whose sizes differed by one then shared gate ids under one R).
+// Step numbers only enter the hash tweaks (64 * step + lane < 2^59 with at most 65536 circuits) and, as differences
+// within a launch, the table rows.  Returns false when a circuit does not fit its stride.
+static const uint64_t kSweepCircuitStride = 1ull << 36;
+inline bool replicate_program(Program &P, const Program &P0, size_t count, const uint64_t *lambda_fixed, size_t first_copy = 0) {
     P.w = P0.w; P.p = P0.p; P.d = P0.d; P.T = P0.T; P.nshares = P0.nshares;
     P.gate_hash = P0.gate_hash;
     P.cap_steps = P0.cap_steps;
@@ -754,6 +761,8 @@ inline void replicate_program(Program &P, const Program &P0, size_t count, const
     P.n_reveal = (uint32_t)count * P.reveal_stride;
     P.in_base = P0.in_base; P.rv_beta = P0.rv_beta; P.rv_trace = P0.rv_trace; P.rv_ab = P0.rv_ab;
     P.lam_rec = ~0u;
+    if (P0.prefix_steps >= kSweepCircuitStride || P0.total_steps - P0.prefix_steps > kSweepCircuitStride || first_copy + count > 65536)
+        return false;
     size_t next_iter = 0;
     const uint32_t shared_end = P0.shared_end;
     for (size_t li = 0; li < P0.launches.size(); li++) {
@@ -763,7 +772,7 @@ inline void replicate_program(Program &P, const Program &P0, size_t count, const
             P.new_launch();
             P.prefix_launches = (uint32_t)P.launches.size();
             P.prefix_steps = P.total_steps;
-            P.step_cursor = P0.prefix_steps + (uint64_t)first_copy * (P0.total_steps - P0.prefix_steps);
+            P.step_cursor = P0.prefix_steps + (uint64_t)first_copy * kSweepCircuitStride;
         }
         // a merged launch that exceeds the table cap is cut into EQUAL pieces (a ragged last piece of a MAC launch would
         // be a launch of a few hundred records: most of the chip idle, or the wrong kernel altogether)
@@ -823,6 +832,7 @@ inline void replicate_program(Program &P, const Program &P0, size_t count, const
             next_iter++;
         }
     }
+    return true;
 }
 
 // Garbled-table ring (co-located solver): launch i owns the byte range [off[i], off[i] + len[i]) of a

@@ -43,6 +43,13 @@ struct lgc_party {
     int ring_slots;
     size_t ring_slot_bytes;
     bool ring_imported;
+    // ... or, as a BYTE ring (lgc_party_ring_create_bytes): launch k owns [ring_off[k], ring_off[k] + its table bytes) of
+    // ring_bytes, laid out by plan_table_ring on both sides (same program, same size: same offsets); before the garbler
+    // overwrites a range it waits for the evaluation of launch ring_wait[k].  ring_slots == 0 in this mode.
+    size_t ring_bytes;
+    std::vector<size_t> ring_off;
+    std::vector<int64_t> ring_wait;
+    size_t tab_bytes;      // size of the private buffer `tab`
 };
 
 // (m0, m1) = (zero label, zero label ^ R) per input bit of one share: yaoKeyNewPair (input.c:94-101)
@@ -107,9 +114,32 @@ extern "C" uint64_t lgc_party_prefix_and_gates(const lgc_party *p) {
 // constant zero, inputs, share sums -- over xGMI (hipMemcpyPeer) and then runs launches [prefix_launches, n) only.
 extern "C" int lgc_party_share_prefix(lgc_party *dst, const lgc_party *src) {
     if (!dst || !src) return lgc_fail(LGC_EINVAL, "null party");
-    if (dst->role != src->role || dst->P.shared_end != src->P.shared_end || dst->P.prefix_launches != src->P.prefix_launches ||
-        !src->P.prefix_launches || dst->P.w != src->P.w)
+    const Program &D = dst->P, &S = src->P;
+    if (dst->role != src->role || D.shared_end != S.shared_end || D.prefix_launches != S.prefix_launches || !S.prefix_launches ||
+        D.w != S.w || D.p != S.p || D.d != S.d || D.T != S.T || D.nshares != S.nshares || D.gate_hash != S.gate_hash ||
+        D.prefix_steps != S.prefix_steps || D.in_base != S.in_base)
         return lgc_fail(LGC_EINVAL, "the parties are not blocks of the same sweep");
+    // the prefix itself: the same records in the same launches (what the source garbled is what the destination's circuits read)
+    for (uint32_t li = 0; li < S.prefix_launches; li++) {
+        const Launch &a = D.launches[li], &b = S.launches[li];
+        if (a.first_rec != b.first_rec || a.nrec != b.nrec || a.step0 != b.step0 || a.steps != b.steps ||
+            (a.nrec && memcmp(&D.recs[a.first_rec], &S.recs[b.first_rec], (size_t)a.nrec * sizeof(Rec)) != 0))
+            return lgc_fail(LGC_EINVAL, "the parties are not blocks of the same sweep: their prefix launches differ");
+    }
+    // both blocks hash under one R: their gate steps beyond the prefix must not meet (replicate_program lays the circuits of
+    // a sweep on a canonical stride, so this only fails for blocks that cover a common circuit)
+    auto body = [](const Program &P, uint64_t &lo, uint64_t &hi) {
+        lo = ~0ull; hi = 0;
+        for (size_t li = P.prefix_launches; li < P.launches.size(); li++) {
+            const Launch &L = P.launches[li];
+            if (!L.steps) continue;
+            if (L.step0 < lo) lo = L.step0;
+            if (L.step0 + L.steps > hi) hi = L.step0 + L.steps;
+        }
+    };
+    uint64_t dlo, dhi, slo, shi;
+    body(D, dlo, dhi); body(S, slo, shi);
+    if (dlo < shi && slo < dhi) return lgc_fail(LGC_EINVAL, "the blocks overlap in gate steps: they cover a common circuit of the sweep");
     if (dst->role == LGC_ROLE_GARBLER && memcmp(&dst->R, &src->R, sizeof(Lbl)) != 0)
         return lgc_fail(LGC_EINVAL, "garbler blocks of one sweep share the seed");
     if (!src->labels_ready) return lgc_fail(LGC_ESTATE, "the source has no input labels yet");
@@ -132,12 +162,10 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
     if (role == LGC_ROLE_GARBLER && !seed) return lgc_fail(LGC_EINVAL, "the garbler needs a seed");
     rc = lgc_need_device(device);
     if (rc) return rc;
-    rc = lgc_upload_constants();
-    if (rc) return rc;
     lgc_party *p = new lgc_party();
     p->sys = *sys; p->device = device; p->role = role;
     p->words = 0; p->tab = 0; p->dec = 0; p->recs = 0; p->labels_ready = false;
-    p->ring = 0; p->ring_slots = 0; p->ring_slot_bytes = 0; p->ring_imported = false;
+    p->ring = 0; p->ring_slots = 0; p->ring_slot_bytes = 0; p->ring_imported = false; p->ring_bytes = 0; p->tab_bytes = 0;
     if (!max_launch_table_bytes) max_launch_table_bytes = (size_t)256 << 20;
     const uint64_t cap = max_launch_table_bytes / 2048 ? max_launch_table_bytes / 2048 : 1;
     if (lambdas) {
@@ -147,6 +175,7 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
         rc = build(p->P, sys, cap);
         if (rc) { delete p; return rc; }
     }
+    lgc_trace_mark("lib: program lowered");
     memset(&p->R, 0, sizeof(Lbl)); memset(&p->seed, 0, sizeof(Lbl));
     if (role == LGC_ROLE_GARBLER) {
         memcpy(&p->seed, seed, 16);
@@ -174,6 +203,7 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
     }
     p->hdec.resize(P.n_reveal + 1);
     *out = p;
+    lgc_trace_mark(role == LGC_ROLE_GARBLER ? "lib: word file, records, input zero-labels on the device" : "lib: word file and records on the device");
     return LGC_OK;
 }
 
@@ -270,13 +300,28 @@ extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint
 // memory the evaluator process maps (the hipIpc ring) keeps the zero-label stash of critical-path launches in its
 // PRIVATE buffer p->tab: only finished ciphertexts are ever stored to the shared slot (src/input.c:94-108 -- label
 // pairs never leave the CSP)
-static hipError_t party_need_tab(lgc_party *p) {
-    if (p->tab) return hipSuccess;
-    return hipMalloc(&p->tab, p->P.max_launch_steps * 2048 + 16);
+// Bytes of stash a garbler needs when its tables go to a ring: the largest launch that CAN run as critical-path garbling
+// (few records: gc_launch_mode; the run-time switches only ever turn such launches into ordinary ones).  Rounds 2-3 sized the
+// private buffer for the largest launch of all -- 2.6 GB at d = 100, allocated inside the first garbling call.
+static size_t party_stash_bytes(const lgc_party *p) {
+    uint64_t steps = 0;
+    const uint32_t lim = kSplitMaxRecs > kQuadOnePerCu ? kSplitMaxRecs : kQuadOnePerCu;
+    for (const Launch &L : p->P.launches)
+        if (L.nrec <= lim && L.steps > steps) steps = L.steps;
+    return (size_t)steps * 2048 + 16;
 }
+static hipError_t party_need_tab(lgc_party *p, size_t bytes) {
+    if (p->tab && p->tab_bytes >= bytes) return hipSuccess;
+    if (p->tab) { (void)hipDeviceSynchronize(); (void)hipFree(p->tab); p->tab = 0; p->tab_bytes = 0; }
+    hipError_t e = hipMalloc(&p->tab, bytes);
+    if (e == hipSuccess) p->tab_bytes = bytes;
+    return e;
+}
+static hipError_t party_need_tab(lgc_party *p) { return party_need_tab(p, (size_t)p->P.max_launch_steps * 2048 + 16); }
 template <bool G>
 static hipError_t party_launch(lgc_party *p, const Launch &L, Lbl *tab = 0, int stages = 3, bool *was_crit = 0) {
-    if (!tab || G) { hipError_t e = party_need_tab(p); if (e != hipSuccess) return e; }
+    if (!tab) { hipError_t e = party_need_tab(p); if (e != hipSuccess) return e; }
+    else if (G) { hipError_t e = party_need_tab(p, party_stash_bytes(p)); if (e != hipSuccess) return e; }
     return gc_launch<G>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab ? tab : p->tab, p->R, p->P.w, p->P.p, 0, (G && tab) ? p->tab : (Lbl *)0,
                         stages, was_crit);
 }
@@ -309,20 +354,14 @@ extern "C" int lgc_party_evaluate(lgc_party *p, size_t launch, const uint8_t *ta
 }
 // ---- table ring (device-resident hand-off; replaces the osend/orecv byte stream of the Yao
 // protocol when both roles run on one node)
-extern "C" int lgc_party_ring_create(lgc_party *p, int nslots, uint8_t handle_out[64], size_t *slot_bytes) {
-    if (!p || !handle_out || !slot_bytes) return lgc_fail(LGC_EINVAL, "null argument");
-    if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "the garbler owns the table ring");
-    if (nslots < 1 || nslots > 64) return lgc_fail(LGC_EINVAL, "nslots must be in 1..64");
-    if (p->ring) return lgc_fail(LGC_ESTATE, "the ring already exists");
+static int ring_alloc_export(lgc_party *p, size_t bytes, uint8_t handle_out[64]) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
     RCHK(hipSetDevice(p->device));
-    size_t sb = ((size_t)p->P.max_launch_steps * 2048 + 4095) & ~(size_t)4095;
-    if (!sb) sb = 4096;
-    hipError_t e = hipMalloc(&p->ring, sb * (size_t)nslots);
-    if (e != hipSuccess) return lgc_fail(LGC_ENOMEM, "hipMalloc(table ring, %zu bytes): %s", sb * (size_t)nslots, hipGetErrorString(e));
+    hipError_t e = hipMalloc(&p->ring, bytes);
+    if (e != hipSuccess) return lgc_fail(LGC_ENOMEM, "hipMalloc(table ring, %zu bytes): %s", bytes, hipGetErrorString(e));
     // the evaluator process maps the whole ring: it must never see what this allocation held before
     // (inactive lanes and padding are not written by the kernels)
-    e = hipMemset(p->ring, 0, sb * (size_t)nslots);
+    e = hipMemset(p->ring, 0, bytes);
     if (e != hipSuccess) { (void)hipFree(p->ring); p->ring = 0; return lgc_fail(LGC_EHIP, "hipMemset(table ring): %s", hipGetErrorString(e)); }
     hipIpcMemHandle_t h;
     e = hipIpcGetMemHandle(&h, p->ring);
@@ -331,7 +370,34 @@ extern "C" int lgc_party_ring_create(lgc_party *p, int nslots, uint8_t handle_ou
         return lgc_fail(LGC_EHIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
     }
     memcpy(handle_out, &h, 64);
-    p->ring_slots = nslots; p->ring_slot_bytes = sb; p->ring_imported = false;
+    // the stash of the critical-path launches now as well, not inside the first garbling call
+    e = party_need_tab(p, party_stash_bytes(p));
+    if (e != hipSuccess) { (void)hipFree(p->ring); p->ring = 0; return lgc_fail(LGC_ENOMEM, "hipMalloc(stash): %s", hipGetErrorString(e)); }
+    p->ring_imported = false;
+    lgc_trace_mark("lib: table ring allocated, zero-filled, exported");
+    return LGC_OK;
+}
+static int ring_map(lgc_party *p, const uint8_t handle[64]) {
+    RCHK(hipSetDevice(p->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    void *ptr = 0;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return lgc_fail(LGC_EHIP, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+    p->ring = (Lbl *)ptr; p->ring_imported = true;
+    lgc_trace_mark("lib: table ring mapped");
+    return LGC_OK;
+}
+extern "C" int lgc_party_ring_create(lgc_party *p, int nslots, uint8_t handle_out[64], size_t *slot_bytes) {
+    if (!p || !handle_out || !slot_bytes) return lgc_fail(LGC_EINVAL, "null argument");
+    if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "the garbler owns the table ring");
+    if (nslots < 1 || nslots > 64) return lgc_fail(LGC_EINVAL, "nslots must be in 1..64");
+    if (p->ring) return lgc_fail(LGC_ESTATE, "the ring already exists");
+    size_t sb = ((size_t)p->P.max_launch_steps * 2048 + 4095) & ~(size_t)4095;
+    if (!sb) sb = 4096;
+    int rc = ring_alloc_export(p, sb * (size_t)nslots, handle_out);
+    if (rc) return rc;
+    p->ring_slots = nslots; p->ring_slot_bytes = sb; p->ring_bytes = 0;
     *slot_bytes = sb;
     return LGC_OK;
 }
@@ -341,16 +407,51 @@ extern "C" int lgc_party_ring_open(lgc_party *p, const uint8_t handle[64], int n
     if (nslots < 1 || nslots > 64) return lgc_fail(LGC_EINVAL, "nslots must be in 1..64");
     if (slot_bytes < (size_t)p->P.max_launch_steps * 2048) return lgc_fail(LGC_EINVAL, "ring slots are smaller than the largest launch");
     if (p->ring) return lgc_fail(LGC_ESTATE, "the ring is already open");
-    RCHK(hipSetDevice(p->device));
-    hipIpcMemHandle_t h;
-    memcpy(&h, handle, 64);
-    void *ptr = 0;
-    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
-    if (e != hipSuccess) return lgc_fail(LGC_EHIP, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
-    p->ring = (Lbl *)ptr; p->ring_slots = nslots; p->ring_slot_bytes = slot_bytes; p->ring_imported = true;
+    int rc = ring_map(p, handle);
+    if (rc) return rc;
+    p->ring_slots = nslots; p->ring_slot_bytes = slot_bytes; p->ring_bytes = 0;
     return LGC_OK;
 }
+// The byte ring: the largest launch plus room for what the garbler runs ahead by (default: half as much again, between
+// 64 MiB and 4 GiB), instead of `nslots` times the largest launch -- 3.9 GB against 10.5 GB at d = 100, 12 GB against 33 GB
+// for config 4: a fresh device allocation costs 30-70 ms per GB on this driver (and the same again when it is released), which
+// was the largest single item of an end-to-end run of config 3.  Both processes lay the launches out with plan_table_ring.
+static size_t default_ring_bytes(const Program &P) {
+    const size_t largest = ((size_t)P.max_launch_steps * 2048 + 4095) & ~(size_t)4095;
+    size_t slack = largest / 2;
+    if (slack < ((size_t)64 << 20)) slack = (size_t)64 << 20;
+    if (slack > ((size_t)4 << 30)) slack = (size_t)4 << 30;
+    return largest + slack + 4096;
+}
+extern "C" int lgc_party_ring_create_bytes(lgc_party *p, size_t ring_bytes, uint8_t handle_out[64], size_t *ring_bytes_out) {
+    if (!p || !handle_out || !ring_bytes_out) return lgc_fail(LGC_EINVAL, "null argument");
+    if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "the garbler owns the table ring");
+    if (p->ring) return lgc_fail(LGC_ESTATE, "the ring already exists");
+    const size_t bytes = plan_table_ring(p->P, ring_bytes ? ring_bytes : default_ring_bytes(p->P), p->ring_off, p->ring_wait);
+    int rc = ring_alloc_export(p, bytes, handle_out);
+    if (rc) return rc;
+    p->ring_slots = 0; p->ring_slot_bytes = 0; p->ring_bytes = bytes;
+    *ring_bytes_out = bytes;
+    return LGC_OK;
+}
+extern "C" int lgc_party_ring_open_bytes(lgc_party *p, const uint8_t handle[64], size_t ring_bytes) {
+    if (!p || !handle) return lgc_fail(LGC_EINVAL, "null argument");
+    if (p->role != LGC_ROLE_EVALUATOR) return lgc_fail(LGC_ESTATE, "the evaluator opens the garbler's ring");
+    if (p->ring) return lgc_fail(LGC_ESTATE, "the ring is already open");
+    if (ring_bytes < (size_t)p->P.max_launch_steps * 2048) return lgc_fail(LGC_EINVAL, "the ring is smaller than the largest launch");
+    if (plan_table_ring(p->P, ring_bytes, p->ring_off, p->ring_wait) != ring_bytes)
+        return lgc_fail(LGC_EINVAL, "the ring does not fit this program");
+    int rc = ring_map(p, handle);
+    if (rc) return rc;
+    p->ring_slots = 0; p->ring_slot_bytes = 0; p->ring_bytes = ring_bytes;
+    return LGC_OK;
+}
+extern "C" int64_t lgc_party_ring_wait_for(const lgc_party *p, size_t launch) {
+    if (!p || !p->ring_bytes || launch >= p->ring_wait.size()) return -1;
+    return p->ring_wait[launch];
+}
 static Lbl *ring_slot(lgc_party *p, size_t launch) {
+    if (p->ring_bytes) return (Lbl *)((char *)p->ring + p->ring_off[launch]);
     return (Lbl *)((char *)p->ring + (launch % (size_t)p->ring_slots) * p->ring_slot_bytes);
 }
 extern "C" int lgc_party_garble_ring(lgc_party *p, size_t launch) {
@@ -377,7 +478,9 @@ extern "C" int lgc_test_party_garble_ring_stage(lgc_party *p, size_t launch, int
     return LGC_OK;
 }
 extern "C" int lgc_test_party_ring_read(lgc_party *p, size_t launch, uint8_t *out, size_t bytes) {
-    if (!p || !p->ring || !out || bytes > p->ring_slot_bytes) return lgc_fail(LGC_EINVAL, "bad argument");
+    if (!p || !p->ring || !out || launch >= p->P.launches.size() ||
+        bytes > (p->ring_bytes ? (size_t)p->P.launches[launch].steps * 2048 : p->ring_slot_bytes))
+        return lgc_fail(LGC_EINVAL, "bad argument");
     RCHK(hipSetDevice(p->device));
     RCHK(hipMemcpy(out, ring_slot(p, launch), bytes, hipMemcpyDeviceToHost));
     return LGC_OK;

@@ -376,7 +376,7 @@ gc_split_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *
     hc.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = hc.lane & 3;
 #pragma unroll
-    for (int k = 0; k < 11; k++) hc.rkl[k] = c_rk[4 * k + c];
+    for (int k = 0; k < 11; k++) hc.rkl[k] = c_aes.rk[4 * k + c];
     hc.Rq = GARBLER ? (c == 0 ? R.x : c == 1 ? R.y : c == 2 ? R.z : R.w) : 0u;
     hc.sx = lds_sx;
     hc.tabw = reinterpret_cast<uint32_t *>(tab);

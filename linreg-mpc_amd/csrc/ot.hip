@@ -30,8 +30,6 @@ using namespace gc;
 
 int lgc_fail(int code, const char *fmt, ...);
 int lgc_need_device(int device);
-int lgc_upload_constants();
-hipError_t ot_tu_upload(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24) { return gc_tu_upload(rk, te0, rk24); }
 
 #define OTCHK(x)                                                                             \
     do {                                                                                     \
@@ -171,8 +169,8 @@ ot_gilboa_send_kernel(const uint4 *rows, uint4 delta, const uint64_t *bvals, uin
             Lbl x[4] = {r1, lxor(r1, u4_lbl(delta)), r2, lxor(r2, u4_lbl(delta))};
             uint64_t tw[4] = {tweak0 + i, tweak0 + i, tweak0 + i2, tweak0 + i2};
             Lbl h[4];
-            hash_n<2, LdsTab4>(lt, c_rk, x, tw, h, c_rk24);
-            hash_n<2, LdsTab4>(lt, c_rk, x + 2, tw + 2, h + 2, c_rk24);
+            hash_n<2, LdsTab4>(lt, c_aes.rk, x, tw, h, c_aes.rk24);
+            hash_n<2, LdsTab4>(lt, c_aes.rk, x + 2, tw + 2, h + 2, c_aes.rk24);
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 if (e == 1 && !two) break;
@@ -210,7 +208,7 @@ ot_gilboa_recv_kernel(const uint4 *rows, const uint64_t *avals, uint64_t n, int 
             uint64_t tw[2] = {tweak0 + i, tweak0 + i2};
             const uint64_t yv[2] = {y[i], y[i2]};         // in flight during the hashes
             Lbl h[2];
-            hash_n<2, LdsTab4>(lt, c_rk, x, tw, h, c_rk24);
+            hash_n<2, LdsTab4>(lt, c_aes.rk, x, tw, h, c_aes.rk24);
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 if (e == 1 && !two) break;
@@ -264,8 +262,8 @@ ot_labels_send_kernel(const uint4 *rows, uint4 delta, const uint4 *m0, const uin
         Lbl x[4] = {r1, lxor(r1, u4_lbl(delta)), r2, lxor(r2, u4_lbl(delta))};
         uint64_t tw[4] = {tweak0 + i, tweak0 + i, tweak0 + i2, tweak0 + i2};
         Lbl h[4];
-        hash_n<2, LdsTab4>(lt, c_rk, x, tw, h, c_rk24);
-        hash_n<2, LdsTab4>(lt, c_rk, x + 2, tw + 2, h + 2, c_rk24);
+        hash_n<2, LdsTab4>(lt, c_aes.rk, x, tw, h, c_aes.rk24);
+        hash_n<2, LdsTab4>(lt, c_aes.rk, x + 2, tw + 2, h + 2, c_aes.rk24);
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             if (k == 1 && !two) break;
@@ -290,7 +288,7 @@ ot_labels_recv_kernel(const uint4 *rows, const uint64_t *cbits, const uint4 *e, 
         const uint32_t c1 = (uint32_t)(cbits[i >> 6] >> (i & 63)) & 1u, c2 = (uint32_t)(cbits[i2 >> 6] >> (i2 & 63)) & 1u;
         const uint4 ev1 = e[2 * i + c1], ev2 = e[2 * i2 + c2];      // in flight during the hashes
         Lbl h[2];
-        hash_n<2, LdsTab4>(lt, c_rk, x, tw, h, c_rk24);
+        hash_n<2, LdsTab4>(lt, c_aes.rk, x, tw, h, c_aes.rk24);
         out[i] = make_uint4(ev1.x ^ h[0].x, ev1.y ^ h[0].y, ev1.z ^ h[0].z, ev1.w ^ h[0].w);
         if (two) out[i2] = make_uint4(ev2.x ^ h[1].x, ev2.y ^ h[1].y, ev2.z ^ h[1].z, ev2.w ^ h[1].w);
     }
@@ -392,8 +390,6 @@ extern "C" int lgc_ot_sender_create(lgc_ot_sender **out, int device, const uint8
     if (!out || !delta || !seeds) return lgc_fail(LGC_EINVAL, "null argument");
     int rc = lgc_need_device(device);
     if (rc) return rc;
-    rc = lgc_upload_constants();
-    if (rc) return rc;
     lgc_ot_sender *s = new lgc_ot_sender();
     s->device = device; s->ctr = 0; s->tweak = 0; s->rk = 0; s->st = 0; s->dev_io = false;
     memcpy(&s->delta, delta, 16);
@@ -420,8 +416,6 @@ extern "C" void lgc_ot_receiver_destroy(lgc_ot_receiver *r) {
 extern "C" int lgc_ot_receiver_create(lgc_ot_receiver **out, int device, const uint8_t seeds0[128][16], const uint8_t seeds1[128][16]) {
     if (!out || !seeds0 || !seeds1) return lgc_fail(LGC_EINVAL, "null argument");
     int rc = lgc_need_device(device);
-    if (rc) return rc;
-    rc = lgc_upload_constants();
     if (rc) return rc;
     lgc_ot_receiver *r = new lgc_ot_receiver();
     r->device = device; r->rk0 = 0; r->rk1 = 0; r->ctr = 0; r->tweak = 0; r->st = 0; r->dev_io = false; r->head = 0; r->count = 0;

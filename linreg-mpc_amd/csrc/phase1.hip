@@ -23,8 +23,6 @@ using namespace gc;
 
 int lgc_fail(int code, const char *fmt, ...);
 int lgc_need_device(int device);
-int lgc_upload_constants();
-hipError_t p1_tu_upload(const uint32_t *rk, const uint32_t *te0, const uint32_t *rk24) { return gc_tu_upload(rk, te0, rk24); }
 
 #define P1CHK(x)                                                                             \
     do {                                                                                     \
@@ -644,8 +642,6 @@ static int ti_generate(int device, const uint8_t seed[16], uint64_t first_pair, 
     if (npairs == 0) return LGC_OK;
     int rc = lgc_need_device(device);
     if (rc) return rc;
-    rc = lgc_upload_constants();
-    if (rc) return rc;
     AesTables t;
     aes_build_tables(t, seed);
     uint32_t *drk = 0;
@@ -695,8 +691,6 @@ extern "C" int lgc_ti_generate_scatter(int device, const uint8_t seed[16], uint6
     if (width != 32 && width != 64) return lgc_fail(LGC_EINVAL, "width must be 32 or 64");
     if (npairs == 0) return LGC_OK;
     int rc = lgc_need_device(device);
-    if (rc) return rc;
-    rc = lgc_upload_constants();
     if (rc) return rc;
     // keystream -> destinations -> <x, y>: three kernels on grow-only per-thread scratch, no allocation per batch
     AesTables t;

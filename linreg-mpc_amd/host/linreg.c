@@ -12,6 +12,7 @@
 #define _GNU_SOURCE
 #include <errno.h>
 #include <math.h>
+#include <openssl/crypto.h>
 #include <openssl/rand.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -44,10 +45,86 @@ static void block_range(size_t n, size_t K, size_t k, size_t *lo, size_t *hi) {
     *hi = *lo + base + (k < extra ? 1 : 0);
 }
 
-typedef struct { node *self; int peer, rc; uint8_t delta[16], seeds[128][16]; pthread_t th; } base_ot_job;
-static void *base_ot_main(void *arg) {
-    base_ot_job *j = arg;
-    j->rc = baseot_ext_sender(j->self, j->peer, j->delta, j->seeds);
+/* The phase-2 object(s) of party 1 / 2: one, or with --devices one block of the sweep per entry (same seed: one set of
+ * input labels, one label OT per data provider; block k starts at circuit lo_k, which keeps its gate ids disjoint), and for
+ * the garbler its table ring(s).  A job, so that the CSP can run it on a thread while it is still the trusted initializer
+ * of phase 1: lowering the program, the word file and -- above all -- a ring of several GB used to start after the barrier,
+ * with every other party waiting. */
+typedef struct {
+    lgc_system sys; int role, device, n_devices, ring_slots; const int *devices; size_t table_chunk, n_lambdas; const double *lambdas;
+    lgc_party **blocks, *party_obj; int rc; char err[256]; pthread_t th; int started;
+} create_job;
+static void *create_main(void *arg) {
+    create_job *j = arg;
+    uint8_t seed[16];
+    const uint8_t *seedp = NULL;
+    j->rc = 1;
+    if (j->role == LGC_ROLE_GARBLER) {
+        if (RAND_bytes(seed, sizeof seed) != 1) { snprintf(j->err, sizeof j->err, "RAND_bytes failed"); return NULL; }
+        seedp = seed;
+    }
+#define JLGC(x) do { if ((x) != LGC_OK) { snprintf(j->err, sizeof j->err, "%s", lgc_last_error()); OPENSSL_cleanse(seed, sizeof seed); return NULL; } } while (0)
+    if (j->n_devices) {
+        for (int k = 0; k < j->n_devices; k++) {
+            size_t lo, hi;
+            block_range(j->n_lambdas, (size_t)j->n_devices, (size_t)k, &lo, &hi);
+            JLGC(lgc_party_create_sweep_at(&j->blocks[k], j->devices[k], &j->sys, j->role, seedp, j->table_chunk, hi - lo, j->lambdas + lo, lo));
+        }
+        j->party_obj = j->blocks[0];
+    } else if (j->n_lambdas) JLGC(lgc_party_create_sweep(&j->party_obj, j->device, &j->sys, j->role, seedp, j->table_chunk, j->n_lambdas, j->lambdas));
+    else JLGC(lgc_party_create(&j->party_obj, j->device, &j->sys, j->role, seedp, j->table_chunk));
+#undef JLGC
+    OPENSSL_cleanse(seed, sizeof seed);
+    if (j->role == LGC_ROLE_GARBLER && j->ring_slots > 0) {        /* the ring(s) now, not on the evaluator's clock */
+        for (int k = 0; k < (j->n_devices ? j->n_devices : 1); k++)
+            if (tables_ring_prepare(j->n_devices ? j->blocks[k] : j->party_obj, j->ring_slots)) {
+                snprintf(j->err, sizeof j->err, "could not create table ring %d", k);
+                return NULL;
+            }
+    }
+    lgc_trace_mark(j->role == LGC_ROLE_GARBLER ? "garbler created" : "evaluator created");
+    j->rc = 0;
+    return NULL;
+}
+/* the HIP runtime and the device context come up on a thread of their own while main parses, connects and reads */
+static void *warm_main(void *arg) {
+    int device = *(int *)arg;
+    (void)lgc_device_warm(device);
+    return NULL;
+}
+
+/* One thread per data provider on the CSP: the base OTs (128 P-256 transfers, host work on both sides) and then the label
+ * OT of that provider's share (dcrRecvBitArray, src/input.c:94-108) -- its own connection, its own OpenSSL objects, its own
+ * OT session and page-locked buffers.  The providers are independent of each other; served one after the other, as in
+ * rounds 1-3, the label OTs were 20-25 ms of latency EACH on the critical path of every run. */
+typedef struct {
+    node *self; int peer, device, rc; lgc_party *po; size_t share, bits; char err[256]; pthread_t th;
+} input_ot_job;
+static void *input_ot_main(void *arg) {
+    input_ot_job *j = arg;
+    uint8_t delta[16], seeds[128][16];
+    uint8_t *m0 = NULL, *m1 = NULL, *u = NULL, *e = NULL;
+    lgc_ot_sender *S = NULL;
+    const size_t bits = j->bits;
+    j->rc = 1;
+#define JFAIL(...) do { snprintf(j->err, sizeof j->err, __VA_ARGS__); goto out; } while (0)
+    if (baseot_ext_sender(j->self, j->peer, delta, seeds)) JFAIL("base OT with party %d failed", j->peer);
+    lgc_trace_mark("base OTs done");
+    m0 = lgc_host_alloc(bits * 16); m1 = lgc_host_alloc(bits * 16); u = lgc_host_alloc(lgc_ot_u_bytes(bits)); e = lgc_host_alloc(bits * 32);
+    if (!m0 || !m1 || !u || !e) JFAIL("%s", lgc_last_error());
+    if (lgc_ot_sender_create(&S, j->device, delta, seeds) != LGC_OK) JFAIL("%s", lgc_last_error());
+    if (lgc_party_input_pairs(j->po, j->share, m0, m1) != LGC_OK) JFAIL("%s", lgc_last_error());
+    if (recv_blob(j->self, j->peer, u, lgc_ot_u_bytes(bits))) JFAIL("OT: could not receive u from party %d", j->peer);
+    if (lgc_ot_labels_send(S, m0, m1, bits, u, e) != LGC_OK) JFAIL("%s", lgc_last_error());
+    if (send_blob(j->self, j->peer, e, bits * 32)) JFAIL("OT: could not send to party %d", j->peer);
+    j->rc = 0;
+out:
+#undef JFAIL
+    if (S) lgc_ot_sender_destroy(S);
+    if (m0) OPENSSL_cleanse(m0, bits * 16);                          /* both labels of every input bit: their XOR is R */
+    if (m1) OPENSSL_cleanse(m1, bits * 16);
+    lgc_host_free(m0); lgc_host_free(m1); lgc_host_free(u); lgc_host_free(e);
+    OPENSSL_cleanse(delta, sizeof delta); OPENSSL_cleanse(seeds, sizeof seeds);   /* base-OT delta and seeds */
     return NULL;
 }
 
@@ -59,12 +136,15 @@ int main(int argc, char **argv) {
     lgc_party *blocks[kMaxDevices] = {0};       /* --devices: blocks[0] == party_obj */
     int devices[kMaxDevices], n_devices = 0;
     int status;
+    create_job cj;
+    memset(&cj, 0, sizeof cj);
 
     check(argc > 6, "Usage: %s [Input_file] [Precision] [Party] [Algorithm] [Num. iterations CGD] [Lambda] [Options]\n"
           "Options: --use_ot: Enables the OT-based phase 1 protocol\n"
           "         --prec_phase2=<Precision phase 2>: Use different precision for phase 2 of the protocol\n"
           "         --width_phase1=<32|64>, --width_phase2=<32|64>: bit widths (default 64)\n"
-          "         --table_ring[=slots]: parties 1 and 2 share one node; garbled tables stay in HBM\n"
+          "         --table_ring[=slots]: parties 1 and 2 share one node; garbled tables stay in HBM (a byte ring of the largest\n"
+          "                  launch plus slack; =slots: that many slots of the largest launch instead)\n"
           "         --table_lanes=<K>: garbled tables through the network over K extra TCP connections\n"
           "         --ti_ring: (TI mode) all parties on this node: the vectors of the multiplication protocol stay in HBM\n"
           "         --ot_ring: --use_ot with all data providers on this node: the OT extension's messages stay in HBM\n"
@@ -82,6 +162,8 @@ int main(int argc, char **argv) {
     int party = (int)strtol(argv[3], &end, 10);
     check(!errno, "strtol: %s", strerror(errno));
     check(!*end, "Party must be a number");
+    { char tag_[16]; snprintf(tag_, sizeof tag_, "p%d", party); lgc_trace_set_tag(tag_); }
+    lgc_trace_mark("main entered");
     char *algorithm = argv[4];
     check(!strcmp(algorithm, "cholesky") || !strcmp(algorithm, "ldlt") || !strcmp(algorithm, "cgd"),
           "Algorithm must be cholesky, ldlt, or cgd.");
@@ -125,7 +207,7 @@ int main(int argc, char **argv) {
             for (int k = 0; lgc_gate_hash_name(k); k++) if (!strcmp(argv[i] + 12, lgc_gate_hash_name(k))) kind = k;
             check(kind >= 0 && lgc_set_gate_hash(kind) == LGC_OK, "--gate_hash wants aes128 or chaskey12");
         }
-        else if (!strcmp(argv[i], "--table_ring")) ring_slots = 4;
+        else if (!strcmp(argv[i], "--table_ring")) ring_slots = TABLE_RING_BYTES;
         else if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) {}
         else if (sscanf(argv[i], "--table_lanes=%i", &table_lanes) == 1) protocol_set_table_lanes(table_lanes);
         else if (sscanf(argv[i], "--width_phase1=%i", &w1) == 1) {}
@@ -146,15 +228,24 @@ int main(int argc, char **argv) {
         if (party <= 2) device = devices[0];
     }
 
+    /* HIP runtime + device context (60-150 ms with four or five processes starting at once): on a thread, beside the
+     * configuration file, the socket mesh and a data provider's parsing of its columns */
+    static int warm_device;
+    pthread_t warm_th;
+    warm_device = device;
+    int warm_started = pthread_create(&warm_th, NULL, warm_main, &warm_device) == 0;
+    if (warm_started) pthread_detach(warm_th);
+
     status = config_new(&c, argv[1]);
     check(!status, "Could not read config");
     c->party = party;
     check(party >= 1 && party <= c->num_parties, "Party must be in 1..%d", c->num_parties);
 
+    lgc_trace_mark("configuration read");
     double time = wall_clock();
     /* LINREG_TRACE=1: wall-clock marks on stderr (where an end-to-end run of a small configuration spends its time) */
-    const int tracing = getenv("LINREG_TRACE") != NULL;
-#define TRACE(what) do { if (tracing) fprintf(stderr, "[party %d] %8.3f ms  %s\n", party, (wall_clock() - time) * 1e3, what); } while (0)
+    /* (LGCT lines on the system-wide monotonic clock, shared with the library's own marks: lgc_trace_mark) */
+#define TRACE(what) lgc_trace_mark(what)
     if (party == 2) printf("{\"n\":\"%zd\", \"d\":\"%zd\" \"p\":\"%d\"}\n", c->n, c->d, c->num_parties - 1);
 
     status = node_new(&self, party, c->num_parties, c->endpoint);
@@ -175,33 +266,17 @@ int main(int argc, char **argv) {
     /* table bytes per launch: socket mode moves them through host buffers; ring mode keeps them
      * in HBM (CSP and Evaluator on one node), so launches can be as large as the fused solver's */
     const size_t kTableChunk = ring_slots > 0 ? (size_t)16 << 30 : (size_t)64 << 20;
-    /* the phase-2 object(s) of party 1 / 2: one, or with --devices one block of the sweep per entry (same seed: one set of
-     * input labels, one label OT per data provider; block k starts at circuit lo_k, which keeps its gate ids disjoint) */
-#define CREATE_PARTY(role, seedp) do {                                                                                          \
-        if (n_devices) {                                                                                                      \
-            for (int k_ = 0; k_ < n_devices; k_++) {                                                                          \
-                size_t lo_, hi_;                                                                                              \
-                block_range(n_lambdas, (size_t)n_devices, (size_t)k_, &lo_, &hi_);                                            \
-                LGC(lgc_party_create_sweep_at(&blocks[k_], devices[k_], &sys, role, seedp, kTableChunk, hi_ - lo_, lambdas + lo_, lo_)); \
-            }                                                                                                                 \
-            party_obj = blocks[0];                                                                                            \
-        } else if (n_lambdas) LGC(lgc_party_create_sweep(&party_obj, device, &sys, role, seedp, kTableChunk, n_lambdas, lambdas)); \
-        else LGC(lgc_party_create(&party_obj, device, &sys, role, seedp, kTableChunk));                                       \
-        if (role == LGC_ROLE_GARBLER && ring_slots > 0) {        /* the ring(s) now, not on the evaluator's clock */          \
-            if (n_devices) { for (int k_ = 0; k_ < n_devices; k_++) check(!tables_ring_prepare(blocks[k_], ring_slots), "could not create table ring %d", k_); } \
-            else check(!tables_ring_prepare(party_obj, ring_slots), "could not create the table ring");                       \
-        }                                                                                                                     \
-    } while (0)
+    cj.sys = sys; cj.device = device; cj.n_devices = n_devices; cj.devices = devices; cj.ring_slots = ring_slots;
+    cj.table_chunk = kTableChunk; cj.n_lambdas = n_lambdas; cj.lambdas = lambdas; cj.blocks = blocks;
+    cj.role = party == 1 ? LGC_ROLE_GARBLER : LGC_ROLE_EVALUATOR;
 
     if (party == 1) {
+        /* the garbler of phase 2 is built while this process is the trusted initializer (TI mode) or idle (OT mode) */
+        check(!pthread_create(&cj.th, NULL, create_main, &cj), "could not start the garbler's creation thread");
+        cj.started = 1;
         if (!use_ot) {
             status = run_trusted_initializer(self, c, w1, device);
             check(!status, "Error while running trusted initializer");
-        } else {                                                     /* OT mode: the CSP is idle in phase 1 as well */
-            uint8_t seed[16];
-            check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
-            CREATE_PARTY(LGC_ROLE_GARBLER, seed);
-            TRACE("garbler created");
         }
     } else if (party > 2) {
         status = run_party(self, c, precision, precision_phase2 != -1 ? precision_phase2 : precision, w1, w2, use_ot, device,
@@ -210,8 +285,9 @@ int main(int argc, char **argv) {
     } else {
         /* The Evaluator has no part in phase 1: it brings up its GPU context, program and buffers while the data
          * providers work, instead of after the barrier with the CSP waiting for it (0.3 s of a 0.9 s config-3 run). */
-        CREATE_PARTY(LGC_ROLE_EVALUATOR, NULL);
-        TRACE("evaluator created");
+        create_main(&cj);
+        check(!cj.rc, "%s", cj.err);
+        party_obj = cj.party_obj;
     }
     TRACE("phase 1 done");
     check(!net_barrier(self), "Error while waiting for other peers to finish");
@@ -221,42 +297,27 @@ int main(int argc, char **argv) {
     /* ---------------------------------------------------------------------------- phase 2 */
     if (precision_phase2 != -1) precision = precision_phase2;
     if (party == 1) {                                                /* CSP: garbler */
-        if (!party_obj) {                                            /* TI mode: this process was the initializer until now */
-            uint8_t seed[16];
-            check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
-            CREATE_PARTY(LGC_ROLE_GARBLER, seed);
-            TRACE("garbler created");
-        }
-        size_t bits = lgc_party_input_bits(party_obj);
-        uint8_t *m0 = lgc_host_alloc(bits * 16), *m1 = lgc_host_alloc(bits * 16), *u = lgc_host_alloc(lgc_ot_u_bytes(bits)),
-                *e = lgc_host_alloc(bits * 32);
-        check(m0 && m1 && u && e, "%s", lgc_last_error());
-        /* the base OTs (128 P-256 transfers per data provider, host work on both sides) run for all providers at once: each
-         * uses its own connection and its own OpenSSL objects */
-        base_ot_job *jobs = calloc((size_t)P, sizeof *jobs);
+        pthread_join(cj.th, NULL);
+        cj.started = 0;
+        check(!cj.rc, "%s", cj.err);
+        party_obj = cj.party_obj;
+        input_ot_job *jobs = calloc((size_t)P, sizeof *jobs);
         check(jobs != NULL, "out of memory");
-        for (int k = 3; k <= c->num_parties; k++) {
-            jobs[k - 3].self = self; jobs[k - 3].peer = k;
-            check(!pthread_create(&jobs[k - 3].th, NULL, base_ot_main, &jobs[k - 3]), "could not start a base-OT thread");
+        int started_ot = 0, bad_ot = 0;
+        for (int k = 3; k <= c->num_parties; k++) {                  /* data providers: share k - 3 (linear.oc:31) */
+            input_ot_job *j = &jobs[k - 3];
+            j->self = self; j->peer = k; j->device = device; j->po = party_obj; j->share = (size_t)(k - 3);
+            j->bits = lgc_party_input_bits(party_obj);
+            if (pthread_create(&j->th, NULL, input_ot_main, j)) break;
+            started_ot++;
         }
-        for (int k = 3; k <= c->num_parties; k++) {
-            pthread_join(jobs[k - 3].th, NULL);
-            check(!jobs[k - 3].rc, "base OT with party %d failed", k);
+        for (int k = 0; k < started_ot; k++) {
+            pthread_join(jobs[k].th, NULL);
+            if (jobs[k].rc) { fprintf(stderr, "%s\n", jobs[k].err); bad_ot = 1; }
         }
-        TRACE("base OTs done");
-        for (int k = 3; k <= c->num_parties; k++) {                  /* data providers in order (linear.oc:31) */
-            lgc_ot_sender *S = 0;
-            LGC(lgc_ot_sender_create(&S, device, jobs[k - 3].delta, jobs[k - 3].seeds));
-            LGC(lgc_party_input_pairs(party_obj, (size_t)(k - 3), m0, m1));
-            check(!recv_blob(self, k, u, lgc_ot_u_bytes(bits)), "OT: could not receive u from party %d", k);
-            LGC(lgc_ot_labels_send(S, m0, m1, bits, u, e));
-            check(!send_blob(self, k, e, bits * 32), "OT: could not send to party %d", k);
-            lgc_ot_sender_destroy(S);
-        }
-        memset(m0, 0, bits * 16); memset(m1, 0, bits * 16);              /* both labels of every input bit: their XOR is R */
-        lgc_host_free(m0); lgc_host_free(m1); lgc_host_free(u); lgc_host_free(e);
-        memset(jobs, 0, (size_t)P * sizeof *jobs);                        /* base-OT delta and seeds */
+        bad_ot |= started_ot != P;
         free(jobs);
+        check(!bad_ot, "input sharing with the data providers failed");
         TRACE("input labels sent");
         if (n_devices) {
             /* one table link (hipIpc ring + token connection) and one thread per block.  Block 0 garbles the shared prefix
@@ -413,6 +474,7 @@ int main(int argc, char **argv) {
         printf("party %d connecting to CSP and Evaluator\n", party);
         uint8_t s0[128][16], s1[128][16];
         check(!baseot_ext_receiver(self, 1, s0, s1), "base OT with the CSP failed");
+        TRACE("base OT done");
         printf("party %d connected successfully to CSP and Evaluator\n", party);
         lgc_ot_receiver *R = 0;
         LGC(lgc_ot_receiver_create(&R, device, s0, s1));
@@ -427,20 +489,26 @@ int main(int argc, char **argv) {
         check(!recv_blob(self, 1, e, bits * 32), "OT: could not receive from the CSP");
         LGC(lgc_ot_labels_recv_finish(R, e, labels));
         check(!send_blob(self, 2, labels, bits * 16), "could not forward labels to the Evaluator");   /* input.c:46 */
+        TRACE("labels forwarded to the Evaluator");
         lgc_ot_receiver_destroy(R);
         free(sel); free(u); free(e); free(labels);
     }
 
 done:
+    TRACE("protocol done");
     for (int k = 1; k < n_devices; k++) if (blocks[k]) lgc_party_destroy(blocks[k]);
-    if (party_obj) lgc_party_destroy(party_obj);
+    if (party_obj) lgc_party_destroy(party_obj);           /* (wipes label material before its memory is released) */
     node_destroy(&self);
     config_destroy(&c);
     free(share_A);
     free(share_b);
     free(lambdas);
+    TRACE("exit");
+    /* (leaving through _exit() to skip the HIP runtime's exit handlers -- 70-80 ms per process -- was measured and is WORSE:
+     * the kernel driver then tears the process's queues and mappings down by itself, 250 ms for config 2) */
     return 0;
 error:
+    if (cj.started) { pthread_join(cj.th, NULL); if (!party_obj) party_obj = cj.party_obj; }
     for (int k = 1; k < n_devices; k++) if (blocks[k]) lgc_party_destroy(blocks[k]);
     if (party_obj) lgc_party_destroy(party_obj);
     config_destroy(&c);

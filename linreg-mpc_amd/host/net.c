@@ -174,7 +174,7 @@ void node_destroy(node **nn) {
  * and accepts a lane only from the peer's address and only with the cookie; accept and the cookie read time out. */
 typedef struct { uint32_t k, port; uint8_t cookie[16]; } lane_offer;
 typedef struct { uint32_t lane; uint8_t cookie[16]; } lane_hello;
-enum { kLaneTimeoutSec = 30 };
+enum { kLaneTimeoutSec = 30, kHelloTimeoutSec = 2 };
 static void set_timeouts(int s, int sec) {
     struct timeval tv = {sec, 0};
     (void)setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
@@ -204,15 +204,22 @@ int net_lanes_offer(node *n, int peer, int k, int *fds) {
     if (net_send(n, peer, &o, sizeof o)) { close(ls); return -1; }
     net_flush(n, peer);
     for (int i = 0; i < k; i++) fds[i] = -1;
-    set_timeouts(ls, kLaneTimeoutSec);                   /* accept() honours SO_RCVTIMEO */
+    /* ONE deadline for the whole handshake, and a short one per connection for its hello: a host that can reach the port
+     * from the peer's address (same node, NAT) and sends nothing costs kHelloTimeoutSec of it, not 30 s per connection */
+    struct timespec t0, tn;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     int got = 0, strays = 0;
     while (got < k) {
+        clock_gettime(CLOCK_MONOTONIC, &tn);
+        long left = kLaneTimeoutSec - (long)(tn.tv_sec - t0.tv_sec);
+        if (left <= 0) break;
+        set_timeouts(ls, (int)left);                     /* accept() honours SO_RCVTIMEO */
         struct sockaddr_in ca;
         socklen_t cl = sizeof ca;
         int s = accept(ls, (struct sockaddr *)&ca, &cl);
         if (s < 0) break;                                /* timed out or failed */
         lane_hello h;
-        set_timeouts(s, kLaneTimeoutSec);
+        set_timeouts(s, left < kHelloTimeoutSec ? (int)left : kHelloTimeoutSec);
         unsigned char diff = 0;
         int ok = ca.sin_family == AF_INET && ca.sin_addr.s_addr == pa.sin_addr.s_addr && !io_all(s, &h, sizeof h, 0);
         if (ok) { for (size_t b = 0; b < sizeof o.cookie; b++) diff |= (unsigned char)(h.cookie[b] ^ o.cookie[b]); }

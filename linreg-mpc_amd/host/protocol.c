@@ -318,13 +318,25 @@ static int link_io(table_link *l, void *buf, size_t n, int wr) {
 enum { kMaxPrepared = 16 };
 static struct { lgc_party *po; ring_hello h; } g_prepared[kMaxPrepared];
 static pthread_mutex_t g_prepared_mu = PTHREAD_MUTEX_INITIALIZER;
+static int ring_create(lgc_party *po, int ring_slots, ring_hello *h) {
+    size_t sb = 0;
+    if (ring_slots == TABLE_RING_BYTES) {
+        TCHK(lgc_party_ring_create_bytes(po, 0, h->handle, &sb));
+        h->nslots = 0;
+    } else {
+        TCHK(lgc_party_ring_create(po, ring_slots, h->handle, &sb));
+        h->nslots = (uint64_t)ring_slots;
+    }
+    h->slot_bytes = sb;
+    return 0;
+}
 int tables_ring_prepare(lgc_party *po, int ring_slots) {
     if (ring_slots <= 0) return 0;
     ring_hello h;
     size_t sb = 0;
     memset(&h, 0, sizeof h);
-    TCHK(lgc_party_ring_create(po, ring_slots, h.handle, &sb));
-    h.nslots = (uint64_t)ring_slots; h.slot_bytes = sb;
+    if (ring_create(po, ring_slots, &h)) return 1;
+    (void)sb;
     pthread_mutex_lock(&g_prepared_mu);
     int ok = 0;
     for (int i = 0; i < kMaxPrepared && !ok; i++) if (!g_prepared[i].po) { g_prepared[i].po = po; g_prepared[i].h = h; ok = 1; }
@@ -344,15 +356,12 @@ int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, 
     ring_hello h;
     memset(&h, 0, sizeof h);
     if (sending) {
-        if (!take_prepared(po, &h)) {
-            size_t sb = 0;
-            TCHK(lgc_party_ring_create(po, ring_slots, h.handle, &sb));
-            h.nslots = (uint64_t)ring_slots; h.slot_bytes = sb;
-        }
+        if (!take_prepared(po, &h) && ring_create(po, ring_slots, &h)) return 1;
         if (link_io(l, &h, sizeof h, 1)) return 1;
     } else {
         if (link_io(l, &h, sizeof h, 0)) return 1;
-        TCHK(lgc_party_ring_open(po, h.handle, (int)h.nslots, (size_t)h.slot_bytes));
+        if (h.nslots == 0) TCHK(lgc_party_ring_open_bytes(po, h.handle, (size_t)h.slot_bytes));
+        else TCHK(lgc_party_ring_open(po, h.handle, (int)h.nslots, (size_t)h.slot_bytes));
     }
     l->nslots = (size_t)h.nslots;
     return 0;
@@ -360,9 +369,25 @@ int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, 
 /* garbler: launches [lo, hi); launch i reuses the slot of launch i - nslots and waits for its ack */
 int table_link_send_range(table_link *l, size_t lo, size_t hi) {
     uint8_t tok = 0;
+    if (l->nslots == 0) {
+        /* byte ring: the evaluator acknowledges every launch; launch i may overwrite its range once the launch
+         * lgc_party_ring_wait_for names has been evaluated (launches before l->start never pass through this link) */
+        for (size_t i = lo; i < hi; i++) {
+            int64_t wf = lgc_party_ring_wait_for(l->po, i);
+            size_t need = wf >= (int64_t)l->start ? (size_t)(wf - (int64_t)l->start) + 1 : 0;
+            while (l->acked < need) { if (link_io(l, &tok, 1, 0)) return 1; l->acked++; }
+            TCHK(lgc_party_garble_ring(l->po, i));
+            if (i == 0) lgc_trace_mark("first table garbled");
+            tok = 1;
+            if (link_io(l, &tok, 1, 1)) return 1;
+        }
+        while (l->acked < hi - l->start) { if (link_io(l, &tok, 1, 0)) return 1; l->acked++; }   /* nothing of this range stays in flight */
+        return 0;
+    }
     for (size_t i = lo; i < hi; i++) {
         if (i - l->start >= l->nslots && link_io(l, &tok, 1, 0)) return 1;      /* slot is free again */
         TCHK(lgc_party_garble_ring(l->po, i));
+        if (i == 0) lgc_trace_mark("first table garbled");
         tok = 1;
         if (link_io(l, &tok, 1, 1)) return 1;
     }
@@ -374,7 +399,7 @@ int table_link_recv_range(table_link *l, size_t lo, size_t hi, void (*after_laun
         if (link_io(l, &tok, 1, 0)) return 1;                                   /* launch i is in its slot */
         TCHK(lgc_party_evaluate_ring(l->po, i));
         if (after_launch) after_launch(i, ctx);
-        if (i + l->nslots < l->end && link_io(l, &tok, 1, 1)) return 1;
+        if ((l->nslots == 0 || i + l->nslots < l->end) && link_io(l, &tok, 1, 1)) return 1;
     }
     return 0;
 }
@@ -414,6 +439,7 @@ int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
         uint8_t *tab = table_pipe_acquire(&tp, i);           /* waits until the workers are through with this slot */
         if (!tab) break;
         if (lgc_party_garble(po, i, tab) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); table_pipe_fail(&tp); break; }
+        if (i == 0) lgc_trace_mark("first table garbled");
         table_pipe_publish(&tp);
     }
     table_pipe_stop(&tp, th);
@@ -1331,8 +1357,10 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
         check(!read_own_columns(c->input, n, d, oc0, oc1, me == last, precision, normalizer, w2, Xq, yq), "Could not read data (dimensions or numbers invalid)");
     }
     if (getenv("LINREG_TIMING")) fprintf(stderr, "party %d: input parsed after %.2fs\n", c->party, wall_clock() - t_start);
+    lgc_trace_mark("own columns parsed and quantised");
     LGC(lgc_p1_create(&p1, device, n, d, w1, precision));
     LGC(lgc_p1_set_data(p1, Xq, yq));
+    lgc_trace_mark("phase-1 data on the device");
     const size_t c0 = (size_t)c->index_owned[me], c1 = me < last ? (size_t)c->index_owned[me + 1] : d;
     /* everything this party can do alone: its own block, incl. the floating-point diagonal */
     {

@@ -41,7 +41,10 @@ int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
 int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chunk,
                 void (*after_launch)(size_t launch, void *ctx), void *ctx);
 /* ring mode in pieces, for several blocks of a sweep side by side (bin/linreg --devices): see protocol.c */
-typedef struct { node *self; int peer, fd; lgc_party *po; size_t start, end, nslots; } table_link;
+/* ring_slots: 0 = no ring (tables through the socket), 1..64 = a ring of that many slots of the largest launch,
+ * TABLE_RING_BYTES = the byte ring (largest launch + slack: lgc_party_ring_create_bytes), what plain --table_ring selects */
+enum { TABLE_RING_BYTES = 65 };
+typedef struct { node *self; int peer, fd; lgc_party *po; size_t start, end, nslots, acked; } table_link;   /* nslots 0: byte ring */
 int tables_ring_prepare(lgc_party *po, int ring_slots);   /* garbler, optional: create the ring before tables_send / table_link_open need it */
 int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, int sending, int ring_slots, size_t start);
 int table_link_send_range(table_link *l, size_t lo, size_t hi);

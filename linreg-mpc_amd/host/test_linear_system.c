@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
     const char *host = "localhost";
     for (int i = 7; i < argc; i++) {
         if (sscanf(argv[i], "--width=%i", &w) == 1) continue;
-        if (!strcmp(argv[i], "--table_ring")) { ring_slots = 4; continue; }
+        if (!strcmp(argv[i], "--table_ring")) { ring_slots = TABLE_RING_BYTES; continue; }
         if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) continue;
         { int lanes = 0; if (sscanf(argv[i], "--table_lanes=%i", &lanes) == 1) { protocol_set_table_lanes(lanes); continue; } }
         if (!strncmp(argv[i], "--gate_hash=", 12)) {       /* aes128 (default, the reference's) | chaskey12; the same on both parties */

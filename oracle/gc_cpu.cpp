@@ -17,6 +17,7 @@
 // built here: gate-level parity with it is "unpinned".
 #include <immintrin.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -484,7 +485,14 @@ static void *base_evaluator(void *v) {
     c->gatesE = g;
     return 0;
 }
+// cpu_g / cpu_e: the logical CPUs the two threads are pinned to (-1: left to the scheduler).  Unpinned, the pair landed on
+// SMT siblings of one core in some runs and on two cores in others: 5.2e7 .. 8.3e7 AND-gates/s on the same CPU model
+// (BENCH_r02 / r03); bench.py picks two distinct physical cores and reports them.
+double gcc_baseline_mac_on(int w, int p, uint32_t nrec, uint32_t chunk, int cpu_g, int cpu_e, uint64_t *and_gates, double *seconds);
 double gcc_baseline_mac(int w, int p, uint32_t nrec, uint32_t chunk, uint64_t *and_gates, double *seconds) {
+    return gcc_baseline_mac_on(w, p, nrec, chunk, -1, -1, and_gates, seconds);
+}
+double gcc_baseline_mac_on(int w, int p, uint32_t nrec, uint32_t chunk, int cpu_g, int cpu_e, uint64_t *and_gates, double *seconds) {
     init();
     BaseCtx c;
     c.w = w; c.p = p;
@@ -517,8 +525,13 @@ double gcc_baseline_mac(int w, int p, uint32_t nrec, uint32_t chunk, uint64_t *a
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     pthread_t tg, te;
-    pthread_create(&tg, 0, base_garbler, &c);
-    pthread_create(&te, 0, base_evaluator, &c);
+    pthread_attr_t ag, ae;
+    pthread_attr_init(&ag); pthread_attr_init(&ae);
+    if (cpu_g >= 0) { cpu_set_t st; CPU_ZERO(&st); CPU_SET(cpu_g, &st); pthread_attr_setaffinity_np(&ag, sizeof st, &st); }
+    if (cpu_e >= 0) { cpu_set_t st; CPU_ZERO(&st); CPU_SET(cpu_e, &st); pthread_attr_setaffinity_np(&ae, sizeof st, &st); }
+    pthread_create(&tg, &ag, base_garbler, &c);
+    pthread_create(&te, &ae, base_evaluator, &c);
+    pthread_attr_destroy(&ag); pthread_attr_destroy(&ae);
     pthread_join(tg, 0);
     pthread_join(te, 0);
     clock_gettime(CLOCK_MONOTONIC, &t1);

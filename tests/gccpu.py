@@ -158,9 +158,11 @@ class GcCpu:
             gates += g
         return decG ^ decE, gates, dict(R=R, wordsG=wordsG, wordsE=wordsE)
 
-    def baseline_mac(self, w, p, nrec, chunk):
+    def baseline_mac(self, w, p, nrec, chunk, cpus=(-1, -1)):
         g, s = C.c_uint64(), C.c_double()
-        rate = self.lib.gcc_baseline_mac(w, p, nrec, chunk, C.byref(g), C.byref(s))
+        self.lib.gcc_baseline_mac_on.restype = C.c_double
+        self.lib.gcc_baseline_mac_on.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        rate = self.lib.gcc_baseline_mac_on(w, p, nrec, chunk, int(cpus[0]), int(cpus[1]), C.byref(g), C.byref(s))
         return rate, g.value, s.value
 
 

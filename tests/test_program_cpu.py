@@ -216,6 +216,7 @@ def test_sweep_program_matches_oracle_per_lambda(lgc, gccpu, oracle, w, p, alg):
     # blocks of a sharded sweep: same records, gate steps offset so that no two circuits of the whole sweep
     # share a gate id (the ranks share the prefix and with it the garbler's offset R)
     per = base.info.total_steps - base.info.prefix_steps
+    stride = 1 << 36                                    # gc_program.h kSweepCircuitStride: the canonical gate-step stride of a circuit
     seen = []
     for first, cnt in ((0, 2), (2, 3)):
         blk = lgc.Program(sysm, lambdas=lams[first:first + cnt], first=first)
@@ -223,7 +224,8 @@ def test_sweep_program_matches_oracle_per_lambda(lgc, gccpu, oracle, w, p, alg):
         npre = blk.info.prefix_launches
         assert [(l["step0"], l["steps"]) for l in L[:npre]] == [(l["step0"], l["steps"]) for l in prog.launches()[:npre]]
         lo = min(l["step0"] for l in L[npre:] if l["steps"]); hi = max(l["step0"] + l["steps"] for l in L[npre:])
-        assert lo == base.info.prefix_steps + first * per and hi == base.info.prefix_steps + (first + cnt) * per
+        blk_per = (blk.info.total_steps - blk.info.prefix_steps) // cnt
+        assert lo == base.info.prefix_steps + first * stride and hi == lo + cnt * blk_per and blk_per <= stride
         seen.append((lo, hi))
         words = np.zeros(blk.info.n_words, dtype=np.uint64)
         words[blk.info.in_base:blk.info.in_base + shares.size] = shares.ravel() & m
@@ -232,7 +234,7 @@ def test_sweep_program_matches_oracle_per_lambda(lgc, gccpu, oracle, w, p, alg):
         # plain_run checks step0 against a running counter from 0: renumber the copy for the check
         recs = recs.copy()
         shift = recs["step0"] >= base.info.prefix_steps
-        recs["step0"][shift] -= np.uint64(first * per)
+        recs["step0"][shift] -= np.uint64(first * stride)
         gccpu.plain_run(recs.view(np.uint8), blk.info.n_records, w, p, words, dec)
         for t in range(cnt):
             exp = oracle_solve(oracle, A, b, d, w, p, alg, iters, lams[first + t], 1)[0]
@@ -241,6 +243,39 @@ def test_sweep_program_matches_oracle_per_lambda(lgc, gccpu, oracle, w, p, alg):
     assert seen[0][1] <= seen[1][0]
     with pytest.raises(RuntimeError):                                       # lambda only enters the DP input path
         lgc.Program(lgc.make_system(d, w, p, alg, iters, 0.0, 2, 0, 0, 0), lambdas=lams)
+
+
+@pytest.mark.parametrize("alg,d,w,p,iters,nl,world", [("cholesky", 200, 64, 56, 0, 5, 2), ("cgd", 100, 32, 28, 15, 9, 2),
+                                                       ("cgd", 100, 64, 56, 15, 64, 7), ("cgd", 12, 64, 56, 3, 7, 3)])
+def test_blocks_of_an_uneven_partition_have_disjoint_gate_steps(lgc, alg, d, w, p, iters, nl, world):
+    """the blocks of one sharded sweep share the garbler's R, so no two of them may use a gate step twice -- also when
+    the partition is uneven and the per-circuit step count therefore differs between blocks (the lowering sizes the
+    dot-product records by the number of merged circuits): every block lies inside the canonical stride range of its
+    circuits (round 3 laid block k at first * ITS OWN per-circuit count and the first two cases overlapped)"""
+    from sweep import partition
+    sysm = lgc.make_system(d, w, p, alg, iters, 0.0, 2, 1, 0, 0)
+    lams = [10.0 ** (-6.0 + 6.0 * k / (nl - 1)) for k in range(nl)]
+    stride, ranges, pers, prefix = 1 << 36, [], set(), None
+    for r in range(world):
+        lo, hi = partition(nl, world, r)
+        blk = lgc.Program(sysm, lambdas=lams[lo:hi], first=lo)
+        L = blk.launches()
+        npre = blk.info.prefix_launches
+        pre = [(l["step0"], l["steps"]) for l in L[:npre]]
+        assert prefix is None or pre == prefix                              # one prefix, garbled once
+        prefix = pre
+        s0 = min(l["step0"] for l in L[npre:] if l["steps"]); s1 = max(l["step0"] + l["steps"] for l in L[npre:])
+        assert s0 == blk.info.prefix_steps + lo * stride and s1 <= blk.info.prefix_steps + hi * stride
+        ranges.append((s0, s1))
+        pers.add((blk.info.total_steps - blk.info.prefix_steps) // (hi - lo))
+        recs = np.frombuffer(blk.records().tobytes(), dtype=REC)
+        body = recs[recs["step0"] >= blk.info.prefix_steps]
+        assert body["step0"].min() >= s0 and body["step0"].max() <= s1      # (records without gates, e.g. reveals, may sit at the end)
+    ranges.sort()
+    assert all(a[1] <= b[0] for a, b in zip(ranges, ranges[1:])), ranges
+    assert ranges[0][0] >= sum(s for _, s in prefix)
+    if world == 2 and d >= 100:
+        assert len(pers) == 2              # the case that matters: block sizes differ AND so do the per-circuit step counts
 
 
 def test_library_exports_and_fails_loudly_without_gpu(lgc):

@@ -83,7 +83,7 @@ static int one(int alg, size_t d, int w, int p, int iters, size_t nshares, int n
         for (int half = 0; half < 2; half++) {
             Program P;
             const size_t first = half ? sweep / 2 : 0, count = half ? sweep - sweep / 2 : sweep;
-            replicate_program(P, P0, count, lam.data() + first, first);
+            if (!replicate_program(P, P0, count, lam.data() + first, first)) { printf("%s: sweep block refused\n", what); bad = 1; }
             if (P.overflow || !P.ranges_ok()) { printf("%s: sweep block reports overflow / ranges\n", what); bad = 1; }
             bad |= check_structure(P, what);
             bad |= run_plain(P, what);
