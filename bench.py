@@ -213,9 +213,20 @@ def phase12_wall(np, name, n, d, starts, alg, iters, extra, device_index, prec=5
     logs = [(open(os.path.join(tmp, "out%d" % k), "w+b"), open(os.path.join(tmp, "err%d" % k), "w+b")) for k in range(1, len(starts) + 3)]
     procs = [subprocess.Popen([exe, path, args[0], str(k)] + args[1:], stdout=logs[k - 1][0], stderr=logs[k - 1][1], env=env)
              for k in range(1, len(starts) + 3)]
-    for q in procs:
-        q.wait(timeout=600)
+    # (a blocking wait per child from a thread: Popen.wait(timeout=...) polls with sleeps of up to 50 ms)
+    import threading
+    waiters = [threading.Thread(target=q.wait, daemon=True) for q in procs]
+    for th in waiters:
+        th.start()
+    deadline = time.time() + 900
+    for th in waiters:
+        th.join(max(0.0, deadline - time.time()))
     wall = time.perf_counter() - t0
+    if any(q.poll() is None for q in procs):
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+        return {"config": name, "error": "timed out"}
     outs = []
     for fo, fe in logs:
         fo.seek(0); fe.seek(0)

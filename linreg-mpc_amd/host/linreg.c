@@ -112,10 +112,15 @@ static void *input_ot_main(void *arg) {
     lgc_trace_mark("base OTs done");
     m0 = lgc_host_alloc(bits * 16); m1 = lgc_host_alloc(bits * 16); u = lgc_host_alloc(lgc_ot_u_bytes(bits)); e = lgc_host_alloc(bits * 32);
     if (!m0 || !m1 || !u || !e) JFAIL("%s", lgc_last_error());
+    lgc_trace_mark("input OT: page-locked buffers");
     if (lgc_ot_sender_create(&S, j->device, delta, seeds) != LGC_OK) JFAIL("%s", lgc_last_error());
+    lgc_trace_mark("input OT: sender session");
     if (lgc_party_input_pairs(j->po, j->share, m0, m1) != LGC_OK) JFAIL("%s", lgc_last_error());
+    lgc_trace_mark("input OT: label pairs exported");
     if (recv_blob(j->self, j->peer, u, lgc_ot_u_bytes(bits))) JFAIL("OT: could not receive u from party %d", j->peer);
+    lgc_trace_mark("input OT: u received");
     if (lgc_ot_labels_send(S, m0, m1, bits, u, e) != LGC_OK) JFAIL("%s", lgc_last_error());
+    lgc_trace_mark("input OT: ciphertexts computed");
     if (send_blob(j->self, j->peer, e, bits * 32)) JFAIL("OT: could not send to party %d", j->peer);
     j->rc = 0;
 out:
@@ -478,6 +483,7 @@ int main(int argc, char **argv) {
         printf("party %d connected successfully to CSP and Evaluator\n", party);
         lgc_ot_receiver *R = 0;
         LGC(lgc_ot_receiver_create(&R, device, s0, s1));
+        TRACE("input OT: receiver session");
         const size_t words = T + d, bits = words * (size_t)w2;
         uint8_t *sel = malloc(bits), *u = malloc(lgc_ot_u_bytes(bits)), *e = malloc(bits * 32), *labels = malloc(bits * 16);
         for (size_t i = 0; i < words; i++) {                         /* sel[i*intsize+j] = (input[i]>>j)&1 (input.c:41) */
@@ -486,7 +492,9 @@ int main(int argc, char **argv) {
         }
         LGC(lgc_ot_labels_recv_start(R, sel, bits, u));
         check(!send_blob(self, 1, u, lgc_ot_u_bytes(bits)), "OT: could not send u to the CSP");
+        TRACE("input OT: u sent");
         check(!recv_blob(self, 1, e, bits * 32), "OT: could not receive from the CSP");
+        TRACE("input OT: ciphertexts received");
         LGC(lgc_ot_labels_recv_finish(R, e, labels));
         check(!send_blob(self, 2, labels, bits * 16), "could not forward labels to the Evaluator");   /* input.c:46 */
         TRACE("labels forwarded to the Evaluator");

@@ -88,7 +88,11 @@ static void tune_socket(int s) {
     }
 }
 static int connect_retry(const char *host, const char *port) {
-    for (;;) {   /* retry every 200 ms like util_loop_connect (src/util.c:26-38) */
+    /* retry like util_loop_connect (src/util.c:26-38), which sleeps 200 ms between attempts: here the pause starts at 2 ms
+     * and doubles up to those 200 ms -- parties started together find each other within milliseconds (a peer that was not
+     * listening yet used to cost 0.2 s of a 0.4 s run) */
+    long pause_ns = 2000000;
+    for (;;) {
         struct addrinfo hints, *res = 0;
         memset(&hints, 0, sizeof hints);
         hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
@@ -102,8 +106,10 @@ static int connect_retry(const char *host, const char *port) {
             if (s >= 0) close(s);
             freeaddrinfo(res);
         }
-        struct timespec ts = {0, 200000000};
+        struct timespec ts = {0, pause_ns};
         nanosleep(&ts, 0);
+        if (pause_ns < 200000000) pause_ns *= 2;
+        if (pause_ns > 200000000) pause_ns = 200000000;
     }
 }
 
