@@ -118,6 +118,54 @@ def pick_two_cores():
         return (-1, -1), "unpinned (%s)" % e
 
 
+def sweep_model(np, sweep, shares, lams, d, make, t_all, st_all):
+    """What ONE GPU can measure about the sharded sweep, and what it predicts for N = 2, 4, 8: the
+    block a rank of an N-GPU run gets (64 / N lambdas, gate ids offset as on that rank) is created, fed the prefix and run
+    here, alone on the chip, exactly as that rank would; the broadcast is priced at one xGMI link.  A MODEL: no second GPU
+    was involved.  What it cannot see: RCCL's own latencies, eight processes creating rings at once, clock differences."""
+    import time, torch
+    nl = len(lams)
+    link_bytes_per_s = 153e9            # one xGMI link (MI355X_MICROARCH.md); a broadcast root pushes the same bytes to 7 peers on 7 links
+    rows = {}
+    for n in (2, 4, 8):
+        if nl % n:
+            continue
+        blk = nl // n
+        first = nl - blk                 # the LAST block: it imports the prefix (ranks > 0 do), gate ids offset the furthest
+        stt = {}
+        # untimed pass first: it parks a ring of this block's size, as the warm-up of a real N-GPU run does on every rank
+        for timed in (False, True):
+            seed = os.urandom(16)
+            t0 = time.perf_counter()
+            src = make(lams[:blk], 0, seed)          # "rank 0": garbles and exports the prefix
+            src.set_shares(shares)
+            nbytes = src.prefix_bytes()
+            buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            tg0 = time.perf_counter()
+            src.prefix_garble(); src.prefix_export(buf.data_ptr()); torch.cuda.synchronize()
+            t_prefix = time.perf_counter() - tg0
+            src.close()
+            tc0 = time.perf_counter()
+            blkS = make(lams[first:first + blk], first, seed)
+            t_create = time.perf_counter() - tc0
+            blkS.prefix_import(buf.data_ptr())
+            tb0 = time.perf_counter()
+            blkS.run(); beta = blkS.beta(); torch.cuda.synchronize()
+            t_block = time.perf_counter() - tb0
+            blkS.close()
+            del buf
+        t_bcast = nbytes / link_bytes_per_s
+        t_gather = 50e-6 + nl * d * 8 / link_bytes_per_s
+        t_n = t_create + t_prefix + t_bcast + t_block + t_gather
+        rows[str(n)] = {"block_lambdas": blk, "create_s": t_create, "prefix_garble_export_s": t_prefix, "prefix_bytes": nbytes,
+                        "broadcast_s_at_153GBps": t_bcast, "block_s": t_block, "gather_s_assumed": t_gather,
+                        "predicted_seconds": t_n, "predicted_speedup": t_all / t_n, "predicted_efficiency": t_all / t_n / n}
+    return {"modelled": True, "measured_on": "one GPU: the last block of an N-GPU partition, alone on the chip, prefix imported as on a rank > 0",
+            "n1_seconds": t_all, "n1_create_s": st_all.get("create_s"), "n1_block_s": st_all.get("block_s"), "by_n_gpus": rows,
+            "assumptions": "broadcast = prefix bytes / 153 GB/s (one xGMI link per peer, links in parallel); gather = 50 us + bytes / link; "
+                           "ring of the block already parked (the warm-up of a real run does that); no allowance for RCCL call latency"}
+
+
 def _free_ports(k):
     import socket
     socks = [socket.socket() for _ in range(k)]
@@ -321,6 +369,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the phase-1+2 bin/linreg runs and the two-process ring run")
     ap.add_argument("--child", action="store_true", help="(internal) one bare solve, for the PMC passes")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 64-lambda sweep (BASELINE config 5)")
+    ap.add_argument("--no-sweep-model", action="store_true", help="skip the modelled 2/4/8-GPU figures of the sweep (three more block runs)")
     ap.add_argument("--no-c4", action="store_true", help="skip the end-to-end run of config 4 (n = 50 000, d = 500: ~10 s to write its input, ~1 min to check it)")
     ap.add_argument("--alt-hash", action="store_true", help="also time the headline solve and the sweep over gate hash 1 (Chaskey-12 "
                     "permutation; an option of the library, never the headline): off by default")
@@ -514,6 +563,9 @@ def main():
         if w == 32:
             sshares &= np.uint64(0xffffffff)
         lams = sweep.c5_lambdas(nl)
+        if os.environ.get("LGC_RING_SLACK_MB"):
+            # ranks sharing one GPU (the 8-rank rehearsal of tests/test_gpu_multirank.py): less run-ahead room per ring
+            lgc.set_table_ring_slack(int(os.environ["LGC_RING_SLACK_MB"]) << 20)
         make = sweep.gpu_block_solver_factory(sd, w, p, "cgd", sit, 2, device_index)
         # warm-up: at N > 1 with the blocks of the timed run, so that every rank's table ring is already parked at full size
         # (a fresh hipMalloc of a block's 42 GB ring is 0.27 s against 1.07 s of kernels); at N = 1 two circuits do
@@ -561,6 +613,8 @@ def main():
                          "collectives": ("broadcast(seed, garbled prefix) + all_gather(results) over %s" % backend) if world > 1 else None,
                          "sharding": "contiguous blocks of %d lambdas per rank; prefix (input labels + share-summation tables) garbled once on rank 0" % ((nl + world - 1) // world)}
             sweep_check = (stot, sT, sd, sit, lams, sres, nl)      # compared with the oracle in the cpu_baseline leg
+            if world == 1 and not args.no_sweep_model and nl >= 16:
+                sweep_res["model"] = sweep_model(np, sweep, sshares, lams, sd, make, sdt, sst)
 
     lgc.release_cached_memory()          # the separate-process runs below bring their own rings
     out = None

@@ -391,6 +391,10 @@ void lgc_set_split_kernels(int garbler, int evaluator);
  * plain 64 x 64 array everywhere.  Same integers either way.  Process-wide, takes effect for programs built
  * afterwards; the two roles of one solve must agree (as on every other parameter of the program). */
 void lgc_set_karatsuba(int on);
+/* Co-located solvers created from now on: room in the table ring beyond the largest launch (what the garbler may run ahead of
+ * the evaluator by), default 8 GiB, at most the largest launch again; 0 restores the default.  A block of a sharded sweep
+ * needs little (its launches are few and large): eight ranks rehearsing an 8-GPU sweep on one MI355X set 512 MiB. */
+void lgc_set_table_ring_slack(size_t bytes);
 
 /* The gate hash of the half-gates scheme, H(x, t) = pi(sigma(x) ^ t) ^ sigma(x) ^ t (this library's counterpart of the
  * gate hash inside Obliv-C's Yao runtime, reached from execYaoProtocol, src/cmd/linreg.c:177):

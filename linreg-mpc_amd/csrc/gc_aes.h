@@ -363,4 +363,16 @@ GC_HD Lbl eval_and(const T &tab, const uint32_t *rk, Lbl a, Lbl b, uint64_t gid,
     return lxor(WG, WE);
 }
 
+// two independent gate steps of the evaluator at once: four hashes interleaved in one wave instead of two and two
+template <class T>
+GC_HD void eval_and2(const T &tab, const uint32_t *rk, Lbl a1, Lbl b1, uint64_t gid1, Lbl TG1, Lbl TE1, Lbl a2, Lbl b2, uint64_t gid2,
+                     Lbl TG2, Lbl TE2, Lbl &c1, Lbl &c2, const uint32_t *rk24 = 0) {
+    Lbl in[4] = {a1, b1, a2, b2};
+    uint64_t tw[4] = {2 * gid1, 2 * gid1 + 1, 2 * gid2, 2 * gid2 + 1};
+    Lbl h[4];
+    hash_n<4, T>(tab, rk, in, tw, h, rk24);
+    c1 = lxor(lxor(h[0], lmask(TG1, a1.x & 1u)), lxor(h[1], lmask(lxor(TE1, a1), b1.x & 1u)));
+    c2 = lxor(lxor(h[2], lmask(TG2, a2.x & 1u)), lxor(h[3], lmask(lxor(TE2, a2), b2.x & 1u)));
+}
+
 }  // namespace gc

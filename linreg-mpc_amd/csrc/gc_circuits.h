@@ -283,6 +283,29 @@ struct Circ {
     static GC_HD void umul32x2(B &be, W a, W b, W &L, W &S, W &C) {
         const uint64_t all = ~0ull;
         S = be.zero(); L = be.zero(); C = be.zero();
+        if (B::kPairSteps) {
+            // the partial product of row r + 1 does not depend on row r: it issues with the carry-save AND of row r (same
+            // gate-step numbers as the loop below: pp0, pp1, csa1, pp2, csa2, ...)
+            W pp = be.AND(a, be.bcast2(b, 0), all);
+            for (int r = 0; r < 32; r++) {
+                W ppn = be.zero();
+                if (r == 0) {
+                    S = pp;
+                    ppn = be.AND(a, be.bcast2(b, 1), all);
+                } else {
+                    W t;
+                    if (r + 1 < 32) be.AND2(be.XOR(S, pp), be.XOR(C, pp), all, a, be.bcast2(b, r + 1), all, t, ppn);
+                    else t = be.AND(be.XOR(S, pp), be.XOR(C, pp), all);
+                    W Sn = be.XOR(be.XOR(S, C), pp);
+                    C = be.XOR(t, pp);
+                    S = Sn;
+                }
+                L = be.sel(m2(1ull << r), be.bcast2(S, 0), L);
+                S = shr2(be, S, 1);
+                pp = ppn;
+            }
+            return;
+        }
         for (int r = 0; r < 32; r++) {
             W pp = be.AND(a, be.bcast2(b, r), all);
             if (r == 0) {

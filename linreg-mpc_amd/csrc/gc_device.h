@@ -251,7 +251,13 @@ template <bool GARBLER, int MODE, class TAB = LdsTab, bool CRIT = false>
 struct GpuBackend {
     typedef Lbl W;
     // latency-bound kernels issue independent gate steps of the multiplier as dual steps (gc_circuits.h)
-    static const bool kPairSteps = (MODE == MODE_QUAD);
+    // ... and (GC_EVAL_PAIR) the evaluator's MAC kernels: a wave that evaluates has only two hashes per gate step to interleave,
+    // against the garbler's four; with the independent steps of the multiplier paired it has four as well
+#ifndef GC_EVAL_PAIR
+#define GC_EVAL_PAIR 0
+#endif
+    static const bool kEvalPair = (MODE == MODE_MAC && !GARBLER && GC_EVAL_PAIR != 0);
+    static const bool kPairSteps = (MODE == MODE_QUAD) || kEvalPair;
     int wave;            // MODE_QUAD: wave index inside the workgroup (wave-uniform)
     Lbl *xch;            // MODE_QUAD: LDS exchange area, 2 buffers x 512 labels (16 KiB)
     int xsel;            // MODE_QUAD: buffer used by the next step (adjacent steps alternate)
@@ -333,6 +339,21 @@ struct GpuBackend {
         return and_quad(lt, R, a, b, gid, slot, on, wave, xch + xsel * 512, lane);
     }
     __device__ __forceinline__ void AND2(W a1, W b1, uint64_t act1, W a2, W b2, uint64_t act2, W &c1, W &c2) {
+        if (kEvalPair) {
+            const bool on1 = bit(act1), on2 = bit(act2);
+            const uint64_t gid = step * 64 + (uint64_t)lane;
+            Lbl *slot = tab + (step - launch_step0) * 128 + lane;
+            step += 2;
+            c1 = lzero(); c2 = lzero();
+            if (on1 || on2) {
+                Lbl TG1 = ld_lbl_global(slot), TE1 = ld_lbl_global(slot + 64), TG2 = ld_lbl_global(slot + 128), TE2 = ld_lbl_global(slot + 192);
+                Lbl r1, r2;
+                eval_and2(lt, c_aes.rk, a1, b1, gid, TG1, TE1, a2, b2, gid + 64, TG2, TE2, r1, r2, c_aes.rk24);
+                c1 = lmask(r1, on1 ? 1u : 0u);
+                c2 = lmask(r2, on2 ? 1u : 0u);
+            }
+            return;
+        }
         if (MODE != MODE_QUAD) {
             c1 = AND(a1, b1, act1);
             c2 = AND(a2, b2, act2);

@@ -866,6 +866,10 @@ extern "C" int lgc_reference_gate_count(int algorithm, int width, size_t d, int 
 }
 
 extern "C" void lgc_set_karatsuba(int on) { program_karatsuba() = on != 0; }
+extern "C" void lgc_set_table_ring_slack(size_t bytes) {
+    ring_slack_bytes() = bytes ? ((bytes + 4095) & ~(size_t)4095) : kRingSlackBytes;
+    ring_cache().release(-1);                 // a parked ring was sized with the old slack
+}
 extern "C" int lgc_set_gate_hash(int kind) {
     if (kind < 0 || kind >= GATE_HASH_KINDS) return lgc_fail(LGC_EINVAL, "gate hash %d: 0 (fixed-key AES-128) or 1 (Chaskey-12 permutation)", kind);
     program_gate_hash() = kind;

@@ -32,6 +32,8 @@ static const uint64_t kDefaultCapSteps = 1ull << 25;
 // of a sweep block (32 + 8 GiB) fits the one a d = 500 solver leaves parked (56 + 8 GiB) and need not be allocated afresh
 static const uint64_t kSweepCapSteps = 1ull << 24;
 static const size_t kRingSlackBytes = (size_t)8 << 30;
+// ... adjustable (lgc_set_table_ring_slack): eight ranks rehearsing an 8-GPU sweep on ONE GPU must fit its HBM together
+inline size_t &ring_slack_bytes() { static size_t v = kRingSlackBytes; return v; }
 
 struct Launch {
     uint32_t first_rec, nrec;   // slice of Program::recs
@@ -847,7 +849,7 @@ inline size_t plan_table_ring(const Program &P, size_t ring_bytes, std::vector<s
     const size_t align = 4096, nl = P.launches.size();
     const size_t tbytes = (size_t)P.max_launch_steps * 2048;
     const size_t min_ring = (tbytes + align - 1) / align * align;
-    if (ring_bytes == 0) ring_bytes = min_ring + (min_ring < kRingSlackBytes ? min_ring : kRingSlackBytes) + align;
+    if (ring_bytes == 0) ring_bytes = min_ring + (min_ring < ring_slack_bytes() ? min_ring : ring_slack_bytes()) + align;
     if (ring_bytes < min_ring) ring_bytes = min_ring;
     off.resize(nl);
     wait.assign(nl, -1);

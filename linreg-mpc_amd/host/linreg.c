@@ -15,6 +15,7 @@
 #include <openssl/crypto.h>
 #include <openssl/rand.h>
 #include <pthread.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -27,6 +28,7 @@
 typedef struct { size_t n, next; const uint32_t *launch; double *time; double t0; } iter_marks;
 static void note_launch(size_t i, void *ctx) {
     iter_marks *m = ctx;
+    if (i == 0) host_trace_mark("first table evaluated");
     while (m->next < m->n && m->launch[m->next] == i) m->time[m->next++] = wall_clock() - m->t0;
 }
 
@@ -250,7 +252,7 @@ int main(int argc, char **argv) {
     double time = wall_clock();
     /* LINREG_TRACE=1: wall-clock marks on stderr (where an end-to-end run of a small configuration spends its time) */
     /* (LGCT lines on the system-wide monotonic clock, shared with the library's own marks: lgc_trace_mark) */
-#define TRACE(what) lgc_trace_mark(what)
+#define TRACE(what) host_trace_mark(what)
     if (party == 2) printf("{\"n\":\"%zd\", \"d\":\"%zd\" \"p\":\"%d\"}\n", c->n, c->d, c->num_parties - 1);
 
     status = node_new(&self, party, c->num_parties, c->endpoint);

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <openssl/rand.h>
 #include <pthread.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -151,6 +152,16 @@ int recv_blob(node *self, int from, void *buf, uint64_t len) {
 
 /* ---------------------------------------------------------------- phase 2: table stream */
 #define TCHK(x) do { if ((x) != 0) { fprintf(stderr, "%s: %s\n", #x, lgc_last_error()); return 1; } } while (0)
+/* a trace mark of the host (LINREG_TRACE); in bin/linreg_testhooks also the place where LINREG_DIE_AT=<mark> makes this
+ * party kill itself (tests/test_host.py: a party lost at a known point of the protocol) */
+void host_trace_mark(const char *what) {
+    lgc_trace_mark(what);
+#ifdef LINREG_TEST_HOOKS
+    const char *die = getenv("LINREG_DIE_AT");
+    if (die && !strcmp(die, what)) raise(SIGKILL);
+#endif
+}
+
 typedef struct { uint8_t handle[64]; uint64_t nslots, slot_bytes; } ring_hello;
 
 /* Two-stage pipeline between the GPU and the socket of the table stream: kTableSlots page-locked buffers of
@@ -377,7 +388,7 @@ int table_link_send_range(table_link *l, size_t lo, size_t hi) {
             size_t need = wf >= (int64_t)l->start ? (size_t)(wf - (int64_t)l->start) + 1 : 0;
             while (l->acked < need) { if (link_io(l, &tok, 1, 0)) return 1; l->acked++; }
             TCHK(lgc_party_garble_ring(l->po, i));
-            if (i == 0) lgc_trace_mark("first table garbled");
+            if (i == 0) host_trace_mark("first table garbled");
             tok = 1;
             if (link_io(l, &tok, 1, 1)) return 1;
         }
@@ -387,7 +398,7 @@ int table_link_send_range(table_link *l, size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; i++) {
         if (i - l->start >= l->nslots && link_io(l, &tok, 1, 0)) return 1;      /* slot is free again */
         TCHK(lgc_party_garble_ring(l->po, i));
-        if (i == 0) lgc_trace_mark("first table garbled");
+        if (i == 0) host_trace_mark("first table garbled");
         tok = 1;
         if (link_io(l, &tok, 1, 1)) return 1;
     }
@@ -439,7 +450,7 @@ int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
         uint8_t *tab = table_pipe_acquire(&tp, i);           /* waits until the workers are through with this slot */
         if (!tab) break;
         if (lgc_party_garble(po, i, tab) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); table_pipe_fail(&tp); break; }
-        if (i == 0) lgc_trace_mark("first table garbled");
+        if (i == 0) host_trace_mark("first table garbled");
         table_pipe_publish(&tp);
     }
     table_pipe_stop(&tp, th);

@@ -43,6 +43,7 @@ int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
 /* ring mode in pieces, for several blocks of a sweep side by side (bin/linreg --devices): see protocol.c */
 /* ring_slots: 0 = no ring (tables through the socket), 1..64 = a ring of that many slots of the largest launch,
  * TABLE_RING_BYTES = the byte ring (largest launch + slack: lgc_party_ring_create_bytes), what plain --table_ring selects */
+void host_trace_mark(const char *what);       /* lgc_trace_mark, and the LINREG_DIE_AT hook of bin/linreg_testhooks */
 enum { TABLE_RING_BYTES = 65 };
 typedef struct { node *self; int peer, fd; lgc_party *po; size_t start, end, nslots, acked; } table_link;   /* nslots 0: byte ring */
 int tables_ring_prepare(lgc_party *po, int ring_slots);   /* garbler, optional: create the ring before tables_send / table_link_open need it */

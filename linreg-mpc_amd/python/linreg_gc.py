@@ -600,6 +600,12 @@ def set_karatsuba(on=True):
     lib().lgc_set_karatsuba(int(bool(on)))
 
 
+def set_table_ring_slack(nbytes):
+    """room in a co-located solver's table ring beyond its largest launch (0: the default, 8 GiB)"""
+    lib().lgc_set_table_ring_slack.argtypes = [C.c_size_t]; lib().lgc_set_table_ring_slack.restype = None
+    lib().lgc_set_table_ring_slack(int(nbytes))
+
+
 GATE_HASH = {"aes128": 0, "chaskey12": 1}
 
 

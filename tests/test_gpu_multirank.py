@@ -54,6 +54,36 @@ def test_bench_two_ranks_share_one_gpu(tmp_path, oracle):
         assert [int(v) for v in exp] == d0["beta"][k], (k, lam)
 
 
+def test_bench_eight_ranks_rehearse_the_full_sweep_on_one_gpu(tmp_path, oracle):
+    """BASELINE config 5 at its real size -- d = 100, CGD-15, 64 lambdas -- as EIGHT ranks (gloo), 8 lambdas each, all on the
+    one GPU of the box: the N = 8 code path of bench.py / python/sweep.py (one seed, prefix garbled on rank 0, broadcast,
+    imported on seven ranks, blocks at gate-step offsets 8k x stride, all_gather) with every one of the 64 results checked
+    against the oracle.  Each rank's table ring gets 512 MiB of run-ahead room instead of 8 GiB so that eight of them fit
+    288 GB together (LGC_RING_SLACK_MB); on an 8-GPU node the default applies.  The headline part of the bench is kept tiny."""
+    env = dict(os.environ, LGC_BENCH_BACKEND="gloo", LGC_BENCH_DUMP=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", LGC_RING_SLACK_MB="512")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+           "--dimension", "24", "--iters", "2", "--no-cpu-baseline", "--no-traffic", "--no-e2e"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["barrier_backend"] == "gloo" and out["rccl_ranks"] is None and len(out["devices"]) == 1
+    sw = out["sweep64"]
+    assert (sw["n_gpus"], sw["lambdas"], sw["d"], sw["iterations"]) == (8, 64, 100, 15)
+    assert sw["prefix_bytes_broadcast"] > 100e6 and sw["block_s"] > 0 and "8 lambdas per rank" in sw["sharding"]
+    dumps = [json.load(open(os.path.join(str(tmp_path), "sweep_rank%d.json" % k))) for k in range(8)]
+    assert all(dk["beta"] == dumps[0]["beta"] for dk in dumps)               # every rank holds the gathered results
+    d0 = dumps[0]
+    d, w, p, iters = d0["d"], d0["width"], d0["precision"], d0["iters"]
+    tot = np.array(d0["shares"], dtype=np.uint64).sum(axis=0, dtype=np.uint64)
+    T = d * (d + 1) // 2
+    assert len(d0["lambdas"]) == 64
+    for k, lam in enumerate(d0["lambdas"]):
+        exp, _, _ = oracle_solve(oracle, tot[:T], tot[T:], d, w, p, "cgd", iters, lam, 1)
+        assert [int(v) for v in exp] == d0["beta"][k], (k, lam)
+
+
 def test_bench_launcher_and_self_launch_agree(tmp_path):
     """the torch.distributed.run form the driver documents still works (WORLD_SIZE set: no second level of children)"""
     env = dict(os.environ, LGC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -480,3 +480,60 @@ def test_host_parsers_under_address_sanitizer(tmp_path):
     assert cc.returncode == 0, cc.stderr[-2000:]
     run = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and run.stdout.rstrip().endswith("all ok"), (run.stdout[-1500:], run.stderr[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("victim,mark,extra,must_fail", [
+    (2, "first table evaluated", ["--table_ring"], [1]),                 # the Evaluator dies while the tables stream through the ring
+    (2, "first table evaluated", [], [1]),                               # ... through the socket pipeline
+    (4, "input OT: u sent", ["--table_ring"], [1, 2]),                   # a data provider dies inside the label OT
+    (1, "first table garbled", ["--table_ring"], [2]),                   # the CSP dies after its first table
+], ids=["evaluator-ring", "evaluator-socket", "provider-label-ot", "csp-ring"])
+def test_a_lost_party_makes_the_others_exit_nonzero_in_bounded_time(tmp_path, victim, mark, extra, must_fail):
+    """the reference's convention is check() -> exit 1 for every party (src/check_error.h:5-9, src/cmd/linreg.c:206-211): when a
+    party is lost mid-run, whoever still depends on it must fail within seconds -- not hang on a socket, a ring token or a
+    device-side wait -- and nothing may be left behind.  bin/linreg_testhooks kills the victim at a named point of the
+    protocol (LINREG_DIE_AT, a trace mark).  Parties that were already through with the victim may finish normally (the data
+    providers leave after forwarding their labels, as in the reference)."""
+    import signal, time
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    path = str(tmp_path / "lost.in")
+    _small_instance(path, 60, 12, [0, 4, 8], seed=3)                      # three providers: parties 3, 4, 5
+    exe = os.path.join(HOST, "bin", "linreg_testhooks")
+    shm_before = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
+    procs = []
+    for party in range(1, 6):
+        env = dict(os.environ, LINREG_TRACE="1")
+        if party == victim:
+            env["LINREG_DIE_AT"] = mark
+        procs.append(subprocess.Popen([exe, path, "56", str(party), "cgd", "8", "0.01"] + extra, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, env=env, start_new_session=True))
+    t0 = time.time()
+    deadline = t0 + 60                                                    # start-up included (HIP runtime of five processes)
+    died_at = None
+    while time.time() < deadline and any(p.poll() is None for p in procs):
+        if died_at is None and procs[victim - 1].poll() is not None:
+            died_at = time.time()
+        if died_at is not None and time.time() - died_at > 10:
+            break
+        time.sleep(0.02)
+    hung = [k + 1 for k, p in enumerate(procs) if p.poll() is None]
+    for p in procs:                                                       # whatever is still there: its whole process group
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+    outs = [p.communicate() for p in procs]
+    assert procs[victim - 1].returncode == -signal.SIGKILL, (procs[victim - 1].returncode, outs[victim - 1][1].decode()[-400:])
+    assert not hung, "parties %s still ran 10 s after party %d was lost" % (hung, victim)
+    for k in must_fail:
+        assert procs[k - 1].returncode not in (0, None) and procs[k - 1].returncode > 0, \
+            "party %d: rc %s, stderr %s" % (k, procs[k - 1].returncode, outs[k - 1][1].decode()[-400:])
+    assert b"Result:" not in outs[1][0]                                   # no result without all parties
+    # nothing left behind: every party reaped, no process of these groups alive, no new shared-memory files
+    for p in procs:
+        with pytest.raises(ProcessLookupError):
+            os.killpg(p.pid, 0)
+    if os.path.isdir("/dev/shm"):
+        assert set(os.listdir("/dev/shm")) - shm_before == set()
