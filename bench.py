@@ -263,7 +263,12 @@ def phase12_wall(np, name, n, d, starts, alg, iters, extra, device_index, prec=5
              for k in range(1, len(starts) + 3)]
     # (a blocking wait per child from a thread: Popen.wait(timeout=...) polls with sleeps of up to 50 ms)
     import threading
-    waiters = [threading.Thread(target=q.wait, daemon=True) for q in procs]
+    ended = [None] * len(procs)
+
+    def _wait(k_):
+        procs[k_].wait()
+        ended[k_] = time.monotonic()
+    waiters = [threading.Thread(target=_wait, args=(k_,), daemon=True) for k_ in range(len(procs))]
     for th in waiters:
         th.start()
     deadline = time.time() + 900
@@ -286,6 +291,8 @@ def phase12_wall(np, name, n, d, starts, alg, iters, extra, device_index, prec=5
         res["error"] = outs[[q.returncode != 0 for q in procs].index(True)][1].decode()[-300:]
         return res
     res["timeline"] = startup_timeline([o[1].decode(errors="replace") for o in outs], m0)
+    # when each process was gone (waitpid returned): the gap to its "exit" mark is the HIP runtime's and the driver's teardown
+    res["timeline"]["process_end_s"] = {"p%d" % (k_ + 1): (round(ended[k_] - m0, 4) if ended[k_] else None) for k_ in range(len(procs))}
     ev = outs[1][0].decode()
     m = re.search("Time elapsed: ([0-9.]+)", ev)
     res["evaluator_time_elapsed_s"] = float(m.group(1)) if m else None

@@ -54,11 +54,16 @@ const char *lgc_version(void);
  * adds its protocol steps with the same call, and since the clock is system-wide the marks of all parties of a run line up
  * (bench.py: `phase12[].timeline`).  Replaces nothing in the reference; it is how the start-up of src/cmd/linreg.c:100-199
  * is broken down here.  Without the variable both calls do nothing. */
-/* Brings the HIP runtime and the context of `device` up (60-150 ms when several parties start together); both are
- * process-wide, so a host may call this from a thread while it parses its input and connects (bin/linreg does). */
-int lgc_device_warm(int device);
 void lgc_trace_set_tag(const char *tag);
 void lgc_trace_mark(const char *what);
+/* Brings the HIP runtime and the context of `device` up and issues a first dispatch (60-250 ms when several parties start
+ * together, 20-50 ms for the first dispatch); all of it is process-wide, so a host may call this from a thread while it
+ * parses its input and connects (bin/linreg does). */
+int lgc_device_warm(int device);
+/* Loads code objects and creates streams ahead of their first use (a code object is otherwise loaded inside the first launch of
+ * one of its kernels, 5-10 ms; a stream costs ~10 ms): what & 1 the phase-1 kernels, what & 2 the OT kernels, what & 4 two
+ * streams for the pool the OT sessions draw from.  lgc_party_create* preloads the record kernels of its program by itself. */
+int lgc_preload(int device, int what);
 
 /* ------------------------------------------------------------------ phase 2 */
 
@@ -401,10 +406,15 @@ void lgc_set_table_ring_slack(size_t bytes);
  *   0  pi = AES-128 under a fixed public key -- the reference's choice, and the default.  CDNA4 has no AES instruction:
  *      160 LDS table lookups per block, which is what bounds every kernel of this engine on MI355X.
  *   1  pi = the 12-round permutation of Chaskey (Mouha et al., SAC 2014; Chaskey-12 = ISO/IEC 29192-6): 4 x 32-bit
- *      add / rotate / xor, no tables -- about 1.8x the garbling rate on MI355X.  The half-gates proof models pi as a
- *      fixed random permutation; that is the same assumption the Chaskey MAC's own proof makes of this permutation,
- *      but it is a DIFFERENT primitive from the reference's: an option for deployments that accept it, never a
- *      silent default.  The circuits, gate numbering, table layout and every revealed integer are the same.
+ *      add / rotate / xor, no tables -- about 1.8x the garbling rate on MI355X.  An EXPERIMENT, frozen since round 4 (no
+ *      new kernels, no bench leg by default), and a WEAKER assumption than the reference's: the half-gates proof models pi
+ *      as a fixed PUBLIC random permutation, whereas Chaskey's own proof is Even-Mansour -- pi sits between two XORs of a
+ *      SECRET key and is never evaluated at inputs the adversary knows.  Used bare, pi has properties an ideal permutation
+ *      does not: no round constants, so pi(0) = 0 and rotational relations between inputs and outputs survive, and its
+ *      designers do not claim it to be indistinguishable from random.  H = pi(u) ^ u with u = sigma(x) ^ t and a public
+ *      tweak does not hide these.  Nobody has turned them into an attack on garbling, but modelling this pi as random is a
+ *      heuristic of its own, not the reference's and not Chaskey's.  A deployment has to ask for it on both roles; nothing
+ *      selects it silently.  The circuits, gate numbering, table layout and every revealed integer are the same.
  * Process-wide, takes effect for programs / solvers / parties created afterwards; garbler and evaluator of one solve
  * must agree (a mismatch decodes to garbage, like any other disagreement about the program).  Returns LGC_EINVAL for an
  * unknown kind.  lgc_gate_hash_eval computes H on n labels (16 bytes each, tweaks[i]) on the device: tests pin both

@@ -11,6 +11,7 @@
 
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/linreg_gc.h"
@@ -91,6 +92,50 @@ extern "C" int lgc_device_warm(int device) {
         (void)hipFree(p);
     }
     lgc_trace_mark("lib: first dispatch done (warm-up thread)");
+    return LGC_OK;
+}
+
+// A small pool of HIP streams per device.  hipStreamCreate costs ~10 ms (a hardware queue), and the OT sessions of an
+// end-to-end run are created on its critical path (after the base OTs): lgc_preload creates streams ahead of time, a session
+// takes one from the pool and gives it back when it is destroyed.
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> free_;
+    hipError_t take(int device, hipStream_t *out) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].first == device) { *out = free_[i].second; free_.erase(free_.begin() + (long)i); return hipSuccess; }
+        }
+        return hipStreamCreate(out);
+    }
+    void give(int device, hipStream_t st) {
+        std::lock_guard<std::mutex> g(mu);
+        if (free_.size() < 16) { free_.emplace_back(device, st); return; }
+        (void)hipStreamDestroy(st);
+    }
+};
+static StreamPool &stream_pool() { static StreamPool p; return p; }
+hipError_t lgc_stream_take(int device, hipStream_t *out) { return stream_pool().take(device, out); }
+void lgc_stream_give(int device, hipStream_t st) { stream_pool().give(device, st); }
+
+hipError_t p1_tu_touch(hipStream_t st);
+hipError_t ot_tu_touch(hipStream_t st);
+// what & 1: the phase-1 kernels, what & 2: the OT kernels (their code objects are loaded), what & 4: two pooled streams
+extern "C" int lgc_preload(int device, int what) {
+    int rc = lgc_need_device(device);
+    if (rc) return rc;
+    if (what & 1) HIPCHK(p1_tu_touch(0));
+    if (what & 2) HIPCHK(ot_tu_touch(0));
+    if (what & 4) {
+        for (int k = 0; k < 2; k++) {
+            hipStream_t st;
+            HIPCHK(hipStreamCreate(&st));
+            stream_pool().give(device, st);
+        }
+    }
+    HIPCHK(hipDeviceSynchronize());
+    lgc_trace_mark("lib: kernels preloaded, streams pooled");
     return LGC_OK;
 }
 

@@ -24,9 +24,28 @@ hipError_t GC_CAT3(gc_launch_records_, GC_ROLE_TAG, GC_KERN_PART)(LaunchMode m, 
                                                                    Lbl *tab, Lbl R, int w, int p, hipStream_t st) {
     return gc_launch_records_impl<GC_KERN_G != 0, GC_KERN_PART, GC_KERN_HASH>(m, recs, L, words, dec, tab, R, w, p, st);
 }
+// loads this translation unit's code object (first launch of any of its kernels does: ~5-10 ms) ahead of the first real launch
+__global__ void GC_CAT3(gc_kern_touch_kernel_, GC_ROLE_TAG, GC_KERN_PART)() {}
+hipError_t GC_CAT3(gc_kern_touch_, GC_ROLE_TAG, GC_KERN_PART)(hipStream_t st) {
+    hipLaunchKernelGGL(GC_CAT3(gc_kern_touch_kernel_, GC_ROLE_TAG, GC_KERN_PART), dim3(1), dim3(64), 0, st);
+    return hipGetLastError();
+}
 #if GC_KERN_G && GC_KERN_PART == 2 && !GC_KERN_HASH
 hipError_t gc_launch_tabfill(const Launch &L, const Lbl *stash, Lbl *tab, Lbl R, hipStream_t st) {
     return gc_launch_tabfill_impl(L, stash, tab, R, st);
 }
 #endif
 }  // namespace gc
+#if GC_SPLIT_TRACE && GC_KERN_PART == 2 && !GC_KERN_HASH
+// timing experiments only: the stamps of gc_split.h (GC_SPLIT_TRACE builds), and a reset
+#if GC_KERN_G
+extern "C" int lgc_dbg_split_trace_g(uint64_t *out, uint32_t *n, int reset) {
+#else
+extern "C" int lgc_dbg_split_trace_e(uint64_t *out, uint32_t *n, int reset) {
+#endif
+    if (reset) { uint32_t z[2] = {0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(gc::g_split_trace_n), z, sizeof z); }
+    hipError_t e = hipMemcpyFromSymbol(n, HIP_SYMBOL(gc::g_split_trace_n), 8);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(gc::g_split_trace), 2 * 8192 * 8);
+    return (int)e;
+}
+#endif

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <vector>
 
 #include "gc_aes.h"
 #include "gc_program.h"
@@ -208,7 +209,8 @@ static inline bool gc_mode_is_crit(LaunchMode m, const Launch &L) {
 hipError_t gc_launch_tabfill(const Launch &L, const Lbl *stash, Lbl *tab, Lbl R, hipStream_t st);
 #define GC_KERN_DECL(tag)                                                                                                              \
     hipError_t gc_launch_records_##tag(LaunchMode m, const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec, Lbl *tab, Lbl R, int w, \
-                                       int p, hipStream_t st);
+                                       int p, hipStream_t st);                                                                         \
+    hipError_t gc_kern_touch_##tag(hipStream_t st);
 GC_KERN_DECL(g_0) GC_KERN_DECL(g_1) GC_KERN_DECL(g_2) GC_KERN_DECL(g_3) GC_KERN_DECL(e_0) GC_KERN_DECL(e_1) GC_KERN_DECL(e_2) GC_KERN_DECL(e_3)
 GC_KERN_DECL(g_0h) GC_KERN_DECL(g_1h) GC_KERN_DECL(g_3h) GC_KERN_DECL(e_0h) GC_KERN_DECL(e_1h) GC_KERN_DECL(e_3h)      // gate hash 1
 #undef GC_KERN_DECL
@@ -232,6 +234,35 @@ static inline hipError_t gc_launch_records(LaunchMode m, int hash, const Rec *re
     case LM_WIDE: return G ? gc_launch_records_g_1(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_1(m, recs, L, words, dec, tab, R, w, p, st);
     default: return G ? gc_launch_records_g_3(m, recs, L, words, dec, tab, R, w, p, st) : gc_launch_records_e_3(m, recs, L, words, dec, tab, R, w, p, st);
     }
+}
+
+// Loads the code objects a program's launches will run from, for one role, ahead of the first launch (one empty kernel per
+// translation unit; a code object is otherwise loaded inside the first launch that needs it -- 5-10 ms each, on the critical
+// path of a short run)
+template <bool G>
+static hipError_t gc_preload(const std::vector<Launch> &launches, int hash, hipStream_t st) {
+    bool need[4] = {false, false, false, false};
+    for (const Launch &L : launches) {
+        switch (gc_launch_mode(L, G, hash)) {
+        case LM_NONE: break;
+        case LM_MAC: case LM_MACK: need[0] = true; break;
+        case LM_WIDE: need[1] = true; break;
+        case LM_SPLIT: need[2] = true; break;
+        default: need[3] = true; break;
+        }
+    }
+    hipError_t e = hipSuccess;
+    if (hash == GATE_HASH_CHASKEY12) {
+        if (need[0] && e == hipSuccess) e = G ? gc_kern_touch_g_0h(st) : gc_kern_touch_e_0h(st);
+        if (need[1] && e == hipSuccess) e = G ? gc_kern_touch_g_1h(st) : gc_kern_touch_e_1h(st);
+        if ((need[2] || need[3]) && e == hipSuccess) e = G ? gc_kern_touch_g_3h(st) : gc_kern_touch_e_3h(st);
+        return e;
+    }
+    if (need[0] && e == hipSuccess) e = G ? gc_kern_touch_g_0(st) : gc_kern_touch_e_0(st);
+    if (need[1] && e == hipSuccess) e = G ? gc_kern_touch_g_1(st) : gc_kern_touch_e_1(st);
+    if (need[2] && e == hipSuccess) e = G ? gc_kern_touch_g_2(st) : gc_kern_touch_e_2(st);
+    if (need[3] && e == hipSuccess) e = G ? gc_kern_touch_g_3(st) : gc_kern_touch_e_3(st);
+    return e;
 }
 
 // A whole launch of one role.  stash: garbler only -- where a critical-path record kernel leaves the zero-labels for the

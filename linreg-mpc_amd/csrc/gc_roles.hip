@@ -202,6 +202,10 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
         p->labels_ready = true;
     }
     p->hdec.resize(P.n_reveal + 1);
+    // the code objects of this role's record kernels now (creation runs beside phase 1), not inside the first launches
+    if (role == LGC_ROLE_GARBLER) RCHK(gc_preload<true>(P.launches, P.gate_hash, 0));
+    else RCHK(gc_preload<false>(P.launches, P.gate_hash, 0));
+    RCHK(hipDeviceSynchronize());
     *out = p;
     lgc_trace_mark(role == LGC_ROLE_GARBLER ? "lib: word file, records, input zero-labels on the device" : "lib: word file and records on the device");
     return LGC_OK;

@@ -155,9 +155,31 @@ __device__ __forceinline__ void split_hash_phase(const SplitHashCtx &hc, const S
 // (X0, X1: the two hash results of a gate; their XOR is the gate's output label).  Every hash lane rebuilds the two
 // states it needs -- its own node's and m's -- from what the last barrier made visible, the publisher writes state k - 1
 // for level k + 1; results and published states alternate between two buffers.
+#ifndef GC_SPLIT_TRACE
+#define GC_SPLIT_TRACE 0      /* timing experiments only (scripts/exp/split_trace.py): s_memtime stamps of the adder levels of record 0 */
+#endif
+#if GC_SPLIT_TRACE
+static __device__ uint64_t g_split_trace[2 * 8192];
+static __device__ uint32_t g_split_trace_n[2];
+#define SPLIT_STAMP(tag)                                                                                         \
+    if (tr_on) {                                                                                                 \
+        uint64_t t_;                                                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_));                                         \
+        if (hc.lane == 0 && tr_i < 8192) g_split_trace[tr_w * 8192 + tr_i] = (t_ << 4) | (uint64_t)(tag);        \
+        tr_i++;                                                                                                  \
+    }
+#else
+#define SPLIT_STAMP(tag)
+#endif
 template <bool GARBLER>
 __device__ __forceinline__ void split_sk_add(const SplitHashCtx &hc, const SplitDesc &d) {
     const int q = hc.wave >> 2, r = hc.wave & 3, c = hc.lane & 3, g = 16 * r + (hc.lane >> 2);
+#if GC_SPLIT_TRACE
+    const bool tr_on = blockIdx.x == 0 && (hc.wave == 0 || hc.wave == 4);
+    const int tr_w = hc.wave == 4 ? 1 : 0;
+    uint32_t tr_i = tr_on ? g_split_trace_n[tr_w] : 0u;
+    SPLIT_STAMP(1)                                                                  /* addition entered (after the hand-over barrier) */
+#endif
     const int pl = c * kSplitPlane;
     const uint64_t act = d.act1;
     const int n = 64 - __builtin_clzll(act);                                    // act = lanes(n)
@@ -175,7 +197,9 @@ __device__ __forceinline__ void split_sk_add(const SplitHashCtx &hc, const Split
         split_hash_core<GARBLER>(hc, q, act, st, xg ^ cg, yg ^ cg, hc.sx + kSplitKs + q * kSplitWord, tg);
     }
     st += 1;
+    SPLIT_STAMP(2)                                                                  /* first AND hashed, result stored */
     lds_barrier();
+    SPLIT_STAMP(3)                                                                  /* past the barrier */
     int k = 0;
     for (int h = 1; h < n; h <<= 1, k++) {
         const uint32_t *X0 = hc.sx + kSplitKs + ((k & 1) * 4) * kSplitWord + pl, *X1 = X0 + kSplitWord;   // results of level k - 1
@@ -212,7 +236,12 @@ __device__ __forceinline__ void split_sk_add(const SplitHashCtx &hc, const Split
                 b_op = m0 ^ m1 ^ (up ? mg : 0u);
             }
             if (!(up || host)) { a_op = 0u; b_op = 0u; }
+#if GC_SPLIT_TRACE
+            if (tr_on) { asm volatile("" :: "v"(a_op), "v"(b_op)); }
+            SPLIT_STAMP(4)                                                          /* operands rebuilt (LDS reads back) */
+#endif
             split_hash_core<GARBLER>(hc, q, stepact, st, a_op, b_op, hc.sx + kSplitKs + (((k + 1) & 1) * 4 + q) * kSplitWord, tg);
+            SPLIT_STAMP(5)                                                          /* hashed, result stored */
         } else if (q == 2) {
             // publish state k - 1 of the own lane (read at level k + 1)
             uint32_t *Go = hc.sx + kSplitGs + ((k & 1) * 2) * kSplitWord + pl;
@@ -233,7 +262,11 @@ __device__ __forceinline__ void split_sk_add(const SplitHashCtx &hc, const Split
         }
         st += 1;
         lds_barrier();
+        SPLIT_STAMP(3)
     }
+#if GC_SPLIT_TRACE
+    if (tr_on && hc.lane == 0) g_split_trace_n[tr_w] = tr_i < 8192 ? tr_i : 8192;
+#endif
     // carries = shl(G, 1) ^ cin on the active lanes; sum = P ^ carries; the final generate word for the carry out.
     // Final G at lane t: the state after the last level (k levels were run)
     if (q == 0) {

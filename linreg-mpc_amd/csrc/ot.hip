@@ -30,6 +30,10 @@ using namespace gc;
 
 int lgc_fail(int code, const char *fmt, ...);
 int lgc_need_device(int device);
+hipError_t lgc_stream_take(int device, hipStream_t *out);      // gc_engine.hip: pooled streams (hipStreamCreate is ~10 ms)
+void lgc_stream_give(int device, hipStream_t st);
+__global__ void ot_tu_touch_kernel() {}
+hipError_t ot_tu_touch(hipStream_t st) { hipLaunchKernelGGL(ot_tu_touch_kernel, dim3(1), dim3(64), 0, st); return hipGetLastError(); }
 
 #define OTCHK(x)                                                                             \
     do {                                                                                     \
@@ -379,7 +383,7 @@ static int upload_keys(const uint8_t seeds[][16], uint32_t **out) {
 extern "C" void lgc_ot_sender_destroy(lgc_ot_sender *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    if (s->st) { (void)hipStreamSynchronize(s->st); (void)hipStreamDestroy(s->st); }
+    if (s->st) { (void)hipStreamSynchronize(s->st); lgc_stream_give(s->device, s->st); }
     // q-rows and the sender's messages (both labels of every input bit) must not outlive the session in freed memory
     DevBuf *all[] = {&s->Q, &s->U, &s->rows, &s->b, &s->y, &s->sh, &s->m0, &s->m1, &s->e};
     for (DevBuf *d : all) { if (d->p) (void)hipMemset(d->p, 0, d->cap); d->release(); }
@@ -394,7 +398,6 @@ extern "C" int lgc_ot_sender_create(lgc_ot_sender **out, int device, const uint8
     s->device = device; s->ctr = 0; s->tweak = 0; s->rk = 0; s->st = 0; s->dev_io = false;
     memcpy(&s->delta, delta, 16);
     rc = upload_keys(seeds, &s->rk);
-    if (!rc && hipStreamCreate(&s->st) != hipSuccess) rc = lgc_fail(LGC_EHIP, "hipStreamCreate failed");
     if (rc) { lgc_ot_sender_destroy(s); return rc; }
     *out = s;
     return LGC_OK;
@@ -402,7 +405,7 @@ extern "C" int lgc_ot_sender_create(lgc_ot_sender **out, int device, const uint8
 extern "C" void lgc_ot_receiver_destroy(lgc_ot_receiver *r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
-    if (r->st) { (void)hipStreamSynchronize(r->st); (void)hipStreamDestroy(r->st); }
+    if (r->st) { (void)hipStreamSynchronize(r->st); lgc_stream_give(r->device, r->st); }
     DevBuf *all[] = {&r->T0, &r->U, &r->y, &r->sh, &r->e, &r->out, &r->choice};
     for (DevBuf *d : all) { if (d->p) (void)hipMemset(d->p, 0, d->cap); d->release(); }
     for (size_t k = 0; k < kMaxRecvInFlight; k++) {
@@ -421,7 +424,6 @@ extern "C" int lgc_ot_receiver_create(lgc_ot_receiver **out, int device, const u
     r->device = device; r->rk0 = 0; r->rk1 = 0; r->ctr = 0; r->tweak = 0; r->st = 0; r->dev_io = false; r->head = 0; r->count = 0;
     rc = upload_keys(seeds0, &r->rk0);
     if (!rc) rc = upload_keys(seeds1, &r->rk1);
-    if (!rc && hipStreamCreate(&r->st) != hipSuccess) rc = lgc_fail(LGC_EHIP, "hipStreamCreate failed");
     if (rc) { lgc_ot_receiver_destroy(r); return rc; }
     *out = r;
     return LGC_OK;
@@ -501,6 +503,7 @@ extern "C" int lgc_ot_gilboa_recv_start(lgc_ot_receiver *r, const uint64_t *a, s
     if (!r || !a || !u_out) return lgc_fail(LGC_EINVAL, "null argument");
     if (width != 32 && width != 64) return lgc_fail(LGC_EINVAL, "width must be 32 or 64");
     std::lock_guard<std::mutex> lock(r->mu);
+    if (!r->st && lgc_stream_take(r->device, &r->st) != hipSuccess) return lgc_fail(LGC_EHIP, "hipStreamCreate failed");
     lgc_ot_receiver::Slot *sl = slot_push(r);
     if (!sl) return lgc_fail(LGC_ESTATE, "too many receives in flight (%zu)", r->count);
     struct Undo { lgc_ot_receiver *r; bool armed; ~Undo() { if (armed) slot_unpush(r); } } undo = {r, true};
@@ -531,6 +534,7 @@ extern "C" int lgc_ot_gilboa_send(lgc_ot_sender *s, const uint64_t *b, size_t np
     if (!s || !b || !u_in || !y_out || !shares) return lgc_fail(LGC_EINVAL, "null argument");
     if (width != 32 && width != 64) return lgc_fail(LGC_EINVAL, "width must be 32 or 64");
     OTCHK(hipSetDevice(s->device));
+    if (!s->st && lgc_stream_take(s->device, &s->st) != hipSuccess) return lgc_fail(LGC_EHIP, "hipStreamCreate failed");
     const uint64_t nw = (uint64_t)npairs * n, m = nw * (uint64_t)width, mpp = (uint64_t)n * width;
     int rc = send_extend(s, m, u_in);
     if (rc) return rc;

@@ -23,6 +23,8 @@ using namespace gc;
 
 int lgc_fail(int code, const char *fmt, ...);
 int lgc_need_device(int device);
+__global__ void p1_tu_touch_kernel() {}
+hipError_t p1_tu_touch(hipStream_t st) { hipLaunchKernelGGL(p1_tu_touch_kernel, dim3(1), dim3(64), 0, st); return hipGetLastError(); }
 
 #define P1CHK(x)                                                                             \
     do {                                                                                     \

@@ -89,9 +89,10 @@ static void *create_main(void *arg) {
     return NULL;
 }
 /* the HIP runtime and the device context come up on a thread of their own while main parses, connects and reads */
+static int g_warm_what;
 static void *warm_main(void *arg) {
     int device = *(int *)arg;
-    (void)lgc_device_warm(device);
+    if (lgc_device_warm(device) == LGC_OK && g_warm_what) (void)lgc_preload(device, g_warm_what);
     return NULL;
 }
 
@@ -240,6 +241,9 @@ int main(int argc, char **argv) {
     static int warm_device;
     pthread_t warm_th;
     warm_device = device;
+    /* the code objects this party will launch from, and streams for its OT sessions: data providers run phase 1 and the label
+     * OT, the CSP is the initializer (phase-1 kernels) and the label-OT sender; the Evaluator's kernels come with its program */
+    g_warm_what = party == 2 ? 0 : 3;   /* (no pooled streams: every extra hardware queue costs ~60 ms when four processes tear down at once) */
     int warm_started = pthread_create(&warm_th, NULL, warm_main, &warm_device) == 0;
     if (warm_started) pthread_detach(warm_th);
 

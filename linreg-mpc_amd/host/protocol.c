@@ -377,12 +377,26 @@ int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, 
     l->nslots = (size_t)h.nslots;
     return 0;
 }
+/* byte ring: the newest launch any launch of this link waits for (-1: none) -- the same on both sides (same plan) */
+static int64_t link_last_ack(table_link *l) {
+    if (l->last_ack_known) return l->last_ack;
+    int64_t m = -1;
+    for (size_t i = l->start; i < l->end; i++) {
+        int64_t wf = lgc_party_ring_wait_for(l->po, i);
+        if (wf > m) m = wf;
+    }
+    l->last_ack = m; l->last_ack_known = 1;
+    return m;
+}
 /* garbler: launches [lo, hi); launch i reuses the slot of launch i - nslots and waits for its ack */
 int table_link_send_range(table_link *l, size_t lo, size_t hi) {
     uint8_t tok = 0;
     if (l->nslots == 0) {
-        /* byte ring: the evaluator acknowledges every launch; launch i may overwrite its range once the launch
-         * lgc_party_ring_wait_for names has been evaluated (launches before l->start never pass through this link) */
+        /* byte ring: launch i may overwrite its range once the launch lgc_party_ring_wait_for names has been evaluated
+         * (launches before l->start never pass through this link).  The evaluator acknowledges the launches somebody will
+         * wait for -- those up to link_last_ack -- and no others: the garbler is through when its last launch is garbled,
+         * not when the evaluator is (its exit handlers then run beside the evaluator's tail instead of beside its exit) */
+        const int64_t last_ack = link_last_ack(l);
         for (size_t i = lo; i < hi; i++) {
             int64_t wf = lgc_party_ring_wait_for(l->po, i);
             size_t need = wf >= (int64_t)l->start ? (size_t)(wf - (int64_t)l->start) + 1 : 0;
@@ -392,7 +406,10 @@ int table_link_send_range(table_link *l, size_t lo, size_t hi) {
             tok = 1;
             if (link_io(l, &tok, 1, 1)) return 1;
         }
-        while (l->acked < hi - l->start) { if (link_io(l, &tok, 1, 0)) return 1; l->acked++; }   /* nothing of this range stays in flight */
+        /* acknowledgements of this range that are still on their way stay out of the next message on this channel */
+        size_t due = (last_ack >= (int64_t)l->start) ? (size_t)(last_ack - (int64_t)l->start) + 1 : 0;
+        if (due > hi - l->start) due = hi - l->start;
+        while (l->acked < due) { if (link_io(l, &tok, 1, 0)) return 1; l->acked++; }
         return 0;
     }
     for (size_t i = lo; i < hi; i++) {
@@ -410,7 +427,7 @@ int table_link_recv_range(table_link *l, size_t lo, size_t hi, void (*after_laun
         if (link_io(l, &tok, 1, 0)) return 1;                                   /* launch i is in its slot */
         TCHK(lgc_party_evaluate_ring(l->po, i));
         if (after_launch) after_launch(i, ctx);
-        if ((l->nslots == 0 || i + l->nslots < l->end) && link_io(l, &tok, 1, 1)) return 1;
+        if ((l->nslots == 0 ? (int64_t)i <= link_last_ack(l) : i + l->nslots < l->end) && link_io(l, &tok, 1, 1)) return 1;
     }
     return 0;
 }

@@ -45,7 +45,7 @@ int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
  * TABLE_RING_BYTES = the byte ring (largest launch + slack: lgc_party_ring_create_bytes), what plain --table_ring selects */
 void host_trace_mark(const char *what);       /* lgc_trace_mark, and the LINREG_DIE_AT hook of bin/linreg_testhooks */
 enum { TABLE_RING_BYTES = 65 };
-typedef struct { node *self; int peer, fd; lgc_party *po; size_t start, end, nslots, acked; } table_link;   /* nslots 0: byte ring */
+typedef struct { node *self; int peer, fd; lgc_party *po; size_t start, end, nslots, acked; int64_t last_ack; int last_ack_known; } table_link;   /* nslots 0: byte ring */
 int tables_ring_prepare(lgc_party *po, int ring_slots);   /* garbler, optional: create the ring before tables_send / table_link_open need it */
 int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, int sending, int ring_slots, size_t start);
 int table_link_send_range(table_link *l, size_t lo, size_t hi);

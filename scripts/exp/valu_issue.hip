@@ -26,7 +26,15 @@ __global__ void __launch_bounds__(256) k(unsigned long long *out, int iters, uns
         else if (OP == 2) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(r) : "v"(y)); \
         else if (OP == 3) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r) : "v"(y), "v"(z)); \
         else if (OP == 4) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r) : "v"(y), "v"(z)); \
-        else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(y), "v"(z));
+        else if (OP == 5) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(y), "v"(z)); \
+        else if (OP == 6) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(r) : "v"(y)); \
+        else if (OP == 7) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r) : "v"(y), "v"(z)); \
+        else if (OP == 8) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(r)); \
+        else if (OP == 9) asm volatile("v_lshl_or_b32 %0, %0, 8, %1" : "+v"(r) : "v"(y)); \
+        else if (OP == 10) asm volatile("v_alignbyte_b32 %0, %0, %1, 1" : "+v"(r) : "v"(y)); \
+        else if (OP == 11) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(r) : "v"(y), "v"(z)); \
+        else if (OP == 12) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "+v"(r)); \
+        else asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(y), "v"(r));
         if (DEP) { REP64(ONE(a0)) }
         else { REP8(ONE(a0) ONE(a1) ONE(a2) ONE(a3) ONE(a4) ONE(a5) ONE(a6) ONE(a7)) }
     }
@@ -65,5 +73,13 @@ int main() {
     run<3, true>("v_perm_b32", cus);  run<3, false>("v_perm_b32", cus);
     run<4, true>("v_bitop3", cus);    run<4, false>("v_bitop3", cus);
     run<5, true>("v_fma_f32", cus);   run<5, false>("v_fma_f32", cus);
+    run<6, true>("mov_sdwa", cus);    run<6, false>("mov_sdwa", cus);          // byte insert, other bytes preserved
+    run<7, false>("v_and_or", cus);
+    run<8, false>("v_bfe_u32", cus);
+    run<9, false>("v_lshl_or", cus);
+    run<10, false>("alignbyte", cus);
+    run<11, false>("v_bfi_b32", cus);
+    run<12, true>("mov_dpp", cus);    run<12, false>("mov_dpp", cus);
+    run<13, false>("lshl_sdwa", cus);
     return 0;
 }

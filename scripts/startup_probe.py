@@ -40,6 +40,9 @@ def main():
             print("%-6s rep %d  wall %.3f s  %s" % (name, rep, r.get("phase12_wall_s", -1), r.get("error", "")))
             for k, v in st.items():
                 print("    %-22s %8.3f s  (%s)" % (k, v["t_s"], v["party"]))
+            pe = r.get("timeline", {}).get("process_end_s", {})
+            ex = {tag: [t for t, w_ in lst if w_ == "exit"] for tag, lst in r.get("timeline", {}).get("marks", {}).items()}
+            print("    teardown (exit mark -> process gone): " + ", ".join("%s %.0f ms" % (tag, 1e3 * (pe[tag] - ex[tag][0])) for tag in sorted(pe) if pe.get(tag) and ex.get(tag)))
             sys.stdout.flush()
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
