@@ -409,6 +409,10 @@ def main():
     import numpy as np
     import torch                       # first: one HIP runtime per process (shared SONAME)
     import linreg_gc as lgc
+    if os.environ.get("LGC_RING_SLACK_MB"):
+        # run-ahead room of every co-located solver's table ring: less for ranks sharing one GPU (the 8-rank rehearsal of
+        # tests/test_gpu_multirank.py), more to let a garbling MAC launch overlap the previous one's evaluation (experiments)
+        lgc.set_table_ring_slack(int(os.environ["LGC_RING_SLACK_MB"]) << 20)
 
     if not torch.cuda.is_available() or lgc.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (no HIP device visible; there is no CPU fallback)")
@@ -570,9 +574,6 @@ def main():
         if w == 32:
             sshares &= np.uint64(0xffffffff)
         lams = sweep.c5_lambdas(nl)
-        if os.environ.get("LGC_RING_SLACK_MB"):
-            # ranks sharing one GPU (the 8-rank rehearsal of tests/test_gpu_multirank.py): less run-ahead room per ring
-            lgc.set_table_ring_slack(int(os.environ["LGC_RING_SLACK_MB"]) << 20)
         make = sweep.gpu_block_solver_factory(sd, w, p, "cgd", sit, 2, device_index)
         # warm-up: at N > 1 with the blocks of the timed run, so that every rank's table ring is already parked at full size
         # (a fresh hipMalloc of a block's 42 GB ring is 0.27 s against 1.07 s of kernels); at N = 1 two circuits do

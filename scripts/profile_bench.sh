@@ -27,11 +27,12 @@ python3 scripts/gpu_launch_profile.py 100 cgd 15 > $O/launch_profile_d100_cgd15.
 python3 scripts/gpu_launch_profile.py 20 cholesky 0 > $O/launch_profile_d20_cholesky.txt 2>&1
 python3 scripts/gpu_launch_profile.py 500 cgd 20 32 30 > $O/launch_profile_d500_cgd20_w32.txt 2>&1
 python3 scripts/gpu_probe.py mid big > $O/probe.txt 2>&1
-# the same over gate hash 1 (Chaskey-12 permutation; lgc_set_gate_hash)
-python3 scripts/gpu_launch_profile.py 500 cgd 15 64 chaskey12 > $O/launch_profile_d500_cgd15_chaskey12.txt 2>&1
-python3 scripts/gpu_launch_profile.py 20 cholesky 0 64 chaskey12 > $O/launch_profile_d20_cholesky_chaskey12.txt 2>&1
-python3 scripts/gpu_probe.py mid big hash=chaskey12 > $O/probe_chaskey12.txt 2>&1
-(cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_sq1_h1 -- python3 $R/scripts/gpu_probe.py big hash=chaskey12 > /dev/null 2> $O/pmc_sq1_h1.err)
-(cd /tmp && rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2_h1 -- python3 $R/scripts/gpu_probe.py big hash=chaskey12 > /dev/null 2> $O/pmc_sq2_h1.err)
+# round 4: start-up timelines of the end-to-end runs, the integer VALU issue rates, where a level of the column-split kernel
+# goes (GC_SPLIT_TRACE build, if scripts/exp/libs/lib_strace.so was built), the HIP runtime's start / exit cost
+python3 scripts/startup_probe.py --configs c2,c3-ti,c3-ot,c1,c4 --reps 2 --out $O/startup_timeline.json > $O/startup_timeline.txt 2>&1
+[ -x scripts/exp/bin/valu_issue ] && scripts/exp/bin/valu_issue > $O/valu_issue.txt 2>&1
+[ -f scripts/exp/libs/lib_strace.so ] && LGC_LIB=$R/scripts/exp/libs/lib_strace.so python3 scripts/exp/split_trace.py > $O/split_trace.txt 2>&1
+[ -x scripts/exp/bin/hip_init_probe ] && bash scripts/exp/hip_init_ab.sh > $O/hip_init.txt 2>&1
+[ -x scripts/exp/bin/hip_exit_probe ] && python3 scripts/exp/hip_exit_probe.py > $O/hip_exit.txt 2>&1
 python3 tests/tools/gpu_phase1_baseline.py > $O/phase1_baseline.jsonl 2>&1
 cat $O/bench_line.json | cut -c1-600

@@ -21,7 +21,7 @@ for src, dst in (("stats/**/*_kernel_stats.csv", "bench_kernel_stats.csv"), ("st
         shutil.copy(f, os.path.join(P, tag + "_" + dst))
 for name in ("bench_line.json", "launch_profile_d500_cgd15.txt", "launch_profile_d100_cgd15.txt", "launch_profile_d20_cholesky.txt",
              "launch_profile_d500_cgd20_w32.txt", "probe.txt", "ot_probe.txt", "phase1_probe.txt", "phase1_baseline.jsonl",
-             "launch_profile_d500_cgd15_chaskey12.txt", "launch_profile_d20_cholesky_chaskey12.txt", "probe_chaskey12.txt"):
+             "startup_timeline.json", "startup_timeline.txt", "valu_issue.txt", "split_trace.txt", "hip_init.txt", "hip_exit.txt"):
     if os.path.exists(os.path.join(O, name)):
         shutil.copy(os.path.join(O, name), os.path.join(P, tag + "_" + name))
 
@@ -66,7 +66,6 @@ def derived(c):
 
 
 for dirs, name, what in ((["pmc_sq1", "pmc_sq2"], "mac_sq_counters.json", "python3 scripts/gpu_probe.py big (d=500, one CGD iteration)"),
-                         (["pmc_sq1_h1", "pmc_sq2_h1"], "mac_sq_counters_chaskey12.json", "python3 scripts/gpu_probe.py big hash=chaskey12 (d=500, one CGD iteration, gate hash 1)"),
                          (["pmc_quad1", "pmc_quad2"], "quad_sq_counters.json", "python3 scripts/gpu_probe.py chol (d=20 Cholesky x3: 4-wave latency kernels)")):
     c = counters(dirs)
     keep = {k: dict(v, **derived(v)) for k, v in c.items() if "gc_" in k}
