@@ -44,6 +44,11 @@ extern "C" {
 #define LGC_ALG_CHOLESKY 0
 #define LGC_ALG_LDLT 1
 #define LGC_ALG_CGD 2
+/* Not a solver: "check if inputs have equal dimensions" of the two-party input path (src/linear.oc:109-114,
+ * revealOblivBool(feedOblivInt(d, 1) == feedOblivInt(d, 2))) as a program of its own -- d = 1, nshares = 2, normalize = 0,
+ * width 32; the first input word of share 0 / share 1 is party 1's / party 2's dimension, beta[0] is 1 when they are equal
+ * (31 AND gates).  Run before the solve, whose program both parties can only build once they agree on d. */
+#define LGC_ALG_DIMCHECK 3
 
 const char *lgc_last_error(void);
 int lgc_device_count(void);

@@ -533,6 +533,18 @@ struct Circ {
         }
         return Q;
     }
+    // [a == b] in lane 0: OR of the lanes of a ^ b by halving (w - 1 AND gates in log2 w steps, as many gates as the
+    // reference's comparison of two w-bit words), inverted
+    static GC_HD W equal(B &be, W a, W b, int w) {
+        W nz = be.sel(lanes(w), be.XOR(a, b), be.zero());
+        for (int dist = 32; dist >= 1; dist >>= 1) {
+            if (dist >= w) continue;
+            W sh = be.shr(nz, dist);
+            W t = be.AND(nz, sh, lanes(dist));
+            nz = be.sel(lanes(dist), be.XOR(be.XOR(nz, sh), t), be.zero());
+        }
+        return be.sel(1ull, be.NOTm(nz, 1ull), be.zero());
+    }
     static GC_HD W div(B &be, W a, W b, int w, int p) {
         W sa = be.bcast(a, w - 1), sb = be.bcast(b, w - 1);
         W ua = condneg(be, a, sa, w), ub = condneg(be, b, sb, w);

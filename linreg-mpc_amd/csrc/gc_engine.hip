@@ -275,7 +275,9 @@ static int check_system(const lgc_system *sys) {
         return lgc_fail(LGC_EINVAL, "precision must satisfy 0 <= p < width (src/cmd/linreg.c:85-88)");
     if (sys->d < 1 || sys->d > 4096) return lgc_fail(LGC_EINVAL, "d out of range");
     if (sys->nshares < 1) return lgc_fail(LGC_EINVAL, "nshares must be >= 1");
-    if (sys->algorithm < 0 || sys->algorithm > 2) return lgc_fail(LGC_EINVAL, "Algorithm must be cholesky, ldlt, or cgd.");
+    if (sys->algorithm < 0 || sys->algorithm > LGC_ALG_DIMCHECK) return lgc_fail(LGC_EINVAL, "Algorithm must be cholesky, ldlt, or cgd.");
+    if (sys->algorithm == LGC_ALG_DIMCHECK && (sys->d != 1 || sys->nshares != 2 || sys->normalize))
+        return lgc_fail(LGC_EINVAL, "the dimension check is a program of its own: d = 1, nshares = 2, normalize = 0");
     if (sys->algorithm == LGC_ALG_CGD && sys->num_iterations < 0) return lgc_fail(LGC_EINVAL, "negative iteration count");
     return LGC_OK;
 }

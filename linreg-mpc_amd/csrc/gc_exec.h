@@ -41,6 +41,7 @@ enum Op : uint32_t {
     OP_MACK,    // 64-bit only: OP_MAC through the Karatsuba circuit (Circ::mack2), two products at a time; the words
                 // hdiff(x) of both operand vectors lie c words above the operands: (a + k*sa) + c, (b + k*sb) + c
     OP_HDIFF,   // dst = hdiff(a): |hi32(a) - lo32(a)| and its sign, for OP_MACK
+    OP_EQ,      // dst = [a == b] in lane 0 (other lanes 0): the comparison of the two parties' dimensions, src/linear.oc:109-114
     OP_COUNT_
 };
 
@@ -83,6 +84,9 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
     } break;
     case OP_HDIFF:
         be.store(r.dst, C::hdiff(be, be.load(r.a)));
+        break;
+    case OP_EQ:
+        be.store(r.dst, C::equal(be, be.load(r.a), be.load(r.b), w));
         break;
     case OP_SUM:
     case OP_SUBSUM: {

@@ -43,7 +43,7 @@ struct Launch {
     bool mack;                  // mac_only launch whose records are OP_MACK (Karatsuba products: a kernel of their own)
 };
 
-enum Alg { ALG_CHOLESKY = 0, ALG_LDLT = 1, ALG_CGD = 2 };
+enum Alg { ALG_CHOLESKY = 0, ALG_LDLT = 1, ALG_CGD = 2, ALG_DIMCHECK = 3 };
 
 struct Program {
     int w, p;
@@ -500,6 +500,18 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
     const uint32_t D = (uint32_t)d;
     // word 0 is the constant zero (the word file starts zeroed on both sides)
     P.in_base = P.alloc(nshares * (T + d));
+    if (alg == ALG_DIMCHECK) {
+        // "check if inputs have equal dimensions" (src/linear.oc:109-114): the first word of either party's input is its d;
+        // one comparison, revealed.  d = 1, two shares: a program that does not depend on what it checks
+        const uint32_t eq = P.alloc(1);
+        P.new_launch();
+        P.emit(Program::mk(OP_EQ, eq, P.in_base, P.in_base + (uint32_t)(T + d)));
+        P.new_launch();
+        P.rv_beta = P.alloc_reveal(d);
+        P.emit(Program::mk(OP_REVEAL, P.rv_beta, eq));
+        P.new_launch();
+        return;
+    }
     const uint32_t S_first = normalize ? P.alloc(T + d) : 0;   // share sums (see below): directly after the inputs
     const uint32_t M = P.alloc(d * d);       // full symmetric storage, M[i*d+j] == M[j*d+i]
     const uint32_t bv = P.alloc(d);

@@ -81,12 +81,79 @@ int main(int argc, char **argv) {
     check(!node_new(&self, party, 2, eps), "Could not connect");
     double time = wall_clock();
     if (party == 2) printf("\nAlgorithm: %s\n", algorithm);
-    {   /* "check if inputs have equal dimensions" (src/linear.oc:109-114).  The reference compares the two
-         * d inside the circuit (31 AND gates) and reveals the bit to both; d is public here -- it fixes the
-         * circuit both sides build -- so the two sides simply exchange it. */
-        uint64_t d_mine = d, d_peer = 0;
-        check(!send_blob(self, 3 - party, &d_mine, 8) && !recv_blob(self, 3 - party, &d_peer, 8), "could not exchange dimensions");
-        check(d_mine == d_peer, "Inputs of the two parties differ.");
+    /* "check if inputs have equal dimensions" (src/linear.oc:109-114): revealOblivBool(feedOblivInt(d, 1) == feedOblivInt(d, 2)).
+     * As in the reference the two d are compared INSIDE a circuit -- a program of its own (LGC_ALG_DIMCHECK: one comparison of
+     * two 32-bit words, 31 AND gates, one reveal), because the program of the solve can only be built once both sides agree on
+     * d -- and the bit is revealed to both.  The base OTs come first: the evaluator's d enters through the same OT extension
+     * session as its shares do afterwards.  (Rounds 1-3 exchanged the two d on the socket.) */
+    uint8_t delta[16], seeds[128][16], s0[128][16], s1[128][16];
+    lgc_ot_sender *S = 0;
+    lgc_ot_receiver *R = 0;
+    unsigned long long dim_gates = 0;
+    if (party == 1) { check(!baseot_ext_sender(self, 2, delta, seeds), "base OT failed"); LGC(lgc_ot_sender_create(&S, device, delta, seeds)); }
+    else { check(!baseot_ext_receiver(self, 1, s0, s1), "base OT failed"); LGC(lgc_ot_receiver_create(&R, device, s0, s1)); }
+    {
+        lgc_system ds;
+        memset(&ds, 0, sizeof ds);
+        ds.d = 1; ds.width = 32; ds.precision = 0; ds.algorithm = LGC_ALG_DIMCHECK; ds.nshares = 2;
+        lgc_party *pc = 0;
+        uint64_t din[2] = {(uint64_t)(uint32_t)d, 0};
+        uint8_t equal = 0;
+        if (party == 1) {
+            uint8_t sd[16];
+            check(RAND_bytes(sd, sizeof sd) == 1, "RAND_bytes failed");
+            LGC(lgc_party_create(&pc, device, &ds, LGC_ROLE_GARBLER, sd, (size_t)64 << 20));
+            size_t bits = lgc_party_input_bits(pc);
+            uint8_t *lab = malloc(bits * 16), *m0 = malloc(bits * 16), *m1 = malloc(bits * 16), *u = malloc(lgc_ot_u_bytes(bits)), *e = malloc(bits * 32);
+            LGC(lgc_party_encode_inputs(pc, 0, din, lab));
+            check(!send_blob(self, 2, lab, bits * 16), "could not send labels");
+            LGC(lgc_party_input_pairs(pc, 1, m0, m1));
+            check(!recv_blob(self, 2, u, lgc_ot_u_bytes(bits)), "OT: could not receive u");
+            LGC(lgc_ot_labels_send(S, m0, m1, bits, u, e));
+            check(!send_blob(self, 2, e, bits * 32), "OT: could not send");
+            free(lab); free(m0); free(m1); free(u); free(e);
+            for (size_t i = 0; i < lgc_party_num_launches(pc); i++) {
+                size_t tb = lgc_party_table_bytes(pc, i);
+                uint8_t *tab = malloc(tb + 16);
+                LGC(lgc_party_garble(pc, i, tab));
+                check(!send_blob(self, 2, tab, tb), "could not send tables");
+                free(tab);
+            }
+            uint64_t dec[4] = {0};
+            LGC(lgc_party_decode_bits(pc, dec));
+            check(!send_blob(self, 2, dec, lgc_party_num_reveal(pc) * 8), "could not send decode bits");
+            check(!recv_blob(self, 2, &equal, 1), "could not receive the comparison");        /* revealed to both (party 0) */
+        } else {
+            LGC(lgc_party_create(&pc, device, &ds, LGC_ROLE_EVALUATOR, NULL, (size_t)64 << 20));
+            size_t bits = lgc_party_input_bits(pc);
+            uint8_t *lab = malloc(bits * 16), *sel = malloc(bits), *u = malloc(lgc_ot_u_bytes(bits)), *e = malloc(bits * 32);
+            check(!recv_blob(self, 1, lab, bits * 16), "could not receive labels");
+            LGC(lgc_party_set_input_labels(pc, 0, lab));
+            for (size_t i = 0; i < 2; i++)
+                for (int j = 0; j < 32; j++) sel[i * 32 + (size_t)j] = (uint8_t)((din[i] >> j) & 1);
+            LGC(lgc_ot_labels_recv_start(R, sel, bits, u));
+            check(!send_blob(self, 1, u, lgc_ot_u_bytes(bits)), "OT: could not send u");
+            check(!recv_blob(self, 1, e, bits * 32), "OT: could not receive");
+            LGC(lgc_ot_labels_recv_finish(R, e, lab));
+            LGC(lgc_party_set_input_labels(pc, 1, lab));
+            free(lab); free(sel); free(u); free(e);
+            for (size_t i = 0; i < lgc_party_num_launches(pc); i++) {
+                size_t tb = lgc_party_table_bytes(pc, i);
+                uint8_t *tab = malloc(tb + 16);
+                check(!recv_blob(self, 1, tab, tb), "could not receive tables");
+                LGC(lgc_party_evaluate(pc, i, tab));
+                free(tab);
+            }
+            uint64_t dec[4] = {0};
+            int64_t eqw = 0;
+            check(!recv_blob(self, 1, dec, lgc_party_num_reveal(pc) * 8), "could not receive decode bits");
+            LGC(lgc_party_finish(pc, dec, &eqw, NULL, NULL));
+            equal = (uint8_t)(eqw & 1);
+            check(!send_blob(self, 1, &equal, 1), "could not send the comparison");
+        }
+        dim_gates = (unsigned long long)lgc_party_and_gates(pc);
+        lgc_party_destroy(pc);
+        check(equal == 1, "Inputs of the two parties differ.");
     }
 
     lgc_system sys;
@@ -104,10 +171,6 @@ int main(int argc, char **argv) {
         uint8_t *lab = malloc(bits * 16), *m0 = malloc(bits * 16), *m1 = malloc(bits * 16), *u = malloc(lgc_ot_u_bytes(bits)), *e = malloc(bits * 32);
         LGC(lgc_party_encode_inputs(po, 0, mine, lab));                         /* feedOblivLLong(.., 1) */
         check(!send_blob(self, 2, lab, bits * 16), "could not send labels");
-        uint8_t delta[16], seeds[128][16];
-        check(!baseot_ext_sender(self, 2, delta, seeds), "base OT failed");
-        lgc_ot_sender *S = 0;
-        LGC(lgc_ot_sender_create(&S, device, delta, seeds));
         LGC(lgc_party_input_pairs(po, 1, m0, m1));                              /* feedOblivLLong(.., 2): OT */
         check(!recv_blob(self, 2, u, lgc_ot_u_bytes(bits)), "OT: could not receive u");
         LGC(lgc_ot_labels_send(S, m0, m1, bits, u, e));
@@ -128,10 +191,6 @@ int main(int argc, char **argv) {
         uint8_t *lab = malloc(bits * 16), *sel = malloc(bits), *u = malloc(lgc_ot_u_bytes(bits)), *e = malloc(bits * 32);
         check(!recv_blob(self, 1, lab, bits * 16), "could not receive labels");
         LGC(lgc_party_set_input_labels(po, 0, lab));
-        uint8_t s0[128][16], s1[128][16];
-        check(!baseot_ext_receiver(self, 1, s0, s1), "base OT failed");
-        lgc_ot_receiver *R = 0;
-        LGC(lgc_ot_receiver_create(&R, device, s0, s1));
         for (size_t i = 0; i < T + d; i++)
             for (int j = 0; j < w; j++) sel[i * (size_t)w + (size_t)j] = (uint8_t)((mine[i] >> j) & 1);
         LGC(lgc_ot_labels_recv_start(R, sel, bits, u));
@@ -158,7 +217,7 @@ int main(int argc, char **argv) {
         int64_t *beta = malloc(d * 8), *trace = malloc(((size_t)num_iterations * (d + 4) + 1) * 8);
         LGC(lgc_party_finish(po, dec, beta, trace, NULL));
         free(dec);
-        long long gates = (long long)lgc_party_and_gates(po);
+        long long gates = (long long)lgc_party_and_gates(po) + (long long)dim_gates;   /* yaoGateCount() includes the dimension check */
         if (sys.algorithm == LGC_ALG_CGD) {
             printf("OT time: %f\nStarting iterations.\n", t_ot);
             for (int t = 0; t < num_iterations; t++) {

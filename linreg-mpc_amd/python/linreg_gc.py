@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LGC_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "liblinreg_gc.so")
 
-ALG = {"cholesky": 0, "ldlt": 1, "cgd": 2}
+ALG = {"cholesky": 0, "ldlt": 1, "cgd": 2, "dimcheck": 3}   # dimcheck: the two parties' dimension comparison (src/linear.oc:109-114), not a solver
 
 
 class LgcError(RuntimeError):

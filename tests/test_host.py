@@ -537,3 +537,42 @@ def test_a_lost_party_makes_the_others_exit_nonzero_in_bounded_time(tmp_path, vi
             os.killpg(p.pid, 0)
     if os.path.isdir("/dev/shm"):
         assert set(os.listdir("/dev/shm")) - shm_before == set()
+
+
+@pytest.mark.gpu
+def test_two_parties_with_different_dimensions_are_told_so_by_the_circuit(tmp_path):
+    """src/linear.oc:109-114: the two parties' dimensions are compared INSIDE a circuit and the bit is revealed to both;
+    when they differ both exit non-zero with the reference's message (bin/test_linear_system; rounds 1-3 compared on the
+    socket).  With equal dimensions the gate count printed includes the comparison's 31 gates."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(3)
+    paths = []
+    for d in (3, 4):
+        X = rng.standard_normal((30, d)); X /= np.abs(X).max(axis=0)
+        A = X.T @ X / (30 * d) + np.eye(d) * 1e-2
+        b = A @ rng.random(d)
+        path = str(tmp_path / ("ls%d.in" % d))
+        with open(path, "w") as f:
+            f.write("%d %d\n" % (d, d))
+            np.savetxt(f, A, fmt="%.17g")
+            f.write("%d\n" % d)
+            np.savetxt(f, b[None, :], fmt="%.17g")
+            f.write("%d\n" % d)
+            np.savetxt(f, np.zeros((1, d)), fmt="%g")
+        paths.append(path)
+    exe = os.path.join(HOST, "bin", "test_linear_system")
+    port = _free_ports(1)[0]
+    procs = [subprocess.Popen([exe, str(port), str(k), paths[k - 1], "cgd", "2", "56", "--host=127.0.0.1"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for k in (1, 2)]
+    outs = [q.communicate(timeout=120) for q in procs]
+    for q, (o, e) in zip(procs, outs):
+        assert q.returncode == 1 and b"Inputs of the two parties differ." in e, (q.returncode, e.decode()[-300:])
+    assert b"Result:" not in outs[1][0]
+    port = _free_ports(1)[0]
+    procs = [subprocess.Popen([exe, str(port), str(k), paths[0], "cgd", "2", "56", "--host=127.0.0.1"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for k in (1, 2)]
+    outs = [q.communicate(timeout=120) for q in procs]
+    assert all(q.returncode == 0 for q in procs), outs[0][1].decode()[-300:] + outs[1][1].decode()[-300:]
+    import linreg_gc
+    prog = linreg_gc.Program(linreg_gc.make_system(3, 64, 56, "cgd", 2, 0.0, 2, 0, 0, 1))
+    assert int(re.search("Number of gates: ([0-9]+)", outs[1][0].decode()).group(1)) == prog.info.total_gates + 31

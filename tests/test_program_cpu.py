@@ -34,6 +34,24 @@ def _plain(lgc, gccpu, sysm, shares):
     return prog, dec
 
 
+def test_dimension_check_program(lgc, gccpu):
+    """the in-circuit comparison of the two parties' dimensions (src/linear.oc:109-114: revealOblivBool(feedOblivInt(d, 1) ==
+    feedOblivInt(d, 2))) as a program of its own: one OP_EQ over two 32-bit input words -- 31 AND gates, what a comparison of
+    two 32-bit words costs the reference -- and one reveal; on the plaintext machine and through CPU garbling + evaluation"""
+    sysm = lgc.make_system(1, 32, 0, "dimcheck", 0, 0.0, 2, 0, 0, 0)
+    prog = lgc.Program(sysm)
+    info = prog.info
+    assert (info.total_gates, info.total_steps, info.n_reveal) == (31, 5, 1)
+    for a, b in ((500, 500), (500, 501), (0, 0), (0, 1 << 31), (0xffffffff, 0xffffffff), (0x80000000, 0), (12345, 12345 ^ (1 << 17))):
+        shares = np.array([[a, 0], [b, 0]], dtype=np.uint64)
+        _, dec = _plain(lgc, gccpu, sysm, shares)
+        assert int(dec[info.rv_beta]) == (1 if a == b else 0), (a, b)
+        got, gates, _ = gccpu.garble_eval(prog, shares, seed=bytes(range(16)))
+        assert gates == 31 and int(got[info.rv_beta]) == (1 if a == b else 0), (a, b)
+    with pytest.raises(lgc.LgcError):
+        lgc.Program(lgc.make_system(2, 32, 0, "dimcheck", 0, 0.0, 2, 0, 0, 0))      # a program of its own: d = 1 only
+
+
 CASES = [(64, 56, 5, 40), (64, 54, 7, 60), (32, 30, 6, 50), (32, 28, 4, 30), (64, 30, 3, 20)]
 
 
