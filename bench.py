@@ -695,20 +695,22 @@ def main():
             warm = phase12_wall(np, "warm-up", 200, 4, [0, 2], "cholesky", 0, ["--table_ring"] + hash_opt, device_index)   # untimed: pages the binaries in
             if warm.get("_check"):
                 _sh.rmtree(warm["_check"]["tmp"], ignore_errors=True)
-            e2e = [phase12_wall(np, "c2", 1000, 20, [0, 10], "cholesky", 0, ["--table_ring"] + hash_opt, device_index),
-                   phase12_wall(np, "c3-ti", 10000, 100, [0, 50], "cgd", 15, ["--ti_ring", "--table_ring"] + hash_opt, device_index),
+            # every party runs on this box, so every bulk message may stay in HBM: --table_ring (garbled tables), --ti_ring / --ot_ring
+            # (phase 1), --input_ring (the label OT of phase 2)
+            e2e = [phase12_wall(np, "c2", 1000, 20, [0, 10], "cholesky", 0, ["--table_ring", "--input_ring"] + hash_opt, device_index),
+                   phase12_wall(np, "c3-ti", 10000, 100, [0, 50], "cgd", 15, ["--ti_ring", "--input_ring", "--table_ring"] + hash_opt, device_index),
                    # BASELINE config 3 proper: --use_ot phase 1 (1.6e9 extended OTs); all parties are on this node,
                    # so the bulk messages of both phases stay in HBM (--ot_ring = --use_ot through device rings)
-                   phase12_wall(np, "c3-ot", 10000, 100, [0, 50], "cgd", 15, ["--ot_ring", "--table_ring"] + hash_opt, device_index),
+                   phase12_wall(np, "c3-ot", 10000, 100, [0, 50], "cgd", 15, ["--ot_ring", "--input_ring", "--table_ring"] + hash_opt, device_index),
                    # config 1: the reference's own example (README.md:81), five processes
-                   phase12_wall(np, "c1", 10, 5, [0, 1, 2], "cgd", 10, ["--ti_ring", "--table_ring"] + hash_opt, device_index,
+                   phase12_wall(np, "c1", 10, 5, [0, 1, 2], "cgd", 10, ["--ti_ring", "--input_ring", "--table_ring"] + hash_opt, device_index,
                                 source=os.path.join(ROOT, "tests", "golden", "readme_example.in"))]
             if not args.no_c4:
                 # config 4: five providers, phase 1 in 64 bits, phase 2 in 32 (every share shifted on its own, phase1.c:609-638).
                 # bin/linreg_testhooks = bin/linreg plus ONE getenv that pins the TI's seed, so that the checker can replay the
                 # TI stream and compare the Result line exactly (what a share-level check needs; tests/test_gpu_configs.py)
                 e2e.append(phase12_wall(np, "c4", 50000, 500, [0, 100, 200, 300, 400], "cgd", 20,
-                                        ["--width_phase2=32", "--prec_phase2=30", "--ti_ring", "--table_ring"] + hash_opt, device_index,
+                                        ["--width_phase2=32", "--prec_phase2=30", "--ti_ring", "--input_ring", "--table_ring"] + hash_opt, device_index,
                                         exe_name="linreg_testhooks", env_extra={"LINREG_TI_SEED": bytes(range(0x60, 0x70)).hex()},
                                         prec2=30, w2=32))
             if (w, p) == (64, 56):

@@ -286,6 +286,12 @@ int lgc_party_garble_ring(lgc_party *p, size_t launch);
 int lgc_party_evaluate_ring(lgc_party *p, size_t launch);
 /* evaluator: the labels a data provider forwarded (dcsSendIntArray -> orecv, input.c:46, 84-92) */
 int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint8_t *labels);
+/* The same two hand-overs with the labels left in HBM (bin/linreg --input_ring: all parties on one node).  The garbler exports a
+ * share's label pairs into two device buffers of its own (input_bits x 16 bytes each; never shared, cleared with
+ * lgc_dev_free_secret) which its OT sender session reads in place (lgc_ot_sender_set_device_io); the evaluator imports the
+ * chosen labels from device memory, e.g. a buffer of the data provider mapped with lgc_dev_open. */
+int lgc_party_input_pairs_dev(lgc_party *p, size_t share, void *d0, void *d1);
+int lgc_party_set_input_labels_dev(lgc_party *p, size_t share, const void *dev_labels);
 int lgc_party_garble(lgc_party *p, size_t launch, uint8_t *tables_out);
 int lgc_party_evaluate(lgc_party *p, size_t launch, const uint8_t *tables_in);
 int lgc_party_decode_bits(lgc_party *p, uint64_t *dec_out);       /* garbler -> evaluator */
@@ -296,6 +302,7 @@ int lgc_party_finish(lgc_party *p, const uint64_t *garbler_dec, int64_t *beta, i
  * u / y between two data providers without the socket (bin/linreg --ot_ring), next to the table ring. */
 int lgc_dev_alloc(int device, size_t bytes, void **ptr, uint8_t handle_out[64] /* or NULL */);
 void lgc_dev_free(void *ptr);
+void lgc_dev_free_secret(void *ptr, size_t bytes);     /* zero-filled first */
 int lgc_dev_open(int device, const uint8_t handle[64], void **ptr);
 void lgc_dev_close(void *ptr);
 int lgc_dev_upload(void *dst_dev, const void *src_host, size_t bytes);

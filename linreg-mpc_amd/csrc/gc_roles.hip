@@ -272,6 +272,22 @@ static int export_labels(lgc_party *p, size_t share, const uint64_t *values, uin
 
     return LGC_OK;
 }
+// the same with the pairs left in device memory of the caller (two buffers of input_bits x 16 bytes on the party's device):
+// the label OT of a provider then reads them where they are (lgc_ot_sender_set_device_io) -- both labels of every input bit
+// never pass through the host.  The caller owns the buffers and clears them before freeing (lgc_dev_free_secret).
+extern "C" int lgc_party_input_pairs_dev(lgc_party *p, size_t share, void *d0, void *d1) {
+    if (!p || !d0 || !d1) return lgc_fail(LGC_EINVAL, "null argument");
+    if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "only the garbler owns label pairs");
+    if (share >= p->P.nshares) return lgc_fail(LGC_EINVAL, "share index out of range");
+    RCHK(hipSetDevice(p->device));
+    const uint32_t n = (uint32_t)(p->P.T + p->P.d);
+    const size_t bits = (size_t)n * p->P.w;
+    hipLaunchKernelGGL(gc_export_pairs_kernel, dim3((unsigned)((bits + 255) / 256)), dim3(256), 0, 0, p->words,
+                       p->P.in_base + (uint32_t)(share * n), n, p->R, p->P.w, (const uint64_t *)0, (Lbl *)d0, (Lbl *)d1);
+    RCHK(hipGetLastError());
+    RCHK(hipDeviceSynchronize());
+    return LGC_OK;
+}
 extern "C" int lgc_party_input_pairs(lgc_party *p, size_t share, uint8_t *m0, uint8_t *m1) {
     if (!p || !m0 || !m1) return lgc_fail(LGC_EINVAL, "null argument");
     return export_labels(p, share, 0, m0, m1);
@@ -279,6 +295,20 @@ extern "C" int lgc_party_input_pairs(lgc_party *p, size_t share, uint8_t *m0, ui
 extern "C" int lgc_party_encode_inputs(lgc_party *p, size_t share, const uint64_t *values, uint8_t *labels_out) {
     if (!p || !values || !labels_out) return lgc_fail(LGC_EINVAL, "null argument");
     return export_labels(p, share, values, labels_out, 0);
+}
+// the same from device memory (input_bits x 16 bytes on the party's device, or a peer-mapped buffer: bin/linreg --input_ring)
+extern "C" int lgc_party_set_input_labels_dev(lgc_party *p, size_t share, const void *dev_labels) {
+    if (!p || !dev_labels) return lgc_fail(LGC_EINVAL, "null argument");
+    if (p->role != LGC_ROLE_EVALUATOR) return lgc_fail(LGC_ESTATE, "only the evaluator imports labels");
+    if (share >= p->P.nshares) return lgc_fail(LGC_EINVAL, "share index out of range");
+    RCHK(hipSetDevice(p->device));
+    const uint32_t n = (uint32_t)(p->P.T + p->P.d);
+    hipLaunchKernelGGL(gc_import_labels_kernel, dim3((unsigned)((n * 64u + 255) / 256)), dim3(256), 0, 0, p->words,
+                       p->P.in_base + (uint32_t)(share * n), n, p->P.w, (const Lbl *)dev_labels);
+    RCHK(hipGetLastError());
+    RCHK(hipDeviceSynchronize());
+    p->labels_ready = true;
+    return LGC_OK;
 }
 extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint8_t *labels) {
     DevFree dev_guard;   // temporary device buffers are released on every return path
@@ -550,6 +580,13 @@ extern "C" int lgc_dev_alloc(int device, size_t bytes, void **ptr, uint8_t handl
     return LGC_OK;
 }
 extern "C" void lgc_dev_free(void *ptr) { if (ptr) (void)hipFree(ptr); }
+// for buffers that held secrets (label pairs): cleared before the memory goes back to the driver
+extern "C" void lgc_dev_free_secret(void *ptr, size_t bytes) {
+    if (!ptr) return;
+    (void)hipMemset(ptr, 0, bytes);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(ptr);
+}
 extern "C" int lgc_dev_open(int device, const uint8_t handle[64], void **ptr) {
     if (!handle || !ptr) return lgc_fail(LGC_EINVAL, "null argument");
     int rc = lgc_need_device(device);

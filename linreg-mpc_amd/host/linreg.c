@@ -101,8 +101,39 @@ static void *warm_main(void *arg) {
  * OT session and page-locked buffers.  The providers are independent of each other; served one after the other, as in
  * rounds 1-3, the label OTs were 20-25 ms of latency EACH on the critical path of every run. */
 typedef struct {
-    node *self; int peer, device, rc; lgc_party *po; size_t share, bits; char err[256]; pthread_t th;
+    node *self; int peer, device, rc, ring; lgc_party *po; size_t share, bits; char err[256]; pthread_t th;
 } input_ot_job;
+/* --input_ring (every party on this node): the messages of the label OT stay in HBM.  The provider owns a device buffer
+ * [u | e] that the CSP maps (hipIpc): it holds what the socket would carry between those two -- the provider's masked columns u,
+ * the CSP's ciphertexts e -- and nothing else; the label PAIRS stay in two device buffers private to the CSP; the chosen labels
+ * go to the Evaluator through a second buffer of the provider's that only the Evaluator maps.  Sockets carry the 64-byte
+ * handles and one-byte tokens.  (config 4: 256 MB per provider that used to cross a socket and PCIe twice.) */
+static int input_ot_ring_csp(input_ot_job *j, lgc_ot_sender *S) {
+    const size_t bits = j->bits, ub = lgc_ot_u_bytes(bits);
+    void *d0 = NULL, *d1 = NULL, *ue = NULL;
+    uint8_t h[64], tok = 1;
+    int rc = 1;
+    if (lgc_ot_sender_set_device_io(S, 1) != LGC_OK) goto out;
+    if (lgc_dev_alloc(j->device, bits * 16, &d0, NULL) != LGC_OK || lgc_dev_alloc(j->device, bits * 16, &d1, NULL) != LGC_OK) goto out;
+    if (lgc_party_input_pairs_dev(j->po, j->share, d0, d1) != LGC_OK) goto out;
+    lgc_trace_mark("input OT: label pairs exported");
+    if (recv_blob(j->self, j->peer, h, sizeof h)) { snprintf(j->err, sizeof j->err, "OT: no buffer handle from party %d", j->peer); goto out2; }
+    if (lgc_dev_open(j->device, h, &ue) != LGC_OK) goto out;
+    lgc_trace_mark("input OT: u received");
+    if (lgc_ot_labels_send(S, d0, d1, bits, ue, (uint8_t *)ue + ub) != LGC_OK) goto out;
+    lgc_trace_mark("input OT: ciphertexts computed");
+    lgc_dev_close(ue); ue = NULL;
+    if (send_blob(j->self, j->peer, &tok, 1)) { snprintf(j->err, sizeof j->err, "OT: could not signal party %d", j->peer); goto out2; }
+    rc = 0;
+    goto out2;
+out:
+    snprintf(j->err, sizeof j->err, "%s", lgc_last_error());
+out2:
+    if (ue) lgc_dev_close(ue);
+    lgc_dev_free_secret(d0, bits * 16);                              /* both labels of every input bit: their XOR is R */
+    lgc_dev_free_secret(d1, bits * 16);
+    return rc;
+}
 static void *input_ot_main(void *arg) {
     input_ot_job *j = arg;
     uint8_t delta[16], seeds[128][16];
@@ -113,6 +144,12 @@ static void *input_ot_main(void *arg) {
 #define JFAIL(...) do { snprintf(j->err, sizeof j->err, __VA_ARGS__); goto out; } while (0)
     if (baseot_ext_sender(j->self, j->peer, delta, seeds)) JFAIL("base OT with party %d failed", j->peer);
     lgc_trace_mark("base OTs done");
+    if (j->ring) {
+        if (lgc_ot_sender_create(&S, j->device, delta, seeds) != LGC_OK) JFAIL("%s", lgc_last_error());
+        if (input_ot_ring_csp(j, S)) goto out;
+        j->rc = 0;
+        goto out;
+    }
     m0 = lgc_host_alloc(bits * 16); m1 = lgc_host_alloc(bits * 16); u = lgc_host_alloc(lgc_ot_u_bytes(bits)); e = lgc_host_alloc(bits * 32);
     if (!m0 || !m1 || !u || !e) JFAIL("%s", lgc_last_error());
     lgc_trace_mark("input OT: page-locked buffers");
@@ -156,6 +193,7 @@ int main(int argc, char **argv) {
           "         --table_lanes=<K>: garbled tables through the network over K extra TCP connections\n"
           "         --ti_ring: (TI mode) all parties on this node: the vectors of the multiplication protocol stay in HBM\n"
           "         --ot_ring: --use_ot with all data providers on this node: the OT extension's messages stay in HBM\n"
+          "         --input_ring: (every party, all on this node) the messages of the label OT of phase 2 stay in HBM\n"
           "         --lambdas=l1,l2,...: regularisation sweep -- one circuit per value on the same shares (the data\n"
           "                  providers share their inputs once); [Lambda] is then ignored\n"
           "         --devices=g0,g1,...: (parties 1 and 2, with --lambdas and --table_ring) contiguous blocks of the sweep on\n"
@@ -179,12 +217,13 @@ int main(int argc, char **argv) {
     check(!errno, "strtod: %s", strerror(errno));
     check(!*end, "lambda must be a number");
 
-    int use_ot = 0, precision_phase2 = -1, w1 = 64, w2 = 64, ring_slots = 0, table_lanes = 0;
+    int use_ot = 0, precision_phase2 = -1, w1 = 64, w2 = 64, ring_slots = 0, table_lanes = 0, input_ring = 0;
     double *lambdas = NULL;                     /* --lambdas: the per-lambda sweep (lambda enters at linear.oc:52-57) */
     size_t n_lambdas = 0;
     for (int i = 7; i < argc; i++) {
         if (!strcmp(argv[i], "--use_ot")) use_ot |= 1;
         else if (!strcmp(argv[i], "--ot_ring")) use_ot |= 3;
+        else if (!strcmp(argv[i], "--input_ring")) input_ring = 1;         /* all parties on this node: the label OT's messages stay in HBM */
         else if (!strcmp(argv[i], "--ti_ring")) protocol_set_ti_ring(1);   /* TI mode, all parties on this node: vectors stay in HBM */      /* --use_ot with u / y of the extension in device rings */
         else if (!strncmp(argv[i], "--lambdas=", 10)) {
             const char *q = argv[i] + 10;
@@ -319,6 +358,7 @@ int main(int argc, char **argv) {
             input_ot_job *j = &jobs[k - 3];
             j->self = self; j->peer = k; j->device = device; j->po = party_obj; j->share = (size_t)(k - 3);
             j->bits = lgc_party_input_bits(party_obj);
+            j->ring = input_ring;
             if (pthread_create(&j->th, NULL, input_ot_main, j)) break;
             started_ot++;
         }
@@ -377,6 +417,18 @@ int main(int argc, char **argv) {
         uint8_t *labels = malloc(bits * 16);
         printf("party %d listening for %d inputs", party, P);
         for (int k = 3; k <= c->num_parties; k++) {
+            if (input_ring) {                                     /* the provider's label buffer, mapped; one byte back when it may go */
+                uint8_t h[64], tok = 1;
+                void *dl = NULL;
+                check(!recv_blob(self, k, h, sizeof h), "could not receive the label buffer of party %d", k);
+                LGC(lgc_dev_open(device, h, &dl));
+                int rc_ = lgc_party_set_input_labels_dev(party_obj, (size_t)(k - 3), dl);
+                lgc_dev_close(dl);
+                check(rc_ == LGC_OK, "%s", lgc_last_error());
+                check(!send_blob(self, k, &tok, 1), "could not release party %d", k);
+                printf("Evaluator received A from party %d\nEvaluator received b from party %d\n", k, k);
+                continue;
+            }
             check(!recv_blob(self, k, labels, bits * 16), "could not receive labels from party %d", k);
             LGC(lgc_party_set_input_labels(party_obj, (size_t)(k - 3), labels));
             printf("Evaluator received A from party %d\nEvaluator received b from party %d\n", k, k);
@@ -491,6 +543,33 @@ int main(int argc, char **argv) {
         LGC(lgc_ot_receiver_create(&R, device, s0, s1));
         TRACE("input OT: receiver session");
         const size_t words = T + d, bits = words * (size_t)w2;
+        if (input_ring) {                                            /* see input_ot_ring_csp */
+            const size_t ub = lgc_ot_u_bytes(bits);
+            uint8_t *selh = malloc(bits), hue[64], hl[64], tok = 0;
+            void *dsel = NULL, *due = NULL, *dl = NULL;
+            for (size_t i = 0; i < words; i++) {
+                uint64_t v = i < T ? share_A[i] : share_b[i - T];
+                for (int j = 0; j < w2; j++) selh[i * (size_t)w2 + (size_t)j] = (uint8_t)((v >> j) & 1);
+            }
+            LGC(lgc_ot_receiver_set_device_io(R, 1));
+            LGC(lgc_dev_alloc(device, bits, &dsel, NULL));
+            LGC(lgc_dev_alloc(device, ub + bits * 32, &due, hue));
+            LGC(lgc_dev_alloc(device, bits * 16, &dl, hl));
+            LGC(lgc_dev_upload(dsel, selh, bits));
+            OPENSSL_cleanse(selh, bits); free(selh);
+            LGC(lgc_ot_labels_recv_start(R, dsel, bits, due));
+            check(!send_blob(self, 1, hue, sizeof hue), "OT: could not hand the buffer to the CSP");
+            TRACE("input OT: u sent");
+            check(!recv_blob(self, 1, &tok, 1), "OT: the CSP did not answer");
+            TRACE("input OT: ciphertexts received");
+            LGC(lgc_ot_labels_recv_finish(R, (uint8_t *)due + ub, dl));
+            check(!send_blob(self, 2, hl, sizeof hl), "could not hand the labels to the Evaluator");   /* input.c:46 */
+            check(!recv_blob(self, 2, &tok, 1), "the Evaluator did not take the labels");
+            TRACE("labels forwarded to the Evaluator");
+            lgc_ot_receiver_destroy(R);
+            lgc_dev_free_secret(dsel, bits); lgc_dev_free(due); lgc_dev_free_secret(dl, bits * 16);
+            goto done;
+        }
         uint8_t *sel = malloc(bits), *u = malloc(lgc_ot_u_bytes(bits)), *e = malloc(bits * 32), *labels = malloc(bits * 16);
         for (size_t i = 0; i < words; i++) {                         /* sel[i*intsize+j] = (input[i]>>j)&1 (input.c:41) */
             uint64_t v = i < T ? share_A[i] : share_b[i - T];

@@ -18,11 +18,12 @@ def main():
     a = ap.parse_args()
     if a.root:
         bench.LINREG_EXE = os.path.join(os.path.abspath(a.root), "host", "bin", "linreg")
-    cfgs = {"c2": (1000, 20, [0, 10], "cholesky", 0, ["--table_ring"]),
-            "c3-ti": (10000, 100, [0, 50], "cgd", 15, ["--ti_ring", "--table_ring"]),
-            "c3-ot": (10000, 100, [0, 50], "cgd", 15, ["--ot_ring", "--table_ring"]),
-            "c1": (10, 5, [0, 1, 2], "cgd", 10, ["--ti_ring", "--table_ring"], dict(source=os.path.join(ROOT, "tests", "golden", "readme_example.in"))),
-            "c4": (50000, 500, [0, 100, 200, 300, 400], "cgd", 20, ["--width_phase2=32", "--prec_phase2=30", "--ti_ring", "--table_ring"],
+    IR = [] if os.environ.get("PROBE_NO_INPUT_RING") else ["--input_ring"]
+    cfgs = {"c2": (1000, 20, [0, 10], "cholesky", 0, ["--table_ring"] + IR),
+            "c3-ti": (10000, 100, [0, 50], "cgd", 15, ["--ti_ring", "--table_ring"] + IR),
+            "c3-ot": (10000, 100, [0, 50], "cgd", 15, ["--ot_ring", "--table_ring"] + IR),
+            "c1": (10, 5, [0, 1, 2], "cgd", 10, ["--ti_ring", "--table_ring"] + IR, dict(source=os.path.join(ROOT, "tests", "golden", "readme_example.in"))),
+            "c4": (50000, 500, [0, 100, 200, 300, 400], "cgd", 20, ["--width_phase2=32", "--prec_phase2=30", "--ti_ring", "--table_ring"] + IR,
                    dict(prec2=30, w2=32))}
     bench.phase12_wall(np, "warm-up", 200, 4, [0, 2], "cholesky", 0, ["--table_ring"], 0)
     out = []

@@ -44,21 +44,21 @@ def _write_instance(path, n, d, starts, seed):
     return X, y
 
 
-@pytest.mark.parametrize("ot", ["--use_ot", "--ot_ring"])
+@pytest.mark.parametrize("ot", ["--use_ot", "--ot_ring", "--ot_ring --input_ring"])
 def test_config3_use_ot_full_size(tmp_path, oracle, ot):
     """bin/linreg <file> 56 <party> cgd 15 0.001 --use_ot --table_ring with n = 1e4, d = 100, P = 2
     (--ot_ring: the 39 GB of OT-extension messages between the two providers stay in HBM)"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     path = str(tmp_path / "c3.in")
     _write_instance(path, 10000, 100, [0, 50], 3)
-    outs = _run_all(path, 2, ["56", "cgd", "15", "0.001", ot, "--table_ring"], timeout=900)
+    outs = _run_all(path, 2, ["56", "cgd", "15", "0.001"] + ot.split() + ["--table_ring"], timeout=900)
     got = re.findall("-?[0-9]+\\.[0-9]+", outs[1].strip().splitlines()[-1])
     beta = oracle.linreg_file(path, 56, -1, 64, 64, 2, 15, 0.001)
     assert got == ["%.15f" % (int(v) / 2.0 ** 56) for v in beta]
     assert "Number of gates:" in outs[1]
 
 
-@pytest.mark.parametrize("ring", [[], ["--ti_ring"]], ids=["sockets", "ti-ring"])
+@pytest.mark.parametrize("ring", [[], ["--ti_ring"], ["--ti_ring", "--input_ring"]], ids=["sockets", "ti-ring", "ti-and-input-ring"])
 def test_config4_five_providers_64_32_split_share_level(tmp_path, oracle, gccpu, ring):
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     n, d, starts = 50000, 500, [0, 100, 200, 300, 400]

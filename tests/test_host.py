@@ -119,8 +119,9 @@ README_RESULT = ["0.984331027786964", "0.792399824970372", "0.754117840176144", 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--use_ot"], ["--table_ring"], ["--ot_ring", "--table_ring"], ["--ti_ring", "--table_ring"],
-                                   ["--table_lanes=4"], ["--gate_hash=chaskey12"], ["--gate_hash=chaskey12", "--table_ring"]],
-                         ids=["ti", "ot", "table-ring", "ot-ring", "ti-ring", "table-lanes", "chaskey", "chaskey-ring"])
+                                   ["--table_lanes=4"], ["--gate_hash=chaskey12"], ["--gate_hash=chaskey12", "--table_ring"],
+                                   ["--input_ring"], ["--ti_ring", "--input_ring", "--table_ring"]],
+                         ids=["ti", "ot", "table-ring", "ot-ring", "ti-ring", "table-lanes", "chaskey", "chaskey-ring", "input-ring", "all-rings"])
 def test_five_process_readme_example(tmp_path, golden_dir, extra):
     """bin/linreg examples/readme_example.in 56 $party cgd 10 0.001 (README.md:81) -> README.md:87"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
