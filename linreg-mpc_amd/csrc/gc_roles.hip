@@ -10,7 +10,9 @@
 //               party 2 only, cgd.oc:206-208)
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <time.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/linreg_gc.h"
@@ -388,8 +390,26 @@ extern "C" int lgc_party_evaluate(lgc_party *p, size_t launch, const uint8_t *ta
 }
 // ---- table ring (device-resident hand-off; replaces the osend/orecv byte stream of the Yao
 // protocol when both roles run on one node)
+// hipIpcGetMemHandle / hipIpcOpenMemHandle from two threads of one process at once fail now and then with "invalid argument"
+// (seen once bin/linreg built its garbler -- table ring -- on a thread beside the trusted initializer's per-provider rings):
+// one IPC call at a time per process
+static std::mutex &ipc_mutex() { static std::mutex m; return m; }
+// ... and hipIpcGetMemHandle itself fails transiently ("invalid argument", about once in a hundred five-process runs) while
+// another thread of the process allocates or launches: tried again a few times before it counts
+static hipError_t ipc_get_handle(hipIpcMemHandle_t *h, void *ptr) {
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        e = hipIpcGetMemHandle(h, ptr);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+        struct timespec ts = {0, 2000000};
+        nanosleep(&ts, 0);
+    }
+    return e;
+}
 static int ring_alloc_export(lgc_party *p, size_t bytes, uint8_t handle_out[64]) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    std::lock_guard<std::mutex> ipc_lock(ipc_mutex());
     RCHK(hipSetDevice(p->device));
     hipError_t e = hipMalloc(&p->ring, bytes);
     if (e != hipSuccess) return lgc_fail(LGC_ENOMEM, "hipMalloc(table ring, %zu bytes): %s", bytes, hipGetErrorString(e));
@@ -398,7 +418,7 @@ static int ring_alloc_export(lgc_party *p, size_t bytes, uint8_t handle_out[64])
     e = hipMemset(p->ring, 0, bytes);
     if (e != hipSuccess) { (void)hipFree(p->ring); p->ring = 0; return lgc_fail(LGC_EHIP, "hipMemset(table ring): %s", hipGetErrorString(e)); }
     hipIpcMemHandle_t h;
-    e = hipIpcGetMemHandle(&h, p->ring);
+    e = ipc_get_handle(&h, p->ring);
     if (e != hipSuccess) {
         (void)hipFree(p->ring); p->ring = 0;
         return lgc_fail(LGC_EHIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
@@ -412,6 +432,7 @@ static int ring_alloc_export(lgc_party *p, size_t bytes, uint8_t handle_out[64])
     return LGC_OK;
 }
 static int ring_map(lgc_party *p, const uint8_t handle[64]) {
+    std::lock_guard<std::mutex> ipc_lock(ipc_mutex());
     RCHK(hipSetDevice(p->device));
     hipIpcMemHandle_t h;
     memcpy(&h, handle, 64);
@@ -567,12 +588,13 @@ extern "C" int lgc_dev_alloc(int device, size_t bytes, void **ptr, uint8_t handl
     int rc = lgc_need_device(device);
     if (rc) return rc;
     void *p = 0;
+    std::lock_guard<std::mutex> ipc_lock(ipc_mutex());
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return lgc_fail(LGC_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     e = hipMemset(p, 0, bytes);
     if (e == hipSuccess && handle_out) {
         hipIpcMemHandle_t h;
-        e = hipIpcGetMemHandle(&h, p);
+        e = ipc_get_handle(&h, p);
         if (e == hipSuccess) memcpy(handle_out, &h, 64);
     }
     if (e != hipSuccess) { (void)hipFree(p); return lgc_fail(LGC_EHIP, "lgc_dev_alloc: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e)); }
@@ -594,12 +616,17 @@ extern "C" int lgc_dev_open(int device, const uint8_t handle[64], void **ptr) {
     hipIpcMemHandle_t h;
     memcpy(&h, handle, 64);
     void *p = 0;
+    std::lock_guard<std::mutex> ipc_lock(ipc_mutex());
     hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) return lgc_fail(LGC_EHIP, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
     *ptr = p;
     return LGC_OK;
 }
-extern "C" void lgc_dev_close(void *ptr) { if (ptr) (void)hipIpcCloseMemHandle(ptr); }
+extern "C" void lgc_dev_close(void *ptr) {
+    if (!ptr) return;
+    std::lock_guard<std::mutex> ipc_lock(ipc_mutex());
+    (void)hipIpcCloseMemHandle(ptr);
+}
 extern "C" int lgc_dev_upload(void *dst_dev, const void *src_host, size_t bytes) {
     if (!dst_dev || !src_host) return lgc_fail(LGC_EINVAL, "null argument");
     RCHK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <openssl/crypto.h>
 #include <openssl/rand.h>
+#include <poll.h>
 #include <pthread.h>
 #include <signal.h>
 #include <stdio.h>
@@ -77,18 +78,46 @@ static void *create_main(void *arg) {
     else JLGC(lgc_party_create(&j->party_obj, j->device, &j->sys, j->role, seedp, j->table_chunk));
 #undef JLGC
     OPENSSL_cleanse(seed, sizeof seed);
-    if (j->role == LGC_ROLE_GARBLER && j->ring_slots > 0) {        /* the ring(s) now, not on the evaluator's clock */
-        for (int k = 0; k < (j->n_devices ? j->n_devices : 1); k++)
-            if (tables_ring_prepare(j->n_devices ? j->blocks[k] : j->party_obj, j->ring_slots)) {
-                snprintf(j->err, sizeof j->err, "could not create table ring %d", k);
-                return NULL;
-            }
-    }
+    /* (the table ring is NOT created here: hipIpcGetMemHandle on this thread, beside the initializer's own allocations and
+     * exports on the main thread, failed with "invalid argument" in up to a third of the five-process runs on some boxes --
+     * the main thread creates it after phase 1, create_rings below: a millisecond for a byte ring) */
     lgc_trace_mark(j->role == LGC_ROLE_GARBLER ? "garbler created" : "evaluator created");
     j->rc = 0;
     return NULL;
 }
+static int create_rings(create_job *j) {                            /* the garbler's ring(s), before the Evaluator asks for them */
+    if (j->role != LGC_ROLE_GARBLER || j->ring_slots <= 0) return 0;
+    for (int k = 0; k < (j->n_devices ? j->n_devices : 1); k++)
+        if (tables_ring_prepare(j->n_devices ? j->blocks[k] : j->party_obj, j->ring_slots)) {
+            snprintf(j->err, sizeof j->err, "could not create table ring %d", k);
+            return 1;
+        }
+    return 0;
+}
 /* the HIP runtime and the device context come up on a thread of their own while main parses, connects and reads */
+/* The CSP and the Evaluator live until the end of the protocol.  When one of them is gone -- its connection hung up -- the
+ * other normally notices in its next recv() and leaves through check(); but it may sit in a call that never returns once the
+ * peer is dead (seen: hipIpcOpenMemHandle on the ring of a CSP killed a moment earlier; a test of tests/test_host.py hit that
+ * window once in six runs).  A watchdog thread polls the connection and, five seconds after a hang-up that the main thread has
+ * not dealt with, ends the process with the reference's exit code for every failure (src/cmd/linreg.c:206-211). */
+static volatile int g_protocol_over;      /* 1: results are out, cleaning up; 2: main is about to return */
+typedef struct { int fd, party, peer; } watchdog_arg;
+static void *peer_watchdog(void *arg) {
+    watchdog_arg *w = arg;
+    struct pollfd pf = {w->fd, POLLRDHUP, 0};
+    for (;;) {
+        if (g_protocol_over >= 2) return NULL;
+        pf.revents = 0;
+        int r = poll(&pf, 1, 250);
+        if (r > 0 && (pf.revents & (POLLRDHUP | POLLHUP | POLLERR | POLLNVAL))) break;
+    }
+    for (int i = 0; i < 20 && g_protocol_over < 2; i++) usleep(250000);
+    if (g_protocol_over >= 2) return NULL;
+    if (g_protocol_over == 1) { fflush(stdout); _exit(0); }          /* the protocol was through: only the clean-up is stuck */
+    fprintf(stderr, "party %d: party %d is gone and this party is stuck in a call that does not return; giving up\n", w->party, w->peer);
+    _exit(1);
+}
+
 static int g_warm_what;
 static void *warm_main(void *arg) {
     int device = *(int *)arg;
@@ -301,6 +330,12 @@ int main(int argc, char **argv) {
     status = node_new(&self, party, c->num_parties, c->endpoint);
     check(!status, "Could not create node");
     TRACE("connected");
+    static watchdog_arg wd;
+    if (party <= 2) {                                                /* parties 1 and 2 watch each other's connection */
+        pthread_t wt;
+        wd.fd = self->fd[(3 - party) - 1]; wd.party = party; wd.peer = 3 - party;
+        if (wd.fd >= 0 && !pthread_create(&wt, NULL, peer_watchdog, &wd)) pthread_detach(wt);
+    }
 
     /* the phase-2 system: known from the configuration before any protocol message */
     const int precision2 = precision_phase2 != -1 ? precision_phase2 : precision;
@@ -351,6 +386,7 @@ int main(int argc, char **argv) {
         cj.started = 0;
         check(!cj.rc, "%s", cj.err);
         party_obj = cj.party_obj;
+        check(!create_rings(&cj), "%s", cj.err);
         input_ot_job *jobs = calloc((size_t)P, sizeof *jobs);
         check(jobs != NULL, "out of memory");
         int started_ot = 0, bad_ot = 0;
@@ -588,6 +624,7 @@ int main(int argc, char **argv) {
     }
 
 done:
+    g_protocol_over = 1;
     TRACE("protocol done");
     for (int k = 1; k < n_devices; k++) if (blocks[k]) lgc_party_destroy(blocks[k]);
     if (party_obj) lgc_party_destroy(party_obj);           /* (wipes label material before its memory is released) */
@@ -596,6 +633,7 @@ done:
     free(share_A);
     free(share_b);
     free(lambdas);
+    g_protocol_over = 2;
     TRACE("exit");
     /* (leaving through _exit() to skip the HIP runtime's exit handlers -- 70-80 ms per process -- was measured and is WORSE:
      * the kernel driver then tears the process's queues and mappings down by itself, 250 ms for config 2) */
@@ -608,5 +646,6 @@ error:
     node_destroy(&self);
     free(share_A);
     free(share_b);
+    g_protocol_over = 2;
     return 1;
 }

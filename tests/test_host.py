@@ -527,7 +527,8 @@ def test_a_lost_party_makes_the_others_exit_nonzero_in_bounded_time(tmp_path, vi
                 pass
     outs = [p.communicate() for p in procs]
     assert procs[victim - 1].returncode == -signal.SIGKILL, (procs[victim - 1].returncode, outs[victim - 1][1].decode()[-400:])
-    assert not hung, "parties %s still ran 10 s after party %d was lost" % (hung, victim)
+    assert not hung, "parties %s still ran 10 s after party %d was lost; their last marks: %s" % (
+        hung, victim, {k: outs[k - 1][1].decode()[-700:] for k in hung})
     for k in must_fail:
         assert procs[k - 1].returncode not in (0, None) and procs[k - 1].returncode > 0, \
             "party %d: rc %s, stderr %s" % (k, procs[k - 1].returncode, outs[k - 1][1].decode()[-400:])
