@@ -611,10 +611,16 @@ static size_t enumerate_cross(config *c, xpair **out) {
     return np;
 }
 enum { kTiRingSlots = 3 };
+/* pairs per batch: a batch costs every party a fixed ~0.5 ms of tokens and device synchronisations whatever its size, and
+ * config 4 has 1e5 pairs of 5e4 words -- with 64 MiB slots (167 pairs, 602 batches; rounds 2-3) its phase 1 was 0.55 s of
+ * which two thirds were those fixed costs.  LINREG_TI_SLOT_MB overrides the slot size (experiments). */
 static size_t ti_ring_batch(size_t n) {
-    size_t b = ((size_t)64 << 20) / (n * 8);
+    size_t slot_mb = 256;
+    const char *e = getenv("LINREG_TI_SLOT_MB");
+    if (e && atoi(e) > 0) slot_mb = (size_t)atoi(e);
+    size_t b = (slot_mb << 20) / (n * 8);
     if (b < 1) b = 1;
-    if (b > 256) b = 256;
+    if (b > 1024) b = 1024;
     return b;
 }
 static int tok_send(node *self, int to, char t) { return net_send(self, to, &t, 1); }
