@@ -138,7 +138,7 @@ def test_a_role_with_the_other_hash_does_not_decode(lgc, oracle):
     finally:
         lgc.set_gate_hash("aes128")
     E = lgc.Party(sysm, lgc.EVALUATOR)
-    # what the host binaries compare before the first table moves (host/protocol.c: programs_agree)
+    # what the host binaries compare before the first table moves (host/tables.c: programs_agree)
     assert G.program_fingerprint() == E1.program_fingerprint() != E.program_fingerprint()
     E1.close()
     E2 = lgc.Party(lgc.make_system(d, w, p, "cholesky", 0, 0.5, 2, 1, 0, 0), lgc.EVALUATOR)     # another lambda

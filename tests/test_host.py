@@ -142,7 +142,7 @@ def test_five_process_readme_example(tmp_path, golden_dir, extra):
 @pytest.mark.parametrize("odd", [["--gate_hash=chaskey12"], ["--prec_phase2=50"]], ids=["gate-hash", "precision"])
 def test_an_option_given_to_one_party_only_is_an_error_not_a_wrong_result(tmp_path, golden_dir, odd):
     """the CSP and the Evaluator compare the fingerprints of their programs before the first table moves
-    (host/protocol.c: programs_agree): party 1 alone gets the extra option"""
+    (host/tables.c: programs_agree): party 1 alone gets the extra option"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     infile = str(tmp_path / "readme.in")
     P = _rewrite_ports(os.path.join(golden_dir, "readme_example.in"), infile)
