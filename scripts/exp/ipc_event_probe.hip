@@ -9,6 +9,7 @@
 #include <string.h>
 #include <unistd.h>
 #include <sys/wait.h>
+#include <time.h>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (line %d, pid %d)\n", #x, hipGetErrorString(e_), __LINE__, getpid()); exit(2); } } while (0)
 static void rd(int fd, void *p, size_t n) { char *c = (char *)p; while (n) { ssize_t k = read(fd, c, n); if (k <= 0) { fprintf(stderr, "pipe closed\n"); exit(3); } c += k; n -= (size_t)k; } }
 static void wr(int fd, const void *p, size_t n) { if (write(fd, p, n) != (ssize_t)n) { fprintf(stderr, "pipe write\n"); exit(3); } }
@@ -31,7 +32,10 @@ int main() {
         hipIpcMemHandle_t mh; rd(ab[0], &mh, sizeof mh);
         unsigned *buf; CK(hipIpcOpenMemHandle((void **)&buf, mh, hipIpcMemLazyEnablePeerAccess));
         hipIpcEventHandle_t eh[K]; hipEvent_t ev[K];
+        struct timespec ta, tb; clock_gettime(CLOCK_MONOTONIC, &ta);
         for (int k = 0; k < K; k++) { rd(ab[0], &eh[k], sizeof eh[k]); CK(hipIpcOpenEventHandle(&ev[k], eh[k])); }
+        clock_gettime(CLOCK_MONOTONIC, &tb);
+        printf("consumer: %d event handles received + opened in %.2f ms\n", K, ((tb.tv_sec - ta.tv_sec) * 1e3 + (tb.tv_nsec - ta.tv_nsec) * 1e-6));
         unsigned *bad; CK(hipMalloc(&bad, 4)); CK(hipMemset(bad, 0, 4));
         unsigned total_bad = 0;
         for (int r = 0; r < ROUNDS; r++) {
@@ -61,6 +65,22 @@ int main() {
         rd(ba[0], &go, 1);
     }
     CK(hipDeviceSynchronize());
+    {   // what a pool of events costs: create + export (the consumer's open is timed in the first loop above per event too)
+        struct timespec a, b; clock_gettime(CLOCK_MONOTONIC, &a);
+        const int M = 1000; static hipEvent_t pool[1000];
+        for (int k = 0; k < M; k++) { CK(hipEventCreateWithFlags(&pool[k], hipEventDisableTiming | hipEventInterprocess)); hipIpcEventHandle_t eh; CK(hipIpcGetEventHandle(&eh, pool[k])); }
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        printf("producer: %d interprocess events created + exported in %.2f ms\n", M, ((b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6));
+        clock_gettime(CLOCK_MONOTONIC, &a);
+        for (int k = 0; k < M; k++) CK(hipEventRecord(pool[k], st));
+        CK(hipStreamSynchronize(st));
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        printf("producer: %d records + sync in %.2f ms\n", M, ((b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6));
+        clock_gettime(CLOCK_MONOTONIC, &a);
+        for (int k = 0; k < M; k++) CK(hipEventDestroy(pool[k]));
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        printf("producer: %d destroyed in %.2f ms\n", M, ((b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6));
+    }
     int stt = 0; waitpid(pid, &stt, 0);
     printf("producer done; consumer exit %d\n", WIFEXITED(stt) ? WEXITSTATUS(stt) : -1);
     return WIFEXITED(stt) ? WEXITSTATUS(stt) : 5;
