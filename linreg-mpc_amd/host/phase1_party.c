@@ -630,8 +630,13 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
                     if (pj == last) { ri[q] = i; rj[q++] = d; }
                 }
                 if (pi == last) for (size_t j = j0; j < j1; j++) { ri[q] = d; rj[q++] = j; }
-                /* batches of pairs: at most 2^25 OTs (512 MiB of u) each, two in flight on the receiver side */
-                size_t per = ((size_t)1 << 25) / (n * (size_t)w1);
+                /* batches of pairs: at most 2^24 OTs (256 MiB of u) each, two in flight on the receiver side.  Measured on config 3
+                 * (1.6e9 OTs between two provider processes on one GPU, scripts/exp/ot_batch_ab.sh): phase 1 through at 0.46 s with
+                 * 2^24, 0.58 s with 2^25 (rounds 2-3), 0.8 / 1.2 / 2.2 s with 2^26..28 -- the session's buffers grow with the batch
+                 * and a fresh device or page-locked allocation costs more than the per-batch tokens do */
+                int ot_log = 24;
+                { const char *e_ = getenv("LINREG_OT_BATCH_LOG2"); if (e_ && atoi(e_) >= 20 && atoi(e_) <= 30) ot_log = atoi(e_); }   /* experiments */
+                size_t per = ((size_t)1 << ot_log) / (n * (size_t)w1);
                 if (per < 1) per = 1;
                 if (per > npairs) per = npairs;
                 uint64_t *vals = lgc_host_alloc(per * n * 8), *shares = malloc(npairs * 8);
