@@ -29,7 +29,7 @@ python3 scripts/gpu_launch_profile.py 500 cgd 20 32 30 > $O/launch_profile_d500_
 python3 scripts/gpu_probe.py mid big > $O/probe.txt 2>&1
 # round 4: start-up timelines of the end-to-end runs, the integer VALU issue rates, where a level of the column-split kernel
 # goes (GC_SPLIT_TRACE build, if scripts/exp/libs/lib_strace.so was built), the HIP runtime's start / exit cost
-python3 scripts/startup_probe.py --configs c2,c3-ti,c3-ot,c1,c4 --reps 2 --out $O/startup_timeline.json > $O/startup_timeline.txt 2>&1
+python3 scripts/startup_probe.py --configs c2,c3-ti,c3-ot,c1,c4 --reps 5 --out $O/startup_timeline.json > $O/startup_timeline.txt 2>&1
 [ -x scripts/exp/bin/valu_issue ] && scripts/exp/bin/valu_issue > $O/valu_issue.txt 2>&1
 [ -f scripts/exp/libs/lib_strace.so ] && LGC_LIB=$R/scripts/exp/libs/lib_strace.so python3 scripts/exp/split_trace.py > $O/split_trace.txt 2>&1
 [ -x scripts/exp/bin/hip_init_probe ] && bash scripts/exp/hip_init_ab.sh > $O/hip_init.txt 2>&1
