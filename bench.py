@@ -217,8 +217,20 @@ def startup_timeline(stderrs, m0):
             "marks": marks}
 
 
-def phase12_wall(np, name, n, d, starts, alg, iters, extra, device_index, prec=56, source=None, exe_name="linreg", env_extra=None,
-                 prec2=None, w2=64):
+def phase12_wall(*a, **kw):
+    """phase12_wall_once, run again ONCE if a party failed (the runs share the box with whatever else is on it; a failed
+    attempt is reported, not hidden: `attempts`, `first_error`)"""
+    r = phase12_wall_once(*a, **kw)
+    if "error" in r and "not built" not in str(r.get("error")):
+        first = r["error"]
+        r = phase12_wall_once(*a, **kw)
+        r["attempts"] = 2
+        r["first_error"] = first
+    return r
+
+
+def phase12_wall_once(np, name, n, d, starts, alg, iters, extra, device_index, prec=56, source=None, exe_name="linreg", env_extra=None,
+                      prec2=None, w2=64):
     """phases 1 + 2 end to end through bin/linreg, every party its own process on this box (the second
     half of the metric string): synthetic instance of experiments/generate_tests.py:159-169 (or the input file `source`
     with fresh ports: config 1), wall-clock from the first spawn to the last exit (the Result line is compared with the
@@ -279,6 +291,8 @@ def phase12_wall(np, name, n, d, starts, alg, iters, extra, device_index, prec=5
         for q in procs:
             if q.poll() is None:
                 q.kill()
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
         return {"config": name, "error": "timed out"}
     outs = []
     for fo, fe in logs:
@@ -289,6 +303,8 @@ def phase12_wall(np, name, n, d, starts, alg, iters, extra, device_index, prec=5
            "phase12_wall_s": wall, "processes": len(procs)}
     if any(q.returncode != 0 for q in procs):
         res["error"] = outs[[q.returncode != 0 for q in procs].index(True)][1].decode()[-300:]
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
         return res
     res["timeline"] = startup_timeline([o[1].decode(errors="replace") for o in outs], m0)
     # when each process was gone (waitpid returned): the gap to its "exit" mark is the HIP runtime's and the driver's teardown
