@@ -220,6 +220,7 @@ def startup_timeline(stderrs, m0):
 def phase12_wall(*a, **kw):
     """phase12_wall_once, run again ONCE if a party failed (the runs share the box with whatever else is on it; a failed
     attempt is reported, not hidden: `attempts`, `first_error`)"""
+    time.sleep(1.0)          # (the previous run's device memory is being wiped by the driver: see main)
     r = phase12_wall_once(*a, **kw)
     if "error" in r and "not built" not in str(r.get("error")):
         first = r["error"]
@@ -641,6 +642,11 @@ def main():
                 sweep_res["model"] = sweep_model(np, sweep, sshares, lams, sd, make, sdt, sst)
 
     lgc.release_cached_memory()          # the separate-process runs below bring their own rings
+    if world == 1 and not args.no_e2e:
+        # the driver wipes released device memory in the background (tens of GB here) and an allocation made meanwhile may wait
+        # for it (profiles/r4_hip_exit.txt: 0.25 s for 11 GB taken right after 11 GB were freed, 0.3 ms two seconds later):
+        # let it finish before the end-to-end runs start, and give every run's own memory a moment as well (phase12_wall)
+        time.sleep(4.0)
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel (garbling of the MAC launches), HIP events on its stream
