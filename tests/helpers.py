@@ -42,3 +42,31 @@ def sx(v, w):
     if w == 32:
         return v.astype(np.uint32).astype(np.int32).astype(np.int64)
     return v.astype(np.int64)
+
+
+def openssl_gate_hash(labels, tweaks):
+    """The fixed-key AES gate hash H(x, t) = AES_k(sigma(x) ^ t) ^ sigma(x) ^ t, sigma(xL || xR) = (xL ^ xR) || xL, written
+    here from its definition over OpenSSL's AES-128 (libcrypto through ctypes): shares no line with the product's T-table AES
+    or with oracle/gc_cpu.cpp (which is compiled from the product's headers), so agreement is an independent check of both.
+    labels (n, 16) uint8, tweaks (n,) uint64 in the low half.  Key: FIPS-197 Appendix B (the build's fixed public key)."""
+    import ctypes
+    import ctypes.util
+    import numpy as np
+    crypto = ctypes.CDLL(ctypes.util.find_library("crypto") or "libcrypto.so.3")
+    key = bytes.fromhex("2b7e151628aed2a6abf7158809cf4f3c")
+    sched = ctypes.create_string_buffer(256)                           # AES_KEY
+    assert crypto.AES_set_encrypt_key(key, 128, sched) == 0
+    x = np.ascontiguousarray(labels, dtype=np.uint8).reshape(-1, 16)
+    out = np.zeros_like(x)
+    inb, outb = ctypes.create_string_buffer(16), ctypes.create_string_buffer(16)
+    for i in range(len(x)):
+        # the label is a little-endian 128-bit number: xL = its HIGH half (bytes 8..15), xR = its low half (bytes 0..7);
+        # sigma(x) = (xL ^ xR) || xL has xL ^ xR in the high half and xL in the low half; the 64-bit tweak goes into the low half
+        xl, xr = x[i, 8:], x[i, :8]
+        k = np.concatenate([xl, xl ^ xr])
+        tw = np.frombuffer(int(tweaks[i]).to_bytes(8, "little"), dtype=np.uint8)
+        k[:8] ^= tw
+        ctypes.memmove(inb, k.tobytes(), 16)
+        crypto.AES_encrypt(inb, outb, sched)
+        out[i] = np.frombuffer(outb.raw, dtype=np.uint8) ^ k
+    return out

@@ -130,3 +130,85 @@ def test_split_and_four_wave_kernels_are_interchangeable(lgc, oracle, w, p, alg)
             s.close()
     finally:
         lgc.set_split_kernels(1, 1)
+
+
+def test_gate_hash_on_device_matches_openssl(lgc):
+    """the T-table AES of the kernels (LDS tables built at compile time, v_perm addressing) inside the gate hash, against the
+    hash written from its definition over OpenSSL's AES (tests/helpers.py): nothing shared with the product or its CPU mirror.
+    And one AND gate garbled and evaluated by hand with that hash obeys the half-gates equations the kernels implement
+    (ZRE15): what the evaluator computes from (a, b, TG, TE) is c0 ^ (va & vb) R."""
+    from helpers import openssl_gate_hash
+    rng = np.random.default_rng(9)
+    x = rng.integers(0, 256, size=(2048 + 3, 16), dtype=np.uint8)
+    t = rng.integers(0, 2 ** 63, size=len(x), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=len(x), dtype=np.uint64)
+    x[0] = 0; t[0] = 0
+    assert np.array_equal(lgc.gate_hash_eval(0, x, t), openssl_gate_hash(x, t))
+    # half-gates by hand, hashes from the DEVICE: garbler side
+    R = rng.integers(0, 256, size=16, dtype=np.uint8); R[0] |= 1
+    a0 = rng.integers(0, 256, size=16, dtype=np.uint8); b0 = rng.integers(0, 256, size=16, dtype=np.uint8)
+    gid = 123456789
+    H = lambda lab, tw: lgc.gate_hash_eval(0, lab[None, :], np.array([tw], dtype=np.uint64))[0]
+    pa, pb = int(a0[0] & 1), int(b0[0] & 1)
+    h0, h1, h2, h3 = H(a0, 2 * gid), H(a0 ^ R, 2 * gid), H(b0, 2 * gid + 1), H(b0 ^ R, 2 * gid + 1)
+    TG = h0 ^ h1 ^ (R if pb else 0 * R)
+    WG = h0 ^ (TG if pa else 0 * TG)
+    TE = h2 ^ h3 ^ a0
+    WE = h2 ^ ((TE ^ a0) if pb else 0 * TE)
+    c0 = WG ^ WE
+    for va in (0, 1):
+        for vb in (0, 1):
+            a = a0 ^ (R if va else 0 * R); b = b0 ^ (R if vb else 0 * R)
+            sa, sb = int(a[0] & 1), int(b[0] & 1)
+            got = openssl_gate_hash(a[None, :], [2 * gid])[0] ^ (TG if sa else 0 * TG) ^ openssl_gate_hash(b[None, :], [2 * gid + 1])[0] ^ ((TE ^ a) if sb else 0 * TE)
+            assert np.array_equal(got, c0 ^ (R if (va & vb) else 0 * R)), (va, vb)
+
+
+def test_garbled_tables_of_a_circuit_match_half_gates_written_over_openssl(lgc):
+    """Label-level check that shares nothing with the product: the 31-gate dimension comparison (LGC_ALG_DIMCHECK, OP_EQ) is
+    garbled on the GPU, and every ciphertext row of its five gate steps is recomputed here from the garbler's input label pairs
+    with half-gates (ZRE15) written over OpenSSL's AES -- the hash, the tweak numbering gid = 64 step + lane, the (TG, TE) row
+    layout, the free-XOR glue and lane moves of the circuit, and the chaining of output labels from step to step.
+    (oracle/gc_cpu.cpp cannot give that: it is compiled from the product's headers.)"""
+    from helpers import openssl_gate_hash
+    sysm = lgc.make_system(1, 32, 0, "dimcheck", 0, 0.0, 2, 0, 0, 0)
+    prog = lgc.Program(sysm)
+    G = lgc.Party(sysm, 1, seed=bytes(range(32, 48)))
+    A0, A1 = G.input_pairs(0)
+    B0, B1 = G.input_pairs(1)
+    R = A0[0] ^ A1[0]
+    assert R[0] & 1 and all(np.array_equal(A0[i] ^ A1[i], R) and np.array_equal(B0[i] ^ B1[i], R) for i in range(64))
+    Ls = prog.launches()
+    k = [i for i, L in enumerate(Ls) if L["steps"]][0]
+    assert Ls[k]["steps"] == 5 and G.table_bytes(k) == 5 * 2048
+    tab = G.garble(k).reshape(5, 2, 64, 16)                      # step, (TG | TE), lane, label
+    H = lambda lab, tw: openssl_gate_hash(lab[None, :], [tw])[0]
+    Z = np.zeros(16, dtype=np.uint8)
+    nz = [A0[l] ^ B0[l] for l in range(32)] + [Z] * 32           # zero-labels of a ^ b (word 0 of either share), lanes 32.. are 0
+    step = int(Ls[k]["step0"])
+    for s_i, dist in enumerate((16, 8, 4, 2, 1)):
+        sh = [nz[l + dist] if l + dist < 64 else Z for l in range(64)]
+        t = [Z] * 64
+        for l in range(64):
+            if l >= dist:
+                assert not tab[s_i, :, l].any()                  # inactive lanes: zero rows
+                continue
+            a0, b0, gid = nz[l], sh[l], 64 * step + l
+            pa, pb = int(a0[0] & 1), int(b0[0] & 1)
+            h0, h1, h2, h3 = H(a0, 2 * gid), H(a0 ^ R, 2 * gid), H(b0, 2 * gid + 1), H(b0 ^ R, 2 * gid + 1)
+            TG = h0 ^ h1 ^ (R if pb else Z)
+            TE = h2 ^ h3 ^ a0
+            assert np.array_equal(tab[s_i, 0, l], TG) and np.array_equal(tab[s_i, 1, l], TE), (s_i, l)
+            t[l] = h0 ^ (TG if pa else Z) ^ h2 ^ ((TE ^ a0) if pb else Z)
+        nz = [(nz[l] ^ sh[l] ^ t[l]) if l < dist else Z for l in range(64)]
+        step += 1
+    # and the evaluator's side of the same tables: equal inputs decode to 1, different ones to 0
+    for da, db in ((77, 77), (77, 78)):
+        E = lgc.Party(sysm, 2)
+        E.set_input_labels(0, G.encode_inputs(0, [da, 0]))
+        E.set_input_labels(1, G.encode_inputs(1, [db, 0]))
+        for i in range(G.num_launches):
+            E.evaluate(i, tab.reshape(-1) if i == k else G.garble(i))
+        beta, _, _ = E.finish(G.decode_bits())
+        assert int(beta[0]) == (1 if da == db else 0)
+        E.close()
+    G.close()

@@ -34,6 +34,18 @@ def _plain(lgc, gccpu, sysm, shares):
     return prog, dec
 
 
+def test_cpu_checker_hash_matches_openssl(gccpu):
+    """oracle/gc_cpu.cpp is compiled from the product's hash header, so its agreement with the GPU is self-consistency; here its
+    gate hash is checked against the definition written over OpenSSL's AES (tests/helpers.py: openssl_gate_hash) -- independent
+    code, independent AES"""
+    from helpers import openssl_gate_hash
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 256, size=(257, 16), dtype=np.uint8)
+    t = rng.integers(0, 2 ** 63, size=len(x), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=len(x), dtype=np.uint64)
+    x[0] = 0; t[0] = 0; x[1] = 255; t[1] = np.uint64(2 ** 64 - 1)
+    assert np.array_equal(gccpu.gate_hash(0, x, t), openssl_gate_hash(x, t))
+
+
 def test_dimension_check_program(lgc, gccpu):
     """the in-circuit comparison of the two parties' dimensions (src/linear.oc:109-114: revealOblivBool(feedOblivInt(d, 1) ==
     feedOblivInt(d, 2))) as a program of its own: one OP_EQ over two 32-bit input words -- 31 AND gates, what a comparison of
