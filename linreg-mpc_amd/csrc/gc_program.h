@@ -243,11 +243,18 @@ struct Program {
         }
         return t;
     }
-    void dots(const std::vector<DotJob> &jobs, uint32_t scratch, size_t target_waves) {
+    // kara_min: Karatsuba records (jobs with kdelta) where the batch has more than kara_min products; 0 = where the
+    // default chunk holds two products
+    void dots(const std::vector<DotJob> &jobs, uint32_t scratch, size_t target_waves, size_t kara_min = 0) {
         size_t total = 0;
-        for (size_t i = 0; i < jobs.size(); i++) total += jobs[i].len;
+        bool any_kara = false;
+        for (size_t i = 0; i < jobs.size(); i++) { total += jobs[i].len; any_kara = any_kara || (jobs[i].kdelta && w == 64); }
         if (total == 0) return;
-        const size_t c0 = dots_chunk(total, target_waves), clo = dots_chunk_low(total, target_waves);
+        size_t c0 = dots_chunk(total, target_waves), clo = dots_chunk_low(total, target_waves);
+        // Karatsuba records take their products in pairs: only where the batch is large enough for two products per record
+        // (the early and late columns of a factorisation are not: a lone product paired with the zero word costs 220 steps)
+        const bool kara_ok = kara_min ? total > kara_min : c0 >= 2;
+        if (any_kara && kara_ok) { if (c0 < 2) c0 = 2; if (clo < 2) clo = 2; }
         // chunk sizes from half to one and a half times the default (larger chunks: fewer, longer records -- and fewer
         // partial sums to merge); the scratch for the partial sums is sized for the smallest chunk
         size_t chi = c0 + c0 / 2;
@@ -257,10 +264,12 @@ struct Program {
             const size_t by_slot = (size_t)(cap_steps / ((uint64_t)kMinRecsPerLaunch * s1));
             if (chi > by_slot) chi = by_slot > c0 ? by_slot : c0;
         }
+#ifdef GC_X_MV_WAVES_ENV     /* timing experiments only: one chunk size, no shaping */
+        size_t x_clo = clo;
+        if (const char *e = getenv("LGC_X_MV_CHUNK")) if (atol(e) > 0 && (size_t)atol(e) >= clo) { chi = (size_t)atol(e); x_clo = chi; }
+#define clo x_clo
+#endif
         const size_t rep = merge_hint ? merge_hint : 1;
-        // Karatsuba records take their products in pairs: only where the batch is large enough for two products per record
-        // (the early and late columns of a factorisation are not: a lone product paired with the zero word costs 220 steps)
-        const bool kara_ok = c0 >= 2;
         std::vector<Rec> recs_best, recs_try;
         std::vector<std::pair<uint32_t, uint32_t>> parts, parts_try;
         std::vector<uint64_t> sdesc;
@@ -290,6 +299,9 @@ struct Program {
             }
             if (c == 1) break;
         }
+#ifdef GC_X_MV_WAVES_ENV
+#undef clo
+#endif
         if (best < 0) {   // cannot happen (L = lmin + 3 always fits); keep the default shape
             dots_records(jobs, scratch, c0, recs_best, parts, kara_ok);
             best_launches = 0;
@@ -478,8 +490,26 @@ struct Program {
     static size_t inner_scratch(size_t n) { return 4 * n + 4 * (n / 3 + 8) + 16; }   // per job
 };
 
-// target number of concurrent waves for the big dot-product launches
+// Records per big multiply-accumulate launch.  Rounds 1-3 shaped these launches to whole rounds of the chip (12 288 records of
+// ~21 products: three garbler rounds of 4 096 waves, four evaluator rounds of 3 072) -- but records of one length retire in lock
+// step, and the OTHER chain's dependent small launches (sums, inner products, the scalar dividers between two matrix-vector
+// products) then get CUs only at a round boundary: one launch of that chain per ~11 ms round, so the chain ran past the MAC
+// kernel it was meant to hide behind and the next matrix-vector product started 4-7 ms late, every iteration
+// (kernel timelines: profiles/r4_timeline_d500_cgd3_*.txt).  Short records (two products = one Karatsuba pair, 220 gate
+// steps, ~1.5 ms) turn workgroups over continuously: the chain finishes in half the MAC kernel's time, the MAC kernels
+// themselves lose nothing (d = 500 CGD-15: 1.99 -> 1.81 s, d = 300: 0.78 -> 0.71 s; scripts/exp/shape_ab*.sh).  The price is
+// more partial sums to merge (+1 % gate steps at d = 500).  kTargetWaves still decides WHERE Karatsuba records are used
+// (batches of more than that many products), so programs of small systems are what they were.
 static const size_t kTargetWaves = 12288;
+static const size_t kMvRecords64 = 131072;       // matrix-vector products of CGD, 64-bit (chunk floor: one Karatsuba pair)
+static const size_t kMvRecords32 = 65536;        // ... 32-bit (two-chunk OP_MAC2 records; 131 072 costs 5 % more steps)
+static const size_t kFactRecords = 65536;        // a column step of Cholesky / LDL^T (d = 500: 12.6 -> 12.0 s)
+static inline size_t x_fact_waves() {     // records per column step of the factorisations
+#ifdef GC_X_MV_WAVES_ENV     /* timing experiments only (scripts/exp/shape_ab.sh) */
+    if (const char *e = getenv("LGC_X_CHOL_WAVES")) if (atol(e) > 0) return (size_t)atol(e);
+#endif
+    return kFactRecords;
+}
 
 // Build the whole phase-2 program.
 //   normalize = 1: data-provider path (linear.oc:52-65): diag += lambda, off-diag and b divided by d
@@ -567,14 +597,20 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         const uint32_t sc_max = P.alloc(Program::max_tree_scratch(d));
         const uint32_t sc_ip = P.alloc(2 * Program::inner_scratch(d));
         // records per matrix-vector product: enough to fill the chip -- together with the other circuits of a merged sweep
-        size_t mv_waves = kTargetWaves / (P.merge_hint ? P.merge_hint : 1);
-        if (mv_waves < 2 * d) mv_waves = 2 * d < kTargetWaves ? 2 * d : kTargetWaves;     // at least two records per row
+        size_t mv_target = w == 64 ? kMvRecords64 : kMvRecords32;
+#ifdef GC_X_MV_WAVES_ENV     /* timing experiments only: records per matrix-vector launch from the environment */
+        if (const char *e = getenv("LGC_X_MV_WAVES")) if (atol(e) > 0) mv_target = (size_t)atol(e);
+#endif
+        size_t mv_waves = mv_target / (P.merge_hint ? P.merge_hint : 1);
+        if (mv_waves < 2 * d) mv_waves = 2 * d < mv_target ? 2 * d : mv_target;     // at least two records per row
+        size_t kara_min = kTargetWaves / (P.merge_hint ? P.merge_hint : 1);          // Karatsuba products where d * d exceeds this
+        if (kara_min < 2 * d) kara_min = 2 * d < kTargetWaves ? 2 * d : kTargetWaves;
         const uint32_t sc_dot = P.alloc_dots(d * d, d, mv_waves);
         if (trace) P.rv_trace = P.alloc_reveal((size_t)iters * (d + 4));
         // Karatsuba products for A p (w = 64): the words hdiff(M[i][j]) -- once per solve -- and hdiff(p[k]) -- once per
         // iteration -- live in a shadow of the word range [M, pv + d), kdelta words above their operands
         uint32_t kdelta = 0;
-        if (w == 64 && iters > 0 && program_karatsuba() && P.dots_chunk(d * d, mv_waves) >= 2) {   // (needs two products per record)
+        if (w == 64 && iters > 0 && program_karatsuba() && d * d > kara_min) {   // (needs two products per record)
             kdelta = P.alloc((size_t)(pv + D - M)) - M;
             for (size_t i = 0; i < d; i++)
                 for (size_t j = 0; j <= i; j++) P.emit(Program::mk(OP_HDIFF, Mi(i, j) + kdelta, Mi(i, j)));
@@ -601,7 +637,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
                 Program::DotJob J = {pA + (uint32_t)i, 0, Mi(i, 0), pv, D, false, kdelta};
                 jobs[i] = J;
             }
-            P.dots(jobs, sc_dot, mv_waves);
+            P.dots(jobs, sc_dot, mv_waves, kara_min);
             {                                        // q = <pA,p> (:128), gp = <g,p> (:130)
                 std::vector<Program::IpJob> ij(2);
                 Program::IpJob j0 = {q, pA, pv}, j1 = {gp, g, pv};
@@ -643,7 +679,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.new_launch();
     } else if (alg == ALG_CHOLESKY) {
         const uint32_t y = P.alloc(d), beta = P.alloc(d);
-        const uint32_t sc_dot = P.alloc_dots(d * d + d, d + 1, 4096, 4 * d + 8);
+        const uint32_t sc_dot = P.alloc_dots(d * d + d, d + 1, x_fact_waves(), 4 * d + 8);
         // Karatsuba products in the factorisation (w = 64, large d): an entry L_kj -- and y_j -- is final once column j has
         // been scaled, so its hdiff word (shadow of [M, y + d), kdelta words up) is formed in the launch that mirrors the
         // column (independent of the copies: no launch is added to the chain); columns with fewer than two products per
@@ -665,7 +701,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
                 }
                 Program::DotJob F = {bv + (uint32_t)j, bv + (uint32_t)j, Mi(j, 0), y, (uint32_t)j, true, kdelta};   // :70-73
                 jobs.push_back(F);
-                P.dots(jobs, sc_dot, 4096);
+                P.dots(jobs, sc_dot, x_fact_waves(), 4096);
             }
             P.emit(Program::mk(OP_SQRT, Mi(j, j), Mi(j, j)));
             P.new_launch();
@@ -695,7 +731,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.new_launch();
     } else {  // ALG_LDLT
         const uint32_t tv = P.alloc(d);
-        const uint32_t sc_dot = P.alloc_dots(d * d + d, d + 1, 4096, 4 * d + 8);
+        const uint32_t sc_dot = P.alloc_dots(d * d + d, d + 1, x_fact_waves(), 4 * d + 8);
         // Karatsuba products as in the Cholesky lowering: hdiff of L_kj in the launch that mirrors column j, of b_j (final
         // after step j of the forward substitution) and of the products t_k = L_jk D_k in a launch of their own per column
         uint32_t kdelta = 0;
@@ -719,7 +755,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
                 // forming a chain of d - 1 launch pairs of its own after the factorisation (as in the Cholesky lowering)
                 Program::DotJob F = {bv + (uint32_t)j, bv + (uint32_t)j, Mi(j, 0), bv, (uint32_t)j, true, kdelta};
                 jobs.push_back(F);
-                P.dots(jobs, sc_dot, 4096);
+                P.dots(jobs, sc_dot, x_fact_waves(), 4096);
             }
             for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_DIV, Mi(k, j), Mi(k, j), Mi(j, j)));
             P.new_launch();

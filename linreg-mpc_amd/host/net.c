@@ -87,24 +87,49 @@ static void tune_socket(int s) {
         fprintf(stderr, "socket buffers: snd %d rcv %d\n", sb, rb);
     }
 }
+/* How long a party waits for its peers to come up (connect retries, accept): LINREG_CONNECT_TIMEOUT seconds, default 300;
+ * 0 = for ever, as util_loop_connect (src/util.c:26-38) does.  A party whose peer never appears exits non-zero instead of
+ * spinning: with the others gone (check() -> exit 1 everywhere, src/check_error.h) nobody would ever end it. */
+static double connect_deadline_s(void) {
+    const char *e = getenv("LINREG_CONNECT_TIMEOUT");
+    return e && *e ? atof(e) : 300.0;
+}
+static double mono_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+/* a connect() to a local port nobody listens on yet can be given that very port as its source and then completes as a TCP
+ * simultaneous open WITH ITSELF (ports inside the ephemeral range; once in ~10^4 attempts): not a peer */
+static int connected_to_itself(int s) {
+    struct sockaddr_in a, b;
+    socklen_t la = sizeof a, lb = sizeof b;
+    if (getsockname(s, (struct sockaddr *)&a, &la) || getpeername(s, (struct sockaddr *)&b, &lb)) return 0;
+    return a.sin_family == AF_INET && b.sin_family == AF_INET && a.sin_port == b.sin_port && a.sin_addr.s_addr == b.sin_addr.s_addr;
+}
 static int connect_retry(const char *host, const char *port) {
     /* retry like util_loop_connect (src/util.c:26-38), which sleeps 200 ms between attempts: here the pause starts at 2 ms
      * and doubles up to those 200 ms -- parties started together find each other within milliseconds (a peer that was not
      * listening yet used to cost 0.2 s of a 0.4 s run) */
     long pause_ns = 2000000;
+    const double limit = connect_deadline_s(), t0 = mono_s();
     for (;;) {
         struct addrinfo hints, *res = 0;
         memset(&hints, 0, sizeof hints);
         hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM;
         if (getaddrinfo(host, port, &hints, &res) == 0) {
             int s = socket(res->ai_family, res->ai_socktype, res->ai_protocol);
-            if (s >= 0 && connect(s, res->ai_addr, res->ai_addrlen) == 0) {
+            if (s >= 0 && connect(s, res->ai_addr, res->ai_addrlen) == 0 && !connected_to_itself(s)) {
                 tune_socket(s);
                 freeaddrinfo(res);
                 return s;
             }
             if (s >= 0) close(s);
             freeaddrinfo(res);
+        }
+        if (limit > 0 && mono_s() - t0 > limit) {
+            fprintf(stderr, "Could not connect to %s:%s within %.0f s (LINREG_CONNECT_TIMEOUT)\n", host, port, limit);
+            return -1;
         }
         struct timespec ts = {0, pause_ns};
         nanosleep(&ts, 0);
@@ -128,6 +153,7 @@ int node_new(node **out, int party, int num_parties, char **endpoints) {
     for (int q = 1; q < party; q++) {                       /* lower-numbered peers listen */
         if (split_endpoint(endpoints[q - 1], host, sizeof host, port, sizeof port)) goto fail;
         int s = connect_retry(host, port);
+        if (s < 0) goto fail;
         n->fd[q - 1] = s;
         int32_t me = party;
         if (io_all(s, &me, sizeof me, 1)) goto fail;      /* announce ourselves (node.c:35-37) ... */
@@ -146,9 +172,24 @@ int node_new(node **out, int party, int num_parties, char **endpoints) {
             close(ls);
             goto fail;
         }
+        const double limit = connect_deadline_s(), t0 = mono_s();
         for (int k = party; k < num_parties; k++) {
+            if (limit > 0) {                              /* accept() honours SO_RCVTIMEO */
+                double left = limit - (mono_s() - t0);
+                struct timeval tv = {left > 1 ? (time_t)left : 1, 0};
+                setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+            }
             int s = accept(ls, 0, 0);
-            if (s < 0) { close(ls); goto fail; }
+            if (s < 0) {
+                fprintf(stderr, "Party %d: %d of its peers did not connect within %.0f s (LINREG_CONNECT_TIMEOUT): %s\n", party,
+                        num_parties - k, limit, strerror(errno));
+                close(ls);
+                goto fail;
+            }
+            {   /* the timeout was for accept() only (an accepted socket does not inherit it on Linux, but say so) */
+                struct timeval none = {0, 0};
+                setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof none);
+            }
             tune_socket(s);
             int32_t other = 0;
             if (io_all(s, &other, sizeof other, 0) || other <= party || other > num_parties || n->fd[other - 1] >= 0) {

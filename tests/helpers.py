@@ -70,3 +70,30 @@ def openssl_gate_hash(labels, tweaks):
         crypto.AES_encrypt(inb, outb, sched)
         out[i] = np.frombuffer(outb.raw, dtype=np.uint8) ^ k
     return out
+
+
+def free_ports(k):
+    """k listening ports BELOW the kernel's ephemeral range (ip_local_port_range, 32768-60999 here): a port from bind(0)
+    lies inside that range, and while its party is not listening yet a peer's connect() attempt can be given the same number as
+    its SOURCE port -- the attempt then connects to itself (TCP simultaneous open) or the party's bind fails, and the run hangs
+    (one such hang in ~600 runs of the GPU suite)"""
+    import socket, random
+    lo = 12000
+    try:
+        hi = min(30000, int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0]) - 1)
+    except (OSError, ValueError):
+        hi = 30000
+    ports, rnd = [], random.SystemRandom()
+    while len(ports) < k:
+        p = rnd.randrange(lo, hi)
+        if p in ports:
+            continue
+        s_ = socket.socket()
+        try:
+            s_.bind(("127.0.0.1", p))
+            ports.append(p)
+        except OSError:
+            pass
+        finally:
+            s_.close()
+    return ports

@@ -5,6 +5,7 @@ import os
 import re
 import socket
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -80,14 +81,7 @@ def test_pmsg_wire_format(hostlib):
     assert hostlib.pmsg_unpack(bad.ctypes.data, len(bad), C.byref(pv), C.byref(n), C.byref(val)) != 0
 
 
-def _free_ports(k):
-    socks = [socket.socket() for _ in range(k)]
-    for s in socks:
-        s.bind(("127.0.0.1", 0))
-    ports = [s.getsockname()[1] for s in socks]
-    for s in socks:
-        s.close()
-    return ports
+from helpers import free_ports as _free_ports    # ports below the ephemeral range (see there)
 
 
 def _rewrite_ports(src, dst):
@@ -578,3 +572,25 @@ def test_two_parties_with_different_dimensions_are_told_so_by_the_circuit(tmp_pa
     import linreg_gc
     prog = linreg_gc.Program(linreg_gc.make_system(3, 64, 56, "cgd", 2, 0.0, 2, 0, 0, 1))
     assert int(re.search("Number of gates: ([0-9]+)", outs[1][0].decode()).group(1)) == prog.info.total_gates + 31
+
+
+@pytest.mark.parametrize("party", [1, 3, 5], ids=["listener-only", "connects-and-listens", "connects-only"])
+def test_a_party_whose_peers_never_appear_gives_up(tmp_path, golden_dir, party):
+    """util_loop_connect (src/util.c:26-38) retries for ever and accept() waits for ever; with check() -> exit(1) as the
+    failure convention (src/check_error.h:5-9) a party whose peer died before it was reachable would never end.  The
+    connection phase has ONE deadline (LINREG_CONNECT_TIMEOUT seconds, default 300, 0 = for ever): exit 1 with the reason."""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    infile = str(tmp_path / "readme.in")
+    P = _rewrite_ports(os.path.join(golden_dir, "readme_example.in"), infile)
+    assert party <= P + 2
+    t0 = time.time()
+    r = subprocess.run([os.path.join(HOST, "bin", "linreg"), infile, "56", str(party), "cgd", "10", "0.001"], capture_output=True,
+                       text=True, timeout=60, env=dict(os.environ, LINREG_CONNECT_TIMEOUT="1.5"))
+    assert r.returncode == 1 and time.time() - t0 < 20
+    assert "LINREG_CONNECT_TIMEOUT" in r.stderr and "Could not create node" in r.stderr
+
+
+def test_ports_for_the_runs_lie_below_the_ephemeral_range():
+    lo = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+    ports = _free_ports(8)
+    assert len(set(ports)) == 8 and all(1024 < p < lo for p in ports)

@@ -275,7 +275,7 @@ def test_sweep_program_matches_oracle_per_lambda(lgc, gccpu, oracle, w, p, alg):
         lgc.Program(lgc.make_system(d, w, p, alg, iters, 0.0, 2, 0, 0, 0), lambdas=lams)
 
 
-@pytest.mark.parametrize("alg,d,w,p,iters,nl,world", [("cholesky", 200, 64, 56, 0, 5, 2), ("cgd", 100, 32, 28, 15, 9, 2),
+@pytest.mark.parametrize("alg,d,w,p,iters,nl,world", [("cholesky", 200, 64, 56, 0, 5, 2), ("cgd", 100, 32, 28, 15, 27, 2),
                                                        ("cgd", 100, 64, 56, 15, 64, 7), ("cgd", 12, 64, 56, 3, 7, 3)])
 def test_blocks_of_an_uneven_partition_have_disjoint_gate_steps(lgc, alg, d, w, p, iters, nl, world):
     """the blocks of one sharded sweep share the garbler's R, so no two of them may use a gate step twice -- also when

@@ -62,7 +62,8 @@ def test_result_line_regex():
 
 
 def test_msgpack_peer_link_roundtrip():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    from helpers import free_ports
+    port = free_ports(1)[0]
     got = {}
 
     def server():
@@ -154,8 +155,8 @@ def test_fit_two_instances_end_to_end(tmp_path, oracle, alg):
         f.write("age;sex;height;weight;income\n")
         for i in range(n):
             f.write("%r;%s;%r;%r;%r\n" % (float(age[i]), "mw"[1 - int(sex[i])], float(height[i]), float(weight[i]), float(income[i])))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); base = s.getsockname()[1]; s.close()
-    base = 20000 + (base % 20000)
+    from helpers import free_ports
+    base = free_ports(1)[0]          # (below the ephemeral range; base + 100 likewise)
     a_ip, b_ip = "127.0.0.1:%d" % base, "127.0.0.1:%d" % (base + 100)
     args = ["56", alg, "12", "0.001"]
     ctx = mp.get_context("spawn")

@@ -11,12 +11,7 @@ mirror = gccpu.load()
 TI_SEED = bytes(range(0x60, 0x70))
 HOST = os.path.join(ROOT, "linreg-mpc_amd", "host")
 
-def free_ports(k):
-    socks = [socket.socket() for _ in range(k)]
-    for s in socks: s.bind(("127.0.0.1", 0))
-    ports = [s.getsockname()[1] for s in socks]
-    for s in socks: s.close()
-    return ports
+from helpers import free_ports
 
 def write_instance(path, n, d, starts, seed):
     rng = np.random.default_rng(seed)
