@@ -225,6 +225,9 @@ struct Program {
     // of 4096 / 3072 records: a launch of 10 400 records costs three garbler rounds but fills 2.55.
     // Among the chunk sizes down to half the default and the launch counts that respect the table
     // cap, pick the pair with the least rounds x steps, and split the records evenly.
+    // (Round 4: the callers' record targets -- kMvRecords64/32, kFactRecords below -- now ask for records so short that a big
+    // launch is tens of rounds and the round model only decides between neighbouring chunk sizes; it still matters for
+    // mid-size batches and for the launch count of a merged sweep.)
     static const size_t kRoundRecs = 12288;          // lcm(256 x 16, 256 x 12)
     static double round_cost(size_t per, size_t quantum) {   // a workgroup is the unit: a partial round costs a round
         return (double)((per + quantum - 1) / quantum);
