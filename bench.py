@@ -383,7 +383,23 @@ def self_launch(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL), stderr=None))
-    out0, _ = procs[0].communicate()
+    # a rank that dies (out of memory, a failed check) leaves the others inside a collective until the group's timeout:
+    # watch all of them, and when one exits non-zero give the rest ten seconds, then end them
+    import threading, time as _t
+    box = {}
+    th = threading.Thread(target=lambda: box.update(out=procs[0].communicate()[0]), daemon=True)
+    th.start()
+    failed_at = None
+    while any(q.poll() is None for q in procs):
+        if failed_at is None and any(q.poll() not in (None, 0) for q in procs):
+            failed_at = _t.time()
+        if failed_at is not None and _t.time() - failed_at > 10.0:
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()                 # (our own children, by handle)
+        _t.sleep(0.05)
+    th.join()
+    out0 = box.get("out") or b""
     rcs = [q.wait() for q in procs]
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
@@ -470,7 +486,8 @@ def main():
                                     timeout=datetime.timedelta(seconds=600))
             dist.barrier()                           # creates the RCCL communicator now, not inside the timed region
         else:
-            dist.init_process_group(backend=backend)
+            import datetime
+            dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=600))
 
     # what the process group really is: ranks RCCL sees, and the distinct GPUs behind them
     rccl_ranks = dist.get_world_size() if (dist is not None and backend == "nccl") else None

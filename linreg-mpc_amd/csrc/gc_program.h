@@ -25,12 +25,24 @@ static const size_t kMinRecsPerLaunch = 8192;   // >= 2x the chip's resident wav
 // launch runs in whole rounds of the chip (one workgroup per CU: 4096 garbler / 3072 evaluator records per round), so the
 // fewer launches a matrix-vector product is cut into, the less is lost to partly filled last rounds: with 2^23 the d = 500
 // product (27.5 M steps with Karatsuba records) fell into four launches of 3.81 / 5.09 rounds -- the evaluator ran six
-// rounds for five rounds of work -- with 2^25 it is ONE launch of 15.3 / 20.3 rounds.  The table ring is twice the
-// largest launch: 113 GB of the 288 GB of an MI355X at d = 500.
-static const uint64_t kDefaultCapSteps = 1ull << 25;
-// ... a merged sweep program is cut into equal round-shaped pieces anyway (replicate_program): 2^24 there, so that the ring
-// of a sweep block (32 + 8 GiB) fits the one a d = 500 solver leaves parked (56 + 8 GiB) and need not be allocated afresh
-static const uint64_t kSweepCapSteps = 1ull << 24;
+// rounds for five rounds of work -- with 2^25 it is ONE launch.  (Round 4: with records of one Karatsuba pair a launch is tens
+// of rounds and the partly filled last round no longer matters, but every launch still pays ~1 ms of ramp-up and tail, and
+// smaller launches measured slower: d = 500 CGD-15 1.81 s at 2^25, 1.87 at 2^24, 1.93 at 2^23; scripts/exp/mac_ab.sh cap*.)
+// The table ring is the largest launch plus kRingSlackBytes: 64 of the 288 GB of an MI355X at d = 500.
+#ifndef GC_DEFAULT_CAP_LOG2
+#define GC_DEFAULT_CAP_LOG2 25
+#endif
+static const uint64_t kDefaultCapSteps = 1ull << GC_DEFAULT_CAP_LOG2;
+// ... a merged sweep program is cut into equal pieces by the same cap (replicate_program).  Rounds 3 - 4 used 2^24 there, so
+// that the ring of a sweep block (32 + 8 GiB) fitted the one a d = 500 solver leaves parked; but every launch pays ~1 ms of
+// ramp-up and tail (all workgroups start in lock step, the last ones leave CUs idle), and a 64-circuit block has 90 such
+// launches: 2^25 halves them -- 6.27 -> 6.00 s for the 64-lambda block (scripts/exp/sweep_cap_ab.sh); blocks of <= 16 circuits
+// fit one launch per product either way.
+#ifndef GC_SWEEP_CAP_LOG2
+#define GC_SWEEP_CAP_LOG2 25
+#endif
+static const uint64_t kSweepCapSteps = 1ull << GC_SWEEP_CAP_LOG2;
+static const uint64_t kGenericCapSteps = 1ull << 24;     // launches other than MAC launches (Program::emit)
 static const size_t kRingSlackBytes = (size_t)8 << 30;
 // ... adjustable (lgc_set_table_ring_slack): eight ranks rehearsing an 8-GPU sweep on ONE GPU must fit its HBM together
 inline size_t &ring_slack_bytes() { static size_t v = kRingSlackBytes; return v; }
@@ -114,7 +126,11 @@ struct Program {
         cost(r, s, g);
         bool mac = (r.op == OP_MAC || r.op == OP_MAC2 || r.op == OP_MACK);
         const bool mack = r.op == OP_MACK;
-        if (!open || launches.back().steps + s > cap_steps || launches.back().mac_only != mac || launches.back().mack != mack) {
+        // the table cap is for the MAC launches (fewer, larger launches: kDefaultCapSteps); every other launch is cut at
+        // kGenericCapSteps as in rounds 1-4 -- the input division of an 8-circuit sweep block is 18.7 M steps, and as ONE
+        // launch it would set the size of the block's table ring (36 GiB instead of 18)
+        const uint64_t cap_here = mac || cap_steps < kGenericCapSteps ? cap_steps : kGenericCapSteps;
+        if (!open || launches.back().steps + s > cap_here || launches.back().mac_only != mac || launches.back().mack != mack) {
             Launch L;
             L.first_rec = (uint32_t)recs.size();
             L.nrec = 0;
@@ -830,8 +846,9 @@ inline bool replicate_program(Program &P, const Program &P0, size_t count, const
         // a merged launch that exceeds the table cap is cut into EQUAL pieces (a ragged last piece of a MAC launch would
         // be a launch of a few hundred records: most of the chip idle, or the wrong kernel altogether)
         const uint64_t cap_keep = P.cap_steps;
+        const uint64_t cap_l = L.mac_only || cap_keep < kGenericCapSteps ? cap_keep : kGenericCapSteps;   // (as in Program::emit)
         if (!prefix && L.nrec) {
-            const uint64_t tot = L.steps * (uint64_t)count, pieces = (tot + cap_keep - 1) / cap_keep;
+            const uint64_t tot = L.steps * (uint64_t)count, pieces = (tot + cap_l - 1) / cap_l;
             uint64_t smax = 0;
             for (uint32_t k = 0; k < L.nrec; k++) { uint64_t s1, g1; P.cost(P0.recs[L.first_rec + k], s1, g1); if (s1 > smax) smax = s1; }
             uint64_t best_pieces = pieces;
@@ -841,14 +858,14 @@ inline bool replicate_program(Program &P, const Program &P0, size_t count, const
                 const uint64_t R = (uint64_t)L.nrec * count;
                 for (uint64_t q = pieces; q <= pieces + 3; q++) {
                     const size_t per = (size_t)((R + q - 1) / q);
-                    if ((uint64_t)per * smax > cap_keep) continue;
+                    if ((uint64_t)per * smax > cap_l) continue;
                     const double c_est = (double)q * ((double)smax * (64.0 * Program::round_cost(per, 4096) + 24.0 * Program::round_cost(per, 3072)) + 3e2);
                     if (best < 0 || c_est < best) { best = c_est; best_pieces = q; }
                 }
             }
             if (best_pieces > 1) {
                 const uint64_t soft = (tot + best_pieces - 1) / best_pieces + smax;
-                if (soft < cap_keep) P.cap_steps = soft;
+                if (soft < cap_l) P.cap_steps = soft;
             }
         }
         // record-major: record k of every circuit, then record k + 1 ... -- the records of a launch are independent, and

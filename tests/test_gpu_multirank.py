@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+    from helpers import free_ports
+    return free_ports(1)[0]
 
 
 def test_bench_two_ranks_share_one_gpu(tmp_path, oracle):
@@ -65,7 +66,7 @@ def test_bench_eight_ranks_rehearse_the_full_sweep_on_one_gpu(tmp_path, oracle):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
            "--dimension", "24", "--iters", "2", "--no-cpu-baseline", "--no-traffic", "--no-e2e"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 8 and out["barrier_backend"] == "gloo" and out["rccl_ranks"] is None and len(out["devices"]) == 1
