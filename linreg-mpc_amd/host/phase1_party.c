@@ -8,6 +8,7 @@
 #include <pthread.h>
 #include <signal.h>
 #include <stdio.h>
+#include <sys/mman.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/socket.h>
@@ -511,6 +512,12 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
     const size_t n = c->n, d = c->d, T = d * (d + 1) / 2;
     const int me = c->party - 1, last = c->num_parties - 1;
     int64_t *Xq = malloc(n * d * 8), *yq = malloc(n * 8);
+    /* 200 MB at config 4, touched for the first time by the parser's threads while the HIP runtime comes up on another
+     * thread: huge pages mean hundreds of page faults instead of 50 000 fighting that thread for the address-space lock */
+    if (Xq && n * d * 8 >= ((size_t)8 << 20)) {
+        const uintptr_t a = ((uintptr_t)Xq + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)Xq + n * d * 8) & ~(uintptr_t)4095;
+        (void)madvise((void *)a, (size_t)(e - a), MADV_HUGEPAGE);
+    }
     uint64_t *share_A = calloc(T, 8), *share_b = calloc(d, 8), *va = 0, *vb = 0, *tmp = 0, *tmp2 = 0;
     lgc_p1 *p1 = 0;
     int rc = 1;

@@ -27,85 +27,7 @@
 
 size_t idx(size_t i, size_t j) { if (j > i) { size_t t = i; i = j; j = t; } return (i * (i + 1)) / 2 + j; }
 
-/* (fixed_t)(d * (1ll << p)) with the phase-2 type (src/fixed.c:3-5, src/linear.c:51) */
-/* Out of range the C cast is undefined; the reference runs on x86-64, where cvttsd2si yields the
- * "integer indefinite" value (INT_MIN of the type) -- the rule the oracle states (orc_double_to_fixed). */
-int64_t double_to_fixed(double d, int p, int w) {
-    double t = d * (double)(1ll << p);
-    if (w == 32) {
-        if (!(t > -2147483649.0 && t < 2147483648.0)) return (int64_t)INT32_MIN;
-        return (int64_t)(int32_t)t;
-    }
-    if (!(t >= -9223372036854775808.0 && t < 9223372036854775808.0)) return INT64_MIN;
-    return (int64_t)t;
-}
-double fixed_to_double(int64_t f, int p) { return ((double)f) / (double)(1ll << p); }
-
-/* read_matrix / read_vector (src/linear.c:27-102), values divided by the normalizer */
-int read_values(FILE *f, size_t count, int precision, double normalizer, int w2, int64_t *out) {
-    for (size_t i = 0; i < count; i++) {
-        double val;
-        if (fscanf(f, "%lf", &val) != 1) return 1;
-        val /= normalizer;
-        out[i] = double_to_fixed(val, precision, w2);
-    }
-    return 0;
-}
-
-/* read_matrix / read_vector for a data provider: the rest of the input file is slurped and scanned token by
- * token; only the columns this party owns (and the target, if it owns it) are converted -- with strtod, i.e. the
- * same correctly rounded value "%lf" gives -- and quantised, every other entry stays 0 (it is never used: a
- * provider only ever touches its own columns).  Token counts and syntax are still checked for the whole file. */
-static int is_num_char(int ch) { return (ch >= '0' && ch <= '9') || ch == '.' || ch == '-' || ch == '+' || ch == 'e' || ch == 'E' || ch == 'i' || ch == 'n' || ch == 'f' || ch == 'a' || ch == 'I' || ch == 'N' || ch == 'F' || ch == 'A' || ch == 'x' || ch == 'X'; }
-int read_own_columns(FILE *f, size_t n, size_t d, size_t c0, size_t c1, int own_y, int precision, double normalizer, int w2,
-                            int64_t *Xq, int64_t *yq) {
-    long at = ftell(f);
-    if (at < 0 || fseek(f, 0, SEEK_END)) return 1;
-    long end = ftell(f);
-    if (end < at || fseek(f, at, SEEK_SET)) return 1;
-    size_t len = (size_t)(end - at);
-    char *buf = malloc(len + 1);
-    if (!buf || fread(buf, 1, len, f) != len) { free(buf); return 1; }
-    buf[len] = 0;
-    char *p = buf;
-    int rc = 1;
-#define SKIP_WS() while (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f') p++
-    size_t n2 = 0, d2 = 0;
-    { char *e; SKIP_WS(); n2 = strtoull(p, &e, 10); if (e == p) goto out; p = e; SKIP_WS(); d2 = strtoull(p, &e, 10); if (e == p) goto out; p = e; }
-    if (n2 != n || d2 != d) goto out;
-    memset(Xq, 0, n * d * sizeof *Xq);
-    for (size_t k = 0; k < n; k++)
-        for (size_t j = 0; j < d; j++) {
-            SKIP_WS();
-            if (!*p) goto out;
-            if (j >= c0 && j < c1) {
-                char *e;
-                double v = strtod(p, &e);
-                if (e == p) goto out;
-                p = e;
-                Xq[k * d + j] = double_to_fixed(v / normalizer, precision, w2);
-            } else {
-                if (!is_num_char((unsigned char)*p)) goto out;       /* first character checked, the rest of the token skipped */
-                while ((unsigned char)*p > ' ') p++;
-            }
-        }
-    { char *e; SKIP_WS(); n2 = strtoull(p, &e, 10); if (e == p || n2 != n) goto out; p = e; }
-    memset(yq, 0, n * sizeof *yq);
-    for (size_t k = 0; k < n; k++) {
-        SKIP_WS();
-        if (!*p) goto out;
-        char *e;
-        double v = strtod(p, &e);
-        if (e == p) goto out;
-        p = e;
-        if (own_y) yq[k] = double_to_fixed(v / normalizer, precision, w2);
-    }
-#undef SKIP_WS
-    rc = 0;
-out:
-    free(buf);
-    return rc;
-}
+/* double_to_fixed / fixed_to_double / read_values / read_own_columns: readdata.c */
 
 /* length-prefixed protobuf message (src/phase1.c:100-145) */
 int send_pmsg(node *self, int to, const uint64_t *vec, size_t n, uint64_t value) {

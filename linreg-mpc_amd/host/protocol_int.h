@@ -7,8 +7,11 @@
 /* protocol.c */
 extern size_t g_pmsg_limit;
 uint8_t *frame_pmsg(const uint64_t *vec, size_t n, uint64_t value, size_t *len);      /* a length-prefixed proto2 message, malloc'd */
+/* readdata.c */
 int read_own_columns(FILE *f, size_t n, size_t d, size_t c0, size_t c1, int own_y, int precision, double normalizer, int w2,
                             int64_t *Xq, int64_t *yq);
+int read_own_columns_threads(FILE *f, size_t n, size_t d, size_t c0, size_t c1, int own_y, int precision, double normalizer, int w2,
+                             int64_t *Xq, int64_t *yq, int threads);
 /* phase1_ti.c */
 extern int g_ti_ring;                                    /* --ti_ring (protocol_set_ti_ring) */
 void tune_malloc(void);

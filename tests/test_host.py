@@ -594,3 +594,71 @@ def test_ports_for_the_runs_lie_below_the_ephemeral_range():
     lo = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
     ports = _free_ports(8)
     assert len(set(ports)) == 8 and all(1024 < p < lo for p in ports)
+
+
+def _parse_with(hostlib, path, n, d, c0, c1, own_y, prec, norm, w2, threads):
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p; libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    hostlib.read_own_columns_threads.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_double,
+                                                 C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    Xq = np.full(n * d, 7, dtype=np.int64); yq = np.full(n, 7, dtype=np.int64)      # the parser clears what it does not own
+    f = libc.fopen(path.encode(), b"r")
+    rc = hostlib.read_own_columns_threads(f, n, d, c0, c1, own_y, prec, norm, w2, Xq.ctypes.data, yq.ctypes.data, threads)
+    libc.fclose(f)
+    return rc, Xq.reshape(n, d), yq
+
+
+def test_input_file_numbers_parsed_by_several_threads_are_the_ones_one_thread_reads(hostlib, tmp_path):
+    """read_matrix / read_vector for a provider (src/linear.c:27-102): own columns converted as `%lf` would and quantised as
+    (fixed_t)(v / normalizer * 2^p) (src/fixed.c:3-5), the rest zero; the scan is split over threads at token boundaries
+    (host/readdata.c) -- every thread count gives the integers of a plain Python restatement, ragged white space, exponents,
+    a mapped and a read buffer, both widths; malformed files are refused by every thread count"""
+    rng = np.random.default_rng(11)
+    for case, (n, d, c0, c1, own_y, prec, norm, w2) in enumerate([(37, 11, 3, 7, 1, 56, 1.0, 64), (64, 5, 0, 5, 0, 30, 8.0, 32),
+                                                                    (300, 40, 39, 40, 1, 40, 3.0, 64), (2500, 210, 100, 200, 1, 56, 50000.0, 64)]):
+        X = rng.standard_normal((n, d)) * 10.0 ** rng.integers(-3, 3, size=(n, d))
+        y = rng.standard_normal(n)
+        X[0, c0] = 1e300 if w2 == 64 else 3e9            # out of range: the integer-indefinite rule
+        X[n - 1, c1 - 1] = -0.0
+        seps = [" ", "  ", "\t", "\n", " \n", "\r\n"]
+        path = str(tmp_path / ("m%d.in" % case))
+        with open(path, "w") as f:
+            f.write(" %d\t%d\n" % (n, d))
+            for i in range(n):
+                for j in range(d):
+                    v = float(X[i, j])
+                    tok = repr(v) if (i + j) % 3 else "%.17e" % v
+                    f.write(tok + (seps[(i * d + j) % len(seps)] if case != 3 else (" " if j + 1 < d else "\n")))
+            f.write("%d\n" % n + " ".join(repr(float(v)) for v in y))          # no white space after the last number
+        def q(v):
+            t = float(v) / norm * float(1 << prec)
+            if w2 == 32:
+                return int(t) if -2147483649.0 < t < 2147483648.0 else -2 ** 31
+            return int(t) if -9223372036854775808.0 <= t < 9223372036854775808.0 else -2 ** 63
+        expX = np.zeros((n, d), dtype=np.int64)
+        for i in range(n):
+            for j in range(c0, c1):
+                expX[i, j] = q(X[i, j])
+        expy = np.array([q(v) if own_y else 0 for v in y], dtype=np.int64)
+        for threads in (1, 2, 3, 8, 64):
+            rc, Xq, yq = _parse_with(hostlib, path, n, d, c0, c1, own_y, prec, norm, w2, threads)
+            assert rc == 0, (case, threads)
+            assert (Xq == expX).all() and (yq == expy).all(), (case, threads)
+    # malformed: a count that does not match, a number missing, a token that is not a number in an own column, in a foreign one
+    good = open(str(tmp_path / "m0.in")).read()
+    n, d = 37, 11
+    toks = good.split()
+    def write(tl, name):
+        pth = str(tmp_path / name)
+        open(pth, "w").write(" ".join(tl) + "\n")
+        return pth
+    bad_files = [write(toks[:2] + toks[2:2 + n * d] + [str(n + 1)] + toks[3 + n * d:], "b0.in"),          # wrong length of y
+                 write(toks[:-1], "b1.in"),                                                                # one number short
+                 write(toks[:2 + 5] + ["1.5abc"] + toks[2 + 6:], "b2.in"),                                 # column 5: owned
+                 write(toks[:2 + 1] + ["?"] + toks[2 + 2:], "b3.in"),                                      # column 1: foreign
+                 write(["38", "11"] + toks[2:], "b4.in")]                                                  # header does not match
+    for pth in bad_files:
+        for threads in (1, 3, 8):
+            rc, _, _ = _parse_with(hostlib, pth, n, d, 3, 7, 1, 56, 1.0, 64, threads)
+            assert rc != 0, (pth, threads)
