@@ -283,10 +283,8 @@ struct Program {
             const size_t by_slot = (size_t)(cap_steps / ((uint64_t)kMinRecsPerLaunch * s1));
             if (chi > by_slot) chi = by_slot > c0 ? by_slot : c0;
         }
-#ifdef GC_X_MV_WAVES_ENV     /* timing experiments only: one chunk size, no shaping */
-        size_t x_clo = clo;
-        if (const char *e = getenv("LGC_X_MV_CHUNK")) if (atol(e) > 0 && (size_t)atol(e) >= clo) { chi = (size_t)atol(e); x_clo = chi; }
-#define clo x_clo
+#ifdef GC_X_MV_WAVES_ENV     /* timing experiments only (scripts/exp/mvw_ab3.sh): one chunk size, no shaping */
+        if (const char *e = getenv("LGC_X_MV_CHUNK")) if (atol(e) > 0 && (size_t)atol(e) >= clo) { chi = (size_t)atol(e); clo = chi; }
 #endif
         const size_t rep = merge_hint ? merge_hint : 1;
         std::vector<Rec> recs_best, recs_try;
@@ -318,9 +316,6 @@ struct Program {
             }
             if (c == 1) break;
         }
-#ifdef GC_X_MV_WAVES_ENV
-#undef clo
-#endif
         if (best < 0) {   // cannot happen (L = lmin + 3 always fits); keep the default shape
             dots_records(jobs, scratch, c0, recs_best, parts, kara_ok);
             best_launches = 0;
