@@ -49,3 +49,19 @@ def test_config4_cgd20_d500_32bit(lgc, oracle):
 
 def test_ldlt_d60(lgc, oracle):
     _run(lgc, oracle, 800, 60, 64, 56, "ldlt", 0, 2, 1, 1e-3, 6)
+
+
+@pytest.mark.parametrize("d,w,p,iters", [(110, 64, 56, 2), (111, 64, 56, 2), (130, 64, 56, 2), (300, 64, 56, 2), (300, 32, 30, 3), (181, 32, 30, 2)])
+def test_mid_size_cgd_around_the_karatsuba_threshold(lgc, oracle, d, w, p, iters):
+    """round 4 made the records of the matrix-vector launches as short as the circuit allows (gc_program.h: kMvRecords64/32) while
+    Karatsuba records are still used where d * d exceeds 12 288 -- d = 110 is the last plain system, 111 the first with
+    Karatsuba pairs (one pair per record from there on), 300 the size where the old and the new record length differ most;
+    32-bit: two-chunk records of one product per half at d = 181.  Every reveal of every iteration against the oracle."""
+    _run(lgc, oracle, 3 * d, d, w, p, "cgd", iters, 2, 1, 1e-3, 40 + d)
+
+
+@pytest.mark.parametrize("alg,d", [("cholesky", 150), ("ldlt", 190)])
+def test_mid_size_factorisations_with_short_column_records(lgc, oracle, alg, d):
+    """column steps of a factorisation with more than 4 096 products use Karatsuba records of one pair (kFactRecords); d = 150
+    has such steps in the middle columns only, 190 nearly everywhere"""
+    _run(lgc, oracle, 3 * d, d, 64, 56, alg, 0, 2, 1, 1e-3, 60 + d)
