@@ -22,6 +22,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python"))
 
 
+# a party whose peers never come up gives up after this many seconds (host/net.c; default 300): the multi-process tests
+# wait 120-300 s for their children, and a run that cannot connect should fail with the parties' own messages, not with
+# a TimeoutExpired
+os.environ.setdefault("LINREG_CONNECT_TIMEOUT", "60")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
