@@ -617,8 +617,12 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
 #endif
         size_t mv_waves = mv_target / (P.merge_hint ? P.merge_hint : 1);
         if (mv_waves < 2 * d) mv_waves = 2 * d < mv_target ? 2 * d : mv_target;     // at least two records per row
-        size_t kara_min = kTargetWaves / (P.merge_hint ? P.merge_hint : 1);          // Karatsuba products where d * d exceeds this
-        if (kara_min < 2 * d) kara_min = 2 * d < kTargetWaves ? 2 * d : kTargetWaves;
+        size_t kara_target = kTargetWaves;
+#ifdef GC_X_MV_WAVES_ENV     /* timing experiments only */
+        if (const char *e = getenv("LGC_X_KARA_MIN")) if (atol(e) > 0) kara_target = (size_t)atol(e);
+#endif
+        size_t kara_min = kara_target / (P.merge_hint ? P.merge_hint : 1);          // Karatsuba products where d * d exceeds this
+        if (kara_min < 2 * d) kara_min = 2 * d < kara_target ? 2 * d : kara_target;
         const uint32_t sc_dot = P.alloc_dots(d * d, d, mv_waves);
         if (trace) P.rv_trace = P.alloc_reveal((size_t)iters * (d + 4));
         // Karatsuba products for A p (w = 64): the words hdiff(M[i][j]) -- once per solve -- and hdiff(p[k]) -- once per
