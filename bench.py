@@ -35,6 +35,88 @@ def ref_equiv_gates(d, iters):
     return (total20 - 20 * per_it) + iters * per_it
 
 
+COMPACT_LIMIT = 4096             # the driver keeps ~8 000 characters of stdout: the LAST line must stay far below that
+
+
+def _r(v, nd=6):
+    """floats to `nd` significant digits (the full-precision figures are in bench_detail.json)"""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, float):
+        return float("%.*g" % (nd, v))
+    return v
+
+
+def _pick(dct, keys):
+    return {k: _r(dct[k]) for k in keys if dct is not None and k in dct}
+
+
+def compact_line(out, limit=COMPACT_LIMIT):
+    """The ONE stdout line of a bench run: the headline, its roofline / aes_roofline / cpu_baseline and one number per
+    secondary measurement, at most `limit` bytes (the 30 KB line of round 4 did not survive the driver's
+    8 000-character stdout tail, so the round's headline went unmeasured).  Everything else -- timelines, the sweep model,
+    notes, definitions -- stays in the detail dict, which main() writes to bench_detail.json."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data", "exact_vs_oracle", "barrier_backend", "rccl_ranks", "devices", "gate_hash",
+                       "and_gates_per_solve", "ref_equiv_gates_per_s"))
+    cfg = out.get("config") or {}
+    line["config"] = {"workload": "d=%s CGD-%s %s-bit p=%s, two-party masked input, garbler+evaluator co-located; one system per GPU"
+                                  % (cfg.get("d"), cfg.get("iterations"), cfg.get("width"), cfg.get("precision")),
+                      **_pick(cfg, ("d", "iterations", "width", "precision", "sharding"))}
+    rf = out.get("roofline")
+    if rf:
+        line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms",
+                                      "alg_bytes_per_launch", "binding"))
+        fl = rf.get("flat_list_equiv")
+        if fl:
+            line["roofline"]["flat_list_required_over_peak"] = _r(fl.get("required_over_peak"))
+    ar = out.get("aes_roofline")
+    if ar:
+        line["aes_roofline"] = _pick(ar, ("achieved", "achieved_eval_kernel", "peak", "unit", "frac", "frac_eval_kernel", "micro_kernel"))
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "model", "total_cores"))
+        line["cpu_baseline"]["spread"] = _r((cb.get("repeats") or {}).get("spread"))
+        line["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:160]
+        if cb.get("checker_error"):
+            line["cpu_baseline"]["checker_error"] = str(cb["checker_error"])[:120]
+    e2e = out.get("phase12")
+    if e2e:
+        p12 = {}
+        for res in e2e:
+            p12[res.get("config", "?")] = _r(res.get("phase12_wall_s"), 4) if "error" not in res else "error: " + str(res["error"])[-80:]
+        p12["all_exact"] = all(res.get("exact_vs_oracle") is True for res in e2e)
+        line["phase12"] = p12
+    ring = out.get("two_process_ring")
+    if ring:
+        line["two_process_ring"] = _pick(ring, ("seconds_garble_eval", "and_gates_per_s")) if "error" not in ring else {"error": str(ring["error"])[-120:]}
+    sw = out.get("sweep64")
+    if sw:
+        c = _pick(sw, ("lambdas", "d", "iterations", "n_gpus", "seconds", "and_gates_per_s", "prefix_bytes_broadcast",
+                       "create_s", "prefix_garble_s", "broadcast_s", "block_s", "gather_s", "block_lambdas",
+                       "predicted_seconds", "measured_over_predicted", "predicted_from"))
+        c["exact"] = sw.get("exact_vs_oracle")
+        model = (sw.get("model") or {}).get("by_n_gpus")
+        if model:                       # N = 1: what this GPU predicts for the sharded runs, one number each
+            c["predicted_seconds_by_n_gpus"] = {k: _r(v["predicted_seconds"], 4) for k, v in model.items()}
+        line["sweep64"] = c
+    if out.get("alt_gate_hash"):
+        line["alt_gate_hash"] = _pick(out["alt_gate_hash"], ("gate_hash", "seconds_per_solve", "and_gates_per_s", "same_integers_as_headline"))
+    line["detail"] = out.get("detail_file", "bench_detail.json")
+    txt = json.dumps(line, separators=(",", ":"))
+    # belt and braces: drop the least important keys rather than ever print a line the driver cannot keep whole
+    for victim in ("alt_gate_hash", "devices", "two_process_ring", "phase12", "sweep64", "cpu_baseline"):
+        if len(txt) <= limit:
+            break
+        if victim == "devices":
+            line["devices"] = len(line.get("devices") or [])
+        else:
+            line.pop(victim, None)
+            line.setdefault("dropped", []).append(victim)
+        txt = json.dumps(line, separators=(",", ":"))
+    return txt
+
+
 def cpu_info():
     model = None
     try:
@@ -164,6 +246,22 @@ def sweep_model(np, sweep, shares, lams, d, make, t_all, st_all):
             "n1_seconds": t_all, "n1_create_s": st_all.get("create_s"), "n1_block_s": st_all.get("block_s"), "by_n_gpus": rows,
             "assumptions": "broadcast = prefix bytes / 153 GB/s (one xGMI link per peer, links in parallel); gather = 50 us + bytes / link; "
                            "ring of the block already parked (the warm-up of a real run does that); no allowance for RCCL call latency"}
+
+
+def load_sweep_prediction(world, nl, sd, sit):
+    """predicted seconds of the `nl`-lambda sweep on `world` GPUs according to an N = 1 run's model, and where it came from"""
+    cands = [os.path.join(os.environ.get("LGC_BENCH_DETAIL_DIR") or os.getcwd(), "bench_detail.json"),
+             os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "profiles", "sweep_model.json")]
+    for path in cands:
+        try:
+            dct = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        sw = dct.get("sweep64") or {}
+        row = ((sw.get("model") or {}).get("by_n_gpus") or {}).get(str(world))
+        if row and (sw.get("lambdas"), sw.get("d"), sw.get("iterations")) == (nl, sd, sit):
+            return float(row["predicted_seconds"]), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def _free_ports(k):
@@ -670,7 +768,17 @@ def main():
                          **dict(zip(phase_keys, phases)),
                          "collectives": ("broadcast(seed, garbled prefix) + all_gather(results) over %s" % backend) if world > 1 else None,
                          "sharding": "contiguous blocks of %d lambdas per rank; prefix (input labels + share-summation tables) garbled once on rank 0" % ((nl + world - 1) // world)}
+            sweep_res["block_lambdas"] = (nl + world - 1) // world
             sweep_check = (stot, sT, sd, sit, lams, sres, nl)      # compared with the oracle in the cpu_baseline leg
+            if world > 1:
+                # what the N = 1 run's model said this N would take (sweep_model, below): from the N = 1 detail file when that run
+                # left one beside us, else from the committed profile of the builder's last N = 1 run -- so that the first
+                # real multi-GPU run shows measured / predicted in its own line
+                pred, src = load_sweep_prediction(world, nl, sd, sit)
+                if pred is not None:
+                    sweep_res["predicted_seconds"] = pred
+                    sweep_res["measured_over_predicted"] = sdt / pred
+                    sweep_res["predicted_from"] = src
             if world == 1 and not args.no_sweep_model and nl >= 16:
                 sweep_res["model"] = sweep_model(np, sweep, sshares, lams, sd, make, sdt, sst)
 
@@ -720,8 +828,9 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                     "binding": "lds_aes",
                     "flat_list_equiv": {"bytes_per_solve": flat_bytes, "GBs": flat_bytes / step_s / 1e9,
-                                        "frac": flat_bytes / step_s / 1e9 / HBM_PEAK_GBS,
-                                        "formula": "192 N_AND + 128 N_XOR over the whole solve / seconds per solve",
+                                        "required_over_peak": flat_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                                        "formula": "192 N_AND + 128 N_XOR over the whole solve / seconds per solve: what a flat gate "
+                                                   "list WOULD have to stream to keep this pace (not achieved bandwidth; > 1 = more than the HBM delivers)",
                                         "n_and": gates, "n_xor": n_xor,
                                         "n_xor_rule": "word-level XORs of two wire words x width (lane moves, public selects, inverters = wiring)"},
                     "kernel": "gc_mack_kernel<garbler>" if karatsuba else "gc_mac_kernel<garbler>", "avg_launch_ms": avg_dur * 1e3,
@@ -740,6 +849,7 @@ def main():
                                          "peak_source": "256 CUs x 64 lanes/clk x 2.4 GHz / 168 integer instructions per permutation"}
         aes_roofline = {"achieved": aes_achieved, "achieved_eval_kernel": aes_achieved_eval,
                         "peak": lds_roof, "unit": "AES-128 blocks/s", "frac": aes_achieved / lds_roof,
+                        "frac_eval_kernel": aes_achieved_eval / lds_roof,
                         "peak_source": "LDS lookup roof: 256 CUs x 64 lanes x 2.4 GHz / (160 ds_read_b32 x 2 LDS cycles)",
                         "micro_kernel": aes_rate,
                         "micro_kernel_source": "lgc_aes_bench (stand-alone four-table AES kernel), best of 3 in this run"}
@@ -872,7 +982,16 @@ def main():
             "phase12": e2e, "two_process_ring": ring, "sweep64": sweep_res,
             "beta0": float(int(beta_fixed[0]) / scale),
         }
-        print(json.dumps(out), flush=True)
+        # the full record goes to a side file (and nowhere near stdout); stdout gets ONE compact line
+        ddir = os.environ.get("LGC_BENCH_DETAIL_DIR") or os.getcwd()
+        dname = "bench_detail.json" if world == 1 else "bench_detail_n%d.json" % world
+        out["detail_file"] = dname
+        try:
+            with open(os.path.join(ddir, dname), "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:                      # a read-only working directory must not cost the line
+            out["detail_file"] = "not written: %s" % e
+        print(compact_line(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -8,7 +8,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+export LGC_BENCH_DETAIL_DIR=$O   # bench.py: the long record (bench_detail.json) beside the one-line stdout
 python3 $R/bench.py > $O/bench_line.json 2> $O/bench.err
+export LGC_BENCH_DETAIL_DIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic --no-e2e --no-sweep > $O/bench_stats_run.json 2> $O/stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --child > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --child > /dev/null 2> $O/pmc_write.err

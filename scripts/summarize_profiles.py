@@ -19,7 +19,7 @@ for src, dst in (("stats/**/*_kernel_stats.csv", "bench_kernel_stats.csv"), ("st
     f = one(src)
     if f:
         shutil.copy(f, os.path.join(P, tag + "_" + dst))
-for name in ("bench_line.json", "launch_profile_d500_cgd15.txt", "launch_profile_d100_cgd15.txt", "launch_profile_d20_cholesky.txt",
+for name in ("bench_line.json", "bench_detail.json", "launch_profile_d500_cgd15.txt", "launch_profile_d100_cgd15.txt", "launch_profile_d20_cholesky.txt",
              "launch_profile_d500_cgd20_w32.txt", "probe.txt", "ot_probe.txt", "phase1_probe.txt", "phase1_baseline.jsonl",
              "startup_timeline.json", "startup_timeline.txt", "valu_issue.txt", "split_trace.txt", "hip_init.txt", "hip_exit.txt"):
     if os.path.exists(os.path.join(O, name)):

@@ -23,8 +23,18 @@ def _free_port():
     return free_ports(1)[0]
 
 
+def _last_line(stdout):
+    """what the driver does: the LAST line of stdout must be one complete JSON object, and short enough to survive its
+    8 000-character tail (a 30 KB line went unparsed)"""
+    lines = stdout.decode().rstrip("\n").splitlines()
+    assert lines, "no output"
+    assert len(lines[-1]) <= 4096, len(lines[-1])
+    return json.loads(lines[-1])
+
+
 def test_bench_two_ranks_share_one_gpu(tmp_path, oracle):
-    env = dict(os.environ, LGC_BENCH_BACKEND="gloo", LGC_BENCH_DUMP=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, LGC_BENCH_BACKEND="gloo", LGC_BENCH_DUMP=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               LGC_BENCH_DETAIL_DIR=str(tmp_path))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     # plain `python bench.py --gpus 2`, no launcher: bench.py starts its own ranks (what a driver without torchrun gets)
@@ -33,8 +43,7 @@ def test_bench_two_ranks_share_one_gpu(tmp_path, oracle):
            "--no-cpu-baseline", "--no-traffic", "--no-e2e"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    out = _last_line(r.stdout)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["n_gpus"] == out["rccl_ranks"] or out["barrier_backend"] == "gloo"
     assert out["rccl_ranks"] is None and len(out["devices"]) == 1           # two ranks, one GPU, no RCCL group: said so
@@ -42,7 +51,9 @@ def test_bench_two_ranks_share_one_gpu(tmp_path, oracle):
     for k in ("create_s", "prefix_garble_s", "broadcast_s", "block_s", "gather_s"):
         assert sw[k] >= 0.0
     assert sw["block_s"] > 0.0 and sw["prefix_garble_s"] > 0.0
-    assert sw["n_gpus"] == 2 and sw["lambdas"] == 5 and sw["prefix_bytes_broadcast"] > 0 and "broadcast" in sw["collectives"]
+    assert sw["n_gpus"] == 2 and sw["lambdas"] == 5 and sw["prefix_bytes_broadcast"] > 0
+    detail = json.load(open(os.path.join(str(tmp_path), out["detail"])))      # the long form: bench_detail_n2.json
+    assert "broadcast" in detail["sweep64"]["collectives"] and detail["value"] == pytest.approx(out["value"], rel=1e-4)
     dumps = [json.load(open(os.path.join(str(tmp_path), "sweep_rank%d.json" % k))) for k in (0, 1)]
     assert dumps[0]["beta"] == dumps[1]["beta"]                      # every rank holds the gathered results
     d0 = dumps[0]
@@ -61,18 +72,27 @@ def test_bench_eight_ranks_rehearse_the_full_sweep_on_one_gpu(tmp_path, oracle):
     imported on seven ranks, blocks at gate-step offsets 8k x stride, all_gather) with every one of the 64 results checked
     against the oracle.  Each rank's table ring gets 512 MiB of run-ahead room instead of 8 GiB so that eight of them fit
     288 GB together (LGC_RING_SLACK_MB); on an 8-GPU node the default applies.  The headline part of the bench is kept tiny."""
-    env = dict(os.environ, LGC_BENCH_BACKEND="gloo", LGC_BENCH_DUMP=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", LGC_RING_SLACK_MB="512")
+    env = dict(os.environ, LGC_BENCH_BACKEND="gloo", LGC_BENCH_DUMP=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", LGC_RING_SLACK_MB="512",
+               LGC_BENCH_DETAIL_DIR=str(tmp_path))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
            "--dimension", "24", "--iters", "2", "--no-cpu-baseline", "--no-traffic", "--no-e2e"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    out = _last_line(r.stdout)            # the line the driver's SCALE run will have to parse: whole, short, every key there
     assert out["n_gpus"] == 8 and out["barrier_backend"] == "gloo" and out["rccl_ranks"] is None and len(out["devices"]) == 1
+    for k in ("metric", "value", "unit", "ms_per_step", "scaling", "rccl_ranks", "devices", "config", "roofline", "sweep64"):
+        assert k in out, k
     sw = out["sweep64"]
     assert (sw["n_gpus"], sw["lambdas"], sw["d"], sw["iterations"]) == (8, 64, 100, 15)
-    assert sw["prefix_bytes_broadcast"] > 100e6 and sw["block_s"] > 0 and "8 lambdas per rank" in sw["sharding"]
+    for k in ("seconds", "create_s", "prefix_garble_s", "broadcast_s", "block_s", "gather_s"):
+        assert sw[k] >= 0.0, k
+    assert sw["prefix_bytes_broadcast"] > 100e6 and sw["block_s"] > 0 and sw["block_lambdas"] == 8
+    # the N = 1 model's prediction for eight GPUs rides in the same line (profiles/sweep_model.json here: no N = 1 run
+    # left a detail file in this directory), so the first real 8-GPU run shows measured / predicted
+    assert sw["predicted_seconds"] > 0 and sw["measured_over_predicted"] == pytest.approx(sw["seconds"] / sw["predicted_seconds"], rel=1e-3)
+    assert "8 lambdas per rank" in json.load(open(os.path.join(str(tmp_path), out["detail"])))["sweep64"]["sharding"]
     dumps = [json.load(open(os.path.join(str(tmp_path), "sweep_rank%d.json" % k))) for k in range(8)]
     assert all(dk["beta"] == dumps[0]["beta"] for dk in dumps)               # every rank holds the gathered results
     d0 = dumps[0]
@@ -87,13 +107,13 @@ def test_bench_eight_ranks_rehearse_the_full_sweep_on_one_gpu(tmp_path, oracle):
 
 def test_bench_launcher_and_self_launch_agree(tmp_path):
     """the torch.distributed.run form the driver documents still works (WORLD_SIZE set: no second level of children)"""
-    env = dict(os.environ, LGC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, LGC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", LGC_BENCH_DETAIL_DIR=str(tmp_path))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
            "--dimension", "12", "--iters", "1", "--no-sweep", "--no-cpu-baseline", "--no-traffic", "--no-e2e"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    out = _last_line(r.stdout)
     assert out["n_gpus"] == 2 and out["barrier_backend"] == "gloo" and out["rccl_ranks"] is None
 
 
@@ -117,7 +137,7 @@ def test_bench_collectives_through_rccl_one_rank(tmp_path, oracle):
     """The box has one GPU, so the RCCL group has one rank -- but every collective of the N > 1 path (barrier, broadcast
     of the seed and of the exported prefix in device memory, all_gather, all_reduce of the timings) goes through RCCL on
     device tensors here, which the two-rank gloo run above cannot show."""
-    env = dict(os.environ, LGC_BENCH_FORCE_DIST="1", LGC_BENCH_DUMP=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, LGC_BENCH_FORCE_DIST="1", LGC_BENCH_DUMP=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", LGC_BENCH_DETAIL_DIR=str(tmp_path))
     env.pop("LGC_BENCH_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
@@ -125,7 +145,7 @@ def test_bench_collectives_through_rccl_one_rank(tmp_path, oracle):
            "--no-cpu-baseline", "--no-traffic", "--no-e2e"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    out = _last_line(r.stdout)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["barrier_backend"] == "nccl"
     assert out["rccl_ranks"] == 1 and len(out["devices"]) == 1
     d0 = json.load(open(os.path.join(str(tmp_path), "sweep_rank0.json")))
