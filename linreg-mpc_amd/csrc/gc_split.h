@@ -30,7 +30,11 @@ template <int CTRL> __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
 
 // lane 4j + c: x = column c of label j, twc = tweak word of this column (c = 0: low, c = 1: high, else 0).
 // Returns column c of H(x_j, tweak_j) = pi(sigma(x) ^ t) ^ sigma(x) ^ t  (gc_aes.h: hash_prep / hash_n)
-__device__ __forceinline__ uint32_t hash_split(const LdsTab4 &lt, const uint32_t rkl[11], uint32_t x, uint32_t twc, int c) {
+// `beside(rnd)`: work that does not depend on the hash, called once per round between the lookups and their use -- a lone
+// wave waits there for the LDS anyway (the adder levels compute the next level's addresses in those gaps)
+struct HashNoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <class F = HashNoHook>
+__device__ __forceinline__ uint32_t hash_split(const LdsTab4 &lt, const uint32_t rkl[11], uint32_t x, uint32_t twc, int c, F beside = F()) {
     const uint32_t t = quad_perm<0x4E>(x);                 // lanes 0,1 <- columns 2,3 ; lanes 2,3 <- columns 0,1
     const uint32_t k = (c < 2) ? (t ^ twc) : (x ^ t);
     uint32_t s = k ^ rkl[0];
@@ -43,6 +47,7 @@ __device__ __forceinline__ uint32_t hash_split(const LdsTab4 &lt, const uint32_t
         // measured no faster: scripts/exp/lat4.hip 2 118 against 2 142 cycles, the divider 2 % slower)
         const uint32_t s1 = quad_perm<0x39>(s), s2 = quad_perm<0x4E>(s), s3 = quad_perm<0x93>(s);   // columns c+1, c+2, c+3
         const uint32_t v0 = lt.lkt(0, s, 0), v1 = lt.lkt(1, s1, 1), v2 = lt.lkt(2, s2, 2), v3 = lt.lkt(3, s3, 3);
+        beside(rnd);
         s = xor3(xor3(v0, v1, rkl[rnd]), v2, v3);
     }
     const uint32_t s1 = quad_perm<0x39>(s), s2 = quad_perm<0x4E>(s), s3 = quad_perm<0x93>(s);
@@ -61,8 +66,9 @@ enum {
     kSplitX = 4 * kSplitWord,              // results of hash 0..3 (adder: sum, final generate word)
     kSplitKs = 8 * kSplitWord,             // adder levels: two buffers of hash results (level parity; words 0, 1 of each used)
     kSplitGs = 16 * kSplitWord,            // adder levels: two published states (G, P), alternating
-    kSplitDesc = 20 * kSplitWord,          // kind, act1 (2), act2 (2), step (2): two 16-byte stores
-    kSplitWords = 20 * kSplitWord + 8
+    kSplitDesc = 20 * kSplitWord,          // kind | n << 8, step (2), act1 (2), act2 (2): two 16-byte stores (an addition reads the first)
+    kSplitZero = 20 * kSplitWord + 8,      // a dword that stays zero: the "no word here" operand of the adder levels
+    kSplitWords = 20 * kSplitWord + 16
 };
 
 struct SplitDesc {
@@ -78,6 +84,7 @@ struct SplitHashCtx {
     uint32_t rkl[11];       // round-key column lane & 3
     uint32_t Rq;            // column lane & 3 of the garbler's offset R (0 for the evaluator)
     uint32_t *sx;           // LDS exchange areas
+    __attribute__((address_space(3))) uint32_t *sxl;   // the same, as an LDS pointer (32-bit arithmetic in the adder levels)
     uint32_t *tabw;         // this launch's table buffer, as dwords
     uint64_t launch_step0;
     int wave, lane;
@@ -142,146 +149,271 @@ __device__ __forceinline__ void split_hash_phase(const SplitHashCtx &hc, const S
 }
 
 // A whole addition (gc_circuits.h: Circ::add_generic, the Sklansky prefix adder) run by the hash waves in quad layout with
-// ONE barrier per level.  Posted by the glue waves with x, y and the carry-in word in operand words 0..2; sum and final
-// generate word come back in result words 0 and 1.  Gate steps, their order, lanes and activity masks are exactly those of
-// Circ::add_generic: the first AND, then one step per level k, in which lane i with bit k set holds the G-gate of node i
-// (P_i & G_m, m = the top lane of the lower half of i's block of 2^(k+1)) and lane i - 2^k the P-gate of node i (P_i & P_m).
+// ONE barrier per level.  Posted by the glue waves with x, y and the carry-in word in operand words 0..2.  Gate steps, their
+// order, lanes and activity masks are exactly those of Circ::add_generic: the first AND, then one step per level k, in which
+// lane i with bit k set holds the G-gate of node i (P_i & G_m, m = the top lane of the lower half of i's block of 2^(k+1))
+// and lane i - 2^k the P-gate of node i (P_i & P_m).
 //
 // A level is a single gate step: two hashes per gate, waves q = 0 (operand a) and q = 1 (operand b), eight of the sixteen
-// waves -- 1484 cycles in scripts/exp/lat4.hip against 2142 for the four-hash levels of the Kogge-Stone form this replaces
-// (round 2), and six levels after the first AND in both.  Wave q = 2 keeps the published state one level behind:
+// waves.  Wave q = 2 keeps the published state one level behind:
 //   state after level k - 1 at lane t:  G = G_pub(k-2)[t] ^ (bit k-1 of t ? X0 ^ X1 of level k-1 at t : 0)
 //                                       P = (t was a P-node of level k-1 ? X0 ^ X1 of level k-1 at t - 2^(k-1) : P_pub(k-2)[t])
-// (X0, X1: the two hash results of a gate; their XOR is the gate's output label).  Every hash lane rebuilds the two
-// states it needs -- its own node's and m's -- from what the last barrier made visible, the publisher writes state k - 1
-// for level k + 1; results and published states alternate between two buffers.
+// (X0, X1: the two hash results of a gate; their XOR is the gate's output label).  Every hash lane rebuilds what it needs
+// from what the last barrier made visible; results and published states alternate between two buffers.
+//
+// Round 5 (profiles/r4_split_trace.txt: 430-1020 cycles between a level's barrier and its first AES round, 200-700 more at
+// the next barrier waiting for the slower wave, 1 750-2 900 between two additions):
+//   * a hash wave rebuilds ITS OWN operand first -- every operand is the XOR of three LDS words, words a lane does not need
+//     read a zero dword -- and hashes as soon as those three are back.  The OTHER operand enters only after the hash (the
+//     garbler's a-wave needs the colour of b, the evaluator's b-wave the label a for its second ciphertext; the garbler's
+//     b-wave and the evaluator's a-wave need nothing): its loads are issued before the hash and picked up behind it;
+//   * the addresses of level k + 1 do not depend on data: they are computed while level k's loads are in flight, so the
+//     path from the barrier to the first AES round is three loads and two XORs;
+//   * the roles q = 0 / 1 are compiled separately (no per-lane selects between the two operand sets);
+//   * the sum and the carry-out are formed by the glue waves straight from the last level's results (they are visible to
+//     every wave after that level's barrier): no final pass in quad layout, no second hand-over barrier per addition.
 #ifndef GC_SPLIT_TRACE
 #define GC_SPLIT_TRACE 0      /* timing experiments only (scripts/exp/split_trace.py): s_memtime stamps of the adder levels of record 0 */
 #endif
 #if GC_SPLIT_TRACE
 static __device__ uint64_t g_split_trace[2 * 8192];
 static __device__ uint32_t g_split_trace_n[2];
+struct SkTrace { bool on; int w; uint32_t i; };
 #define SPLIT_STAMP(tag)                                                                                         \
-    if (tr_on) {                                                                                                 \
+    if (tr.on) {                                                                                                 \
         uint64_t t_;                                                                                             \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_));                                         \
-        if (hc.lane == 0 && tr_i < 8192) g_split_trace[tr_w * 8192 + tr_i] = (t_ << 4) | (uint64_t)(tag);        \
-        tr_i++;                                                                                                  \
+        if (hc.lane == 0 && tr.i < 8192) g_split_trace[tr.w * 8192 + tr.i] = (t_ << 4) | (uint64_t)(tag);        \
+        tr.i++;                                                                                                  \
     }
 #else
+struct SkTrace {};
 #define SPLIT_STAMP(tag)
 #endif
-template <bool GARBLER>
-__device__ __forceinline__ void split_sk_add(const SplitHashCtx &hc, const SplitDesc &d) {
-    const int q = hc.wave >> 2, r = hc.wave & 3, c = hc.lane & 3, g = 16 * r + (hc.lane >> 2);
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// the three LDS words whose XOR is an operand: own (hashed by this wave) and other (needed after the hash, or not at all)
+struct SkPtrs {
+    const lds_u32 *o0, *o1, *o2;
+    const lds_u32 *p0, *p1, *p2;
+};
+
+// number of prefix levels of an n-lane addition
+__device__ __forceinline__ int sk_levels(int n) { return n <= 1 ? 0 : 32 - __builtin_clz((uint32_t)(n - 1)); }
+
+// Operand words of level k at gate g (k = -1: the first AND of the addition, a = x ^ cin, b = y ^ cin at the own gate):
+//   a = P of the own node t (t = g for a G-gate lane, g + 2^k for a P-gate host): two words
+//   b = G of m (G-gate lane) or P of m (host), m = top lane of the lower half of the block: three words
+// in plane `pl`.  They depend on k, g and the plane only -- not on the operands, the width of the addition or the activity
+// masks.  Level 0 reads the first AND's results (buffer 0) and the operand words; level k > 0 the results of level k - 1
+// and the state published for level k - 2.
+__device__ __forceinline__ void sk_words_a(const lds_u32 *sx, int k, int g, int pl, const lds_u32 *&a0, const lds_u32 *&a1) {
+    const lds_u32 *opx = sx + kSplitOp + pl, *opy = opx + kSplitWord, *opc = opx + 2 * kSplitWord;
+    if (k < 0) { a0 = opx + g; a1 = opc + g; return; }
+    const int h = 1 << k, hp = h >> 1;
+    const int t = ((g >> k) & 1) ? g : ((g + h) & 63);
+    if (k == 0) { a0 = opx + t; a1 = opy + t; return; }
+    const lds_u32 *X0 = sx + kSplitKs + ((k & 1) * 4) * kSplitWord + pl, *X1 = X0 + kSplitWord;           // results of level k - 1
+    const lds_u32 *Pp = sx + kSplitGs + (((k - 1) & 1) * 2 + 1) * kSplitWord + pl;                          // published P, state k - 2
+    const bool tp = (g >> (k - 1)) & 1;                 // t was a P-node of level k - 1 (t >= 2^k, and t = g mod 2^k)
+    const int ti = tp ? t - hp : t;
+    a0 = (tp ? X0 : Pp) + ti;
+    a1 = tp ? X1 + ti : sx + kSplitZero;
+}
+__device__ __forceinline__ void sk_words_b(const lds_u32 *sx, int k, int g, int pl, const lds_u32 *&b0, const lds_u32 *&b1, const lds_u32 *&b2) {
+    const lds_u32 *opx = sx + kSplitOp + pl, *opy = opx + kSplitWord, *opc = opx + 2 * kSplitWord;
+    const lds_u32 *zero = sx + kSplitZero;
+    if (k < 0) { b0 = opy + g; b1 = opc + g; b2 = zero; return; }
+    const int h = 1 << k, hp = h >> 1;
+    const bool up = (g >> k) & 1;
+    const int mb = (g & ~(2 * h - 1)) | (h - 1);
+    const lds_u32 *X0 = sx + kSplitKs + ((k & 1) * 4) * kSplitWord + pl, *X1 = X0 + kSplitWord;
+    if (k == 0) {
+        b0 = (up ? X0 : opx) + mb;
+        b1 = (up ? X1 : opy) + mb;
+        b2 = up ? opc + mb : zero;
+        return;
+    }
+    const lds_u32 *Gp = sx + kSplitGs + (((k - 1) & 1) * 2) * kSplitWord + pl;                               // published G, state k - 2
+    const int mi = up ? mb : ((mb - hp) & 63);          // (m is a G-node and, for hosts, a P-node of level k - 1)
+    b0 = X0 + mi;
+    b1 = X1 + mi;
+    b2 = up ? Gp + mb : zero;
+}
+// own / other operand of hash role Q (0: a, 1: b): own in plane pl, other in plane plo
+template <int Q>
+__device__ __forceinline__ void sk_ptrs_own(SkPtrs &r, const lds_u32 *sx, int k, int g, int pl) {
+    if (Q == 0) { sk_words_a(sx, k, g, pl, r.o0, r.o1); r.o2 = sx + kSplitZero; }
+    else sk_words_b(sx, k, g, pl, r.o0, r.o1, r.o2);
+}
+template <int Q>
+__device__ __forceinline__ void sk_ptrs_oth(SkPtrs &r, const lds_u32 *sx, int k, int g, int plo) {
+    if (Q == 0) sk_words_b(sx, k, g, plo, r.p0, r.p1, r.p2);
+    else { sk_words_a(sx, k, g, plo, r.p0, r.p1); r.p2 = sx + kSplitZero; }
+}
+
+// what a hash lane knows about a level before the level's operands exist: where they will be, whether its gate is active,
+// its tweak column and its dword of the step's table row.  Computed one level ahead (sk_plan), off the dependent chain.
+struct SkPlan {
+    SkPtrs ptr;
+    uint32_t twc;           // tweak word of this lane's column (c = 0: low, c = 1: high, else 0)
+    bool on;                // this lane's gate is active in the step
+    bool any;               // some gate of this wave's sixteen is (wave-uniform)
+};
+// activity of gate g in level k of an n-lane addition (Circ::add_generic: bitk | host): a G-gate lane (bit k of g set) is
+// active below n; a lane with bit k clear hosts the P-gate of node g + 2^k if that node's P is still needed (g >= 2^(k+1))
+// and the node is below n.  k = -1: the first AND.
+__device__ __forceinline__ bool sk_gate_on(int k, int g, int n) {
+    if (k < 0) return g < n;
+    const int h = 1 << k;
+    return ((g >> k) & 1) ? (g < n) : (g >= 2 * h && g + h < n);
+}
+// part 0 .. 3 of the plan of level k (one part per AES round of the level before: sk_finish)
+template <bool GARBLER, int Q>
+__device__ __forceinline__ void sk_plan_part(SkPlan &r, int part, const lds_u32 *sx, int k, int g, int c, int pl, int plo, int n, uint64_t st) {
+    constexpr bool kNeedOth = GARBLER ? (Q == 0) : (Q == 1);
+    if (part == 0) sk_ptrs_own<Q>(r.ptr, sx, k, g, pl);
+    if (part == 1) { if (kNeedOth) sk_ptrs_oth<Q>(r.ptr, sx, k, g, plo); else { r.ptr.p0 = r.ptr.p1 = r.ptr.p2 = sx + kSplitZero; } }
+    if (part == 2) {
+        const uint32_t tlo = ((uint32_t)st << 7) | (uint32_t)(2 * g + Q), thi = (uint32_t)(st >> 25);
+        r.twc = (c == 0) ? tlo : (c == 1) ? thi : 0u;
+    }
+    if (part == 3) {
+        r.on = sk_gate_on(k, g, n);
+        r.any = __builtin_amdgcn_ballot_w64(r.on) != 0ull;
+    }
+}
+template <bool GARBLER, int Q>
+__device__ __forceinline__ SkPlan sk_plan(const lds_u32 *sx, int k, int g, int c, int pl, int plo, int n, uint64_t st) {
+    SkPlan r;
+    for (int part = 0; part < 4; part++) sk_plan_part<GARBLER, Q>(r, part, sx, k, g, c, pl, plo, n, st);
+    return r;
+}
+
+// One hash of one level by role Q (wave 4Q + r: gates 16r .. 16r + 15), in two parts: sk_load issues the LDS reads of the
+// operand words, sk_finish hashes.
+//   garbler  : x_a = H(a0 ^ pa R, 2g) ^ (pa & pb) R,  x_b = H(b0 ^ pb R, 2g + 1);  rows 0 / 1 of the step receive a0 / b0
+//   evaluator: x_a = H(a, 2g) ^ sa TG,  x_b = H(b, 2g + 1) ^ sb (TE ^ a)
+// The other operand is read from plane 0 by the garbler (only its colour matters) and from the own plane by the evaluator.
+struct SkVals { uint32_t l0, l1, l2, m0, m1, m2; };
+template <bool GARBLER, int Q>
+__device__ __forceinline__ SkVals sk_load(const SkPtrs &ptr) {
+    constexpr bool kNeedOth = GARBLER ? (Q == 0) : (Q == 1);
+    SkVals v;
+    // operand a is the XOR of two words, operand b of three (sk_words_a, sk_words_b): the third pointer of an a-set is never read
+    v.l0 = *ptr.o0; v.l1 = *ptr.o1; v.l2 = (Q == 1) ? *ptr.o2 : 0u;
+    v.m0 = v.m1 = v.m2 = 0u;
+    if (kNeedOth) { v.m0 = *ptr.p0; v.m1 = *ptr.p1; v.m2 = (Q == 0) ? *ptr.p2 : 0u; }
+    return v;
+}
+// `beside`: work that does not depend on the hash (the plan of the next level); called inside the hash's basic block so that
+// the scheduler can put it into the waits of the AES rounds
+template <bool GARBLER, int Q, class F>
+__device__ __forceinline__ void sk_finish(const SplitHashCtx &hc, const SkPlan &lv, const SkVals &w, lds_u32 *xo, uint32_t *row, uint32_t tg, F beside) {
+    const int c = hc.lane & 3;
+    const bool on = lv.on;
+    const uint32_t twc = lv.twc;
+    if (!lv.any) {
+        *xo = 0u;
+        if (GARBLER) st_u32_global(row, 0u);
+        for (int rnd = 1; rnd < 10; rnd++) beside(rnd);
+        return;
+    }
+    const uint32_t v = xor3(w.l0, w.l1, w.l2);
+    if (GARBLER) st_u32_global(row, on ? v : 0u);
+    const uint32_t colour = quad_perm<0x00>(v) & 1u;                                   // lsb of column 0 of the own operand
+    const uint32_t x = GARBLER ? (v ^ (colour ? hc.Rq : 0u)) : v;
+    uint32_t h = hash_split(hc.lt, hc.rkl, x, twc, c, beside);
+    if (GARBLER) {
+        if (Q == 0) h ^= (colour & (w.m0 ^ w.m1 ^ w.m2) & 1u) ? hc.Rq : 0u;
+    } else {
+        h ^= colour ? ((Q == 1) ? (tg ^ xor3(w.m0, w.m1, w.m2)) : tg) : 0u;
+    }
+    *xo = on ? h : 0u;
+}
+
+// hash role Q of a whole addition: 1 + sk_levels(n) levels, one barrier behind each.  `pre`: the first AND's operand
+// words, already on their way (the hash waves issue them together with the read of the job descriptor)
+template <bool GARBLER, int Q>
+__device__ __forceinline__ void split_sk_hash(const SplitHashCtx &hc, int n, uint64_t st, const SkVals *pre) {
+    const int r = hc.wave & 3, c = hc.lane & 3, g = 16 * r + (hc.lane >> 2);
+    SkTrace tr;
 #if GC_SPLIT_TRACE
-    const bool tr_on = blockIdx.x == 0 && (hc.wave == 0 || hc.wave == 4);
-    const int tr_w = hc.wave == 4 ? 1 : 0;
-    uint32_t tr_i = tr_on ? g_split_trace_n[tr_w] : 0u;
+    tr.on = blockIdx.x == 0 && (hc.wave == 0 || hc.wave == 4);
+    tr.w = hc.wave == 4 ? 1 : 0;
+    tr.i = tr.on ? g_split_trace_n[tr.w] : 0u;
     SPLIT_STAMP(1)                                                                  /* addition entered (after the hand-over barrier) */
 #endif
-    const int pl = c * kSplitPlane;
-    const uint64_t act = d.act1;
-    const int n = 64 - __builtin_clzll(act);                                    // act = lanes(n)
-    const uint32_t *opx = hc.sx + kSplitOp + pl, *opy = opx + kSplitWord, *opc = opx + 2 * kSplitWord;
-    uint64_t st = d.step;
+    lds_u32 *sx = hc.sxl;
+    const int pl = c * kSplitPlane, plo = GARBLER ? 0 : pl;
+    const int L = sk_levels(n);
     // evaluator: the ciphertext row of a level is fetched one level ahead (every step index of the addition is known)
+    uint32_t *row = split_row(hc, Q, st);
     uint32_t tg = 0, tgn = 0;
-    if (!GARBLER && q < 2) {
-        tg = ld_u32_global(split_row(hc, q, st));
-        if (n > 1) tgn = ld_u32_global(split_row(hc, q, st + 1));
+    if (!GARBLER) {
+        tg = ld_u32_global(row);
+        if (L > 0) tgn = ld_u32_global(row + 512);
     }
     // first AND: G = ((x ^ cin) & (y ^ cin)) ^ cin.  Results of level k go to buffer (k + 1) & 1; this step counts as level -1
-    if (q < 2) {
-        const uint32_t xg = ld_u32_lds(opx + g), yg = ld_u32_lds(opy + g), cg = ld_u32_lds(opc + g);
-        split_hash_core<GARBLER>(hc, q, act, st, xg ^ cg, yg ^ cg, hc.sx + kSplitKs + q * kSplitWord, tg);
-    }
+    SkPlan cur = sk_plan<GARBLER, Q>(sx, -1, g, c, pl, plo, n, st), nxt;
+    SkVals w = pre ? *pre : sk_load<GARBLER, Q>(cur.ptr);
+    sk_finish<GARBLER, Q>(hc, cur, w, sx + kSplitKs + Q * kSplitWord + pl + g, row, tg,
+                          [&](int rnd) { if (rnd >= 2 && rnd < 6) sk_plan_part<GARBLER, Q>(nxt, rnd - 2, sx, 0, g, c, pl, plo, n, st + 1); });
     st += 1;
+    row += 512;
     SPLIT_STAMP(2)                                                                  /* first AND hashed, result stored */
     lds_barrier();
     SPLIT_STAMP(3)                                                                  /* past the barrier */
-    int k = 0;
-    for (int h = 1; h < n; h <<= 1, k++) {
-        const uint32_t *X0 = hc.sx + kSplitKs + ((k & 1) * 4) * kSplitWord + pl, *X1 = X0 + kSplitWord;   // results of level k - 1
-        const uint32_t *Gp = hc.sx + kSplitGs + (((k - 1) & 1) * 2) * kSplitWord + pl, *Pp = Gp + kSplitWord;   // published state k - 2
-        const int hp = h >> 1;
-        const uint64_t bitk = bit_lanes(k) & act;
-        const uint64_t pn = ((2 * h) < n) ? (bitk & ~(((2 * h) >= 64) ? ~0ull : ((1ull << (2 * h)) - 1ull))) : 0ull;
-        const uint64_t stepact = bitk | (pn >> h);
+    for (int k = 0; k < L; k++) {
+        cur = nxt;
+        w = sk_load<GARBLER, Q>(cur.ptr);
         tg = tgn;
-        if (!GARBLER && q < 2 && (2 * h) < n) tgn = ld_u32_global(split_row(hc, q, st + 1));     // row of the next level
-        // The state after level k - 1 at the two lanes this lane needs, WITHOUT branches (every load is issued before the
-        // first wait; a divergent if / else per role and per case cost two to four LDS round trips per level):
-        //   own node t = g (G-gate lane) or g + h (P-gate host):   P
-        //   m = top lane of the lower half of the block:           G (G-gate lane) or P (host)
-        // level 0 reads the first AND's results and the operand words; later levels the published state and the last results
-        if (q < 2) {
-            const bool up = (bitk >> g) & 1ull, host = ((pn >> h) >> g) & 1ull;
-            const int mb = (g & ~(2 * h - 1)) | (h - 1);
-            const int t = up ? g : ((g + h) & 63);
-            uint32_t a_op, b_op;
-            if (k == 0) {
-                const uint32_t px = ld_u32_lds(opx + t), py = ld_u32_lds(opy + t);
-                const uint32_t m0 = ld_u32_lds(X0 + mb), m1 = ld_u32_lds(X1 + mb), mc = ld_u32_lds(opc + mb);
-                const uint32_t mx = ld_u32_lds(opx + mb), my = ld_u32_lds(opy + mb);
-                a_op = px ^ py;
-                b_op = up ? (m0 ^ m1 ^ mc) : (mx ^ my);
-            } else {
-                const bool tp = ((t >> (k - 1)) & 1) && t >= h;                  // t was a P-node of level k - 1
-                const int ti = tp ? t - hp : t;
-                const uint32_t p1 = ld_u32_lds((tp ? X0 : Pp) + ti), p2 = ld_u32_lds(X1 + ti);
-                const int mi = up ? mb : ((mb - hp) & 63);                     // (m is a G-node and, for hosts, a P-node of level k - 1)
-                const uint32_t m0 = ld_u32_lds(X0 + mi), m1 = ld_u32_lds(X1 + mi), mg = ld_u32_lds(Gp + mb);
-                a_op = tp ? (p1 ^ p2) : p1;
-                b_op = m0 ^ m1 ^ (up ? mg : 0u);
-            }
-            if (!(up || host)) { a_op = 0u; b_op = 0u; }
-#if GC_SPLIT_TRACE
-            if (tr_on) { asm volatile("" :: "v"(a_op), "v"(b_op)); }
-            SPLIT_STAMP(4)                                                          /* operands rebuilt (LDS reads back) */
-#endif
-            split_hash_core<GARBLER>(hc, q, stepact, st, a_op, b_op, hc.sx + kSplitKs + (((k + 1) & 1) * 4 + q) * kSplitWord, tg);
-            SPLIT_STAMP(5)                                                          /* hashed, result stored */
-        } else if (q == 2) {
-            // publish state k - 1 of the own lane (read at level k + 1)
-            uint32_t *Go = hc.sx + kSplitGs + ((k & 1) * 2) * kSplitWord + pl;
-            const uint32_t x0 = ld_u32_lds(X0 + g), x1 = ld_u32_lds(X1 + g);
-            uint32_t Gs, Ps;
-            if (k == 0) {
-                Gs = x0 ^ x1 ^ ld_u32_lds(opc + g);
-                Ps = ld_u32_lds(opx + g) ^ ld_u32_lds(opy + g);
-            } else {
-                const bool gp = ((g >> (k - 1)) & 1) && g >= h;
-                const int gi = gp ? g - hp : g;
-                const uint32_t p1 = ld_u32_lds((gp ? X0 : Pp) + gi), p2 = ld_u32_lds(X1 + gi), go = ld_u32_lds(Gp + g);
-                Gs = go ^ (((g >> (k - 1)) & 1) ? (x0 ^ x1) : 0u);
-                Ps = gp ? (p1 ^ p2) : p1;
-            }
-            st_u32_lds(Go + g, Gs);
-            st_u32_lds(Go + kSplitWord + g, Ps);
-        }
+        if (!GARBLER && k + 1 < L) tgn = ld_u32_global(row + 512);                  // row of the next level
+        sk_finish<GARBLER, Q>(hc, cur, w, sx + kSplitKs + (((k + 1) & 1) * 4 + Q) * kSplitWord + pl + g, row, tg,
+                              [&](int rnd) { if (rnd >= 2 && rnd < 6) sk_plan_part<GARBLER, Q>(nxt, rnd - 2, sx, k + 1, g, c, pl, plo, n, st + 1); });
+        SPLIT_STAMP(5)                                                              /* hashed, result stored */
         st += 1;
+        row += 512;
         lds_barrier();
         SPLIT_STAMP(3)
     }
 #if GC_SPLIT_TRACE
-    if (tr_on && hc.lane == 0) g_split_trace_n[tr_w] = tr_i < 8192 ? tr_i : 8192;
+    if (tr.on && hc.lane == 0) g_split_trace_n[tr.w] = tr.i < 8192 ? tr.i : 8192;
 #endif
-    // carries = shl(G, 1) ^ cin on the active lanes; sum = P ^ carries; the final generate word for the carry out.
-    // Final G at lane t: the state after the last level (k levels were run)
-    if (q == 0) {
-        const uint32_t *X0 = hc.sx + kSplitKs + ((k & 1) * 4) * kSplitWord + pl, *X1 = X0 + kSplitWord;
-        const uint32_t *Gp = hc.sx + kSplitGs + (((k - 1) & 1) * 2) * kSplitWord + pl;
-        auto G_fin = [&](int t) -> uint32_t {
-            const uint32_t xr = ld_u32_lds(X0 + t) ^ ld_u32_lds(X1 + t);
-            if (k == 0) return xr ^ ld_u32_lds(opc + t);
-            return ld_u32_lds(Gp + t) ^ (((t >> (k - 1)) & 1) ? xr : 0u);
-        };
-        const uint32_t P0 = ld_u32_lds(opx + g) ^ ld_u32_lds(opy + g), cg = ld_u32_lds(opc + g);
-        const bool in = g < n;
-        const uint32_t Gsh = (in && g > 0) ? G_fin(g - 1) : 0u;
-        st_u32_lds(hc.sx + kSplitX + pl + g, P0 ^ Gsh ^ cg);
-        st_u32_lds(hc.sx + kSplitX + kSplitWord + pl + g, in ? G_fin(g) : 0u);
+}
+
+// the waves that do not hash in an addition: wave q = 2 publishes the state one level behind, wave q = 3 only keeps the barriers
+__device__ __forceinline__ void split_sk_side(const SplitHashCtx &hc, int n) {
+    const int q = hc.wave >> 2, r = hc.wave & 3, c = hc.lane & 3, g = 16 * r + (hc.lane >> 2);
+    lds_u32 *sx = hc.sxl;
+    const int pl = c * kSplitPlane;
+    const lds_u32 *opx = sx + kSplitOp + pl, *opy = opx + kSplitWord, *opc = opx + 2 * kSplitWord;
+    const int L = sk_levels(n);
+    lds_barrier();                                                                  // the first AND
+    for (int k = 0; k < L; k++) {
+        if (q == 2) {
+            // publish state k - 1 of the own lane (read at level k + 1; after the last level, by the glue waves)
+            const int h = 1 << k, hp = h >> 1;
+            const lds_u32 *X0 = sx + kSplitKs + ((k & 1) * 4) * kSplitWord + pl, *X1 = X0 + kSplitWord;      // results of level k - 1
+            const lds_u32 *Gp = sx + kSplitGs + (((k - 1) & 1) * 2) * kSplitWord + pl, *Pp = Gp + kSplitWord;  // published state k - 2
+            lds_u32 *Go = sx + kSplitGs + ((k & 1) * 2) * kSplitWord + pl;
+            const uint32_t x0 = X0[g], x1 = X1[g];
+            uint32_t Gs, Ps;
+            if (k == 0) {
+                Gs = x0 ^ x1 ^ opc[g];
+                Ps = opx[g] ^ opy[g];
+            } else {
+                const bool gp = ((g >> (k - 1)) & 1) && g >= h;
+                const int gi = gp ? g - hp : g;
+                const uint32_t p1 = (gp ? X0 : Pp)[gi], p2 = X1[gi], go = Gp[g];
+                Gs = go ^ (((g >> (k - 1)) & 1) ? (x0 ^ x1) : 0u);
+                Ps = gp ? (p1 ^ p2) : p1;
+            }
+            Go[g] = Gs;
+            Go[kSplitWord + g] = Ps;
+        }
+        lds_barrier();
     }
 }
 
@@ -311,8 +443,20 @@ struct SplitBackend {
         return ok ? v : 0u;
     }
     __device__ __forceinline__ W bblk(W a, int k) const { const int h = 1 << k; return pull(a, (lane & ~(2 * h - 1)) | (h - 1), true); }
-    __device__ __forceinline__ W shl(W a, int k) const { return k >= 64 ? 0u : pull(a, lane - k, lane >= k); }
-    __device__ __forceinline__ W shr(W a, int k) const { return k >= 64 ? 0u : pull(a, lane + k, lane + k < 64); }
+    // a shift by one lane is a DPP move over the whole wave (wave_shr:1 / wave_shl:1, zero into the end lane): the remainder
+    // of a divider moves up one lane per quotient bit, a square root's by two -- a ds_bpermute there is an LDS round trip on
+    // the glue waves' dependent chain
+    __device__ __forceinline__ W up1(W a) const { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x138, 0xf, 0xf, true); }
+    __device__ __forceinline__ W down1(W a) const { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x130, 0xf, 0xf, true); }
+    __device__ __forceinline__ W shl(W a, int k) const {
+        if (k == 1) return up1(a);
+        if (k == 2) return up1(up1(a));
+        return k >= 64 ? 0u : pull(a, lane - k, lane >= k);
+    }
+    __device__ __forceinline__ W shr(W a, int k) const {
+        if (k == 1) return down1(a);
+        return k >= 64 ? 0u : pull(a, lane + k, lane + k < 64);
+    }
 
     __device__ __forceinline__ const uint32_t *col(const Lbl *p) const { return reinterpret_cast<const uint32_t *>(p) + wave; }
     __device__ __forceinline__ uint32_t *col(Lbl *p) const { return reinterpret_cast<uint32_t *>(p) + wave; }
@@ -335,13 +479,15 @@ struct SplitBackend {
 
     __device__ __forceinline__ void publish(int k, W v) { st_u32_lds(hc.sx + kSplitOp + k * kSplitWord + wave * kSplitPlane + lane, v); }
     __device__ __forceinline__ W result(int q) const { return ld_u32_lds(hc.sx + kSplitX + q * kSplitWord + wave * kSplitPlane + lane); }
-    __device__ __forceinline__ void post(const SplitDesc &d) {
+    __device__ __forceinline__ void post(const SplitDesc &d, int n = 0) {
         if (wave == 0 && lane == 0) {
             typedef __attribute__((address_space(3))) gc_u32x4 *lds4;
-            gc_u32x4 lo = {d.kind, (uint32_t)d.act1, (uint32_t)(d.act1 >> 32), (uint32_t)d.act2};
-            gc_u32x4 hi = {(uint32_t)(d.act2 >> 32), (uint32_t)d.step, (uint32_t)(d.step >> 32), 0u};
+            gc_u32x4 lo = {d.kind | ((uint32_t)n << 8), (uint32_t)d.step, (uint32_t)(d.step >> 32), (uint32_t)d.act1};
             ((lds4)(hc.sx + kSplitDesc))[0] = lo;
-            ((lds4)(hc.sx + kSplitDesc))[1] = hi;
+            if (d.kind != 3u) {
+                gc_u32x4 hi = {(uint32_t)(d.act1 >> 32), (uint32_t)d.act2, (uint32_t)(d.act2 >> 32), 0u};
+                ((lds4)(hc.sx + kSplitDesc))[1] = hi;
+            }
         }
     }
     __device__ __forceinline__ W AND(W a, W b, uint64_t act) {
@@ -369,22 +515,38 @@ struct SplitBackend {
         c1 = bit(act1) ? (result(0) ^ result(1)) : 0u;
         c2 = bit(act2) ? (result(2) ^ result(3)) : 0u;
     }
-    // x + y + carry-in over lanes [0, n) as one posted job (Circ::add picks this up): same gate steps as Circ::add_generic,
-    // two barriers around the whole addition plus one per level instead of two per level
+    // x + y + carry-in over lanes [0, n) as one posted job (Circ::add picks this up): same gate steps as Circ::add_generic.
+    // One hand-over barrier, then one barrier per level; after the last one the results of the last level are visible to
+    // every wave, and the glue waves form the sum and the carry-out themselves, in their own layout (wave = column, lane = gate):
+    //   G_fin(t) = state after the last level = G_pub(L-2)[t] ^ (bit L-1 of t ? X0 ^ X1 of level L-1 at t : 0)
+    //   sum = x ^ y ^ cin ^ shl(G_fin, 1) on the active lanes;  carry out = G_fin(n - 1)
     __device__ __forceinline__ W add_native(W x, W y, int n, W cinw, W *cout) {
-        const uint64_t act = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-        SplitDesc d = {3u, act, 0ull, step};
-        step += 1;
-        for (int h = 1; h < n; h <<= 1) step += 1;
+        const int L = sk_levels(n);
+        SplitDesc d = {3u, 0ull, 0ull, step};
+        const uint64_t st0 = step;
+        step += 1 + (uint64_t)L;
         publish(0, x);
         publish(1, y);
         publish(2, cinw);
-        post(d);
+        post(d, n);
         lds_barrier();
-        split_sk_add<GARBLER>(hc, d);
-        lds_barrier();
-        if (cout) *cout = bcast(result(1), n - 1);
-        return result(0);
+        split_sk_hash<GARBLER, 0>(hc, n, st0, (const SkVals *)0);
+        const lds_u32 *sx = hc.sxl;
+        const int pl = wave * kSplitPlane;
+        const lds_u32 *X0 = sx + kSplitKs + ((L & 1) * 4) * kSplitWord + pl, *X1 = X0 + kSplitWord;
+        const lds_u32 *Gp = (L == 0) ? (sx + kSplitOp + 2 * kSplitWord + pl) : (sx + kSplitGs + (((L - 1) & 1) * 2) * kSplitWord + pl);
+        // L = 0: G = X0 ^ X1 ^ cin (the first AND alone); else the published state, and the last level's gates where bit L - 1 is set
+        const int tm = (lane - 1) & 63;
+        const bool xm = (L == 0) || ((tm >> (L - 1)) & 1);
+        const uint32_t gm = Gp[tm], x0m = X0[tm], x1m = X1[tm];
+        uint32_t co = 0u;
+        if (cout) {
+            const bool xc = (L == 0) || (((n - 1) >> (L - 1)) & 1);
+            co = Gp[n - 1] ^ (xc ? (X0[n - 1] ^ X1[n - 1]) : 0u);
+        }
+        const uint32_t Gsh = (lane > 0 && lane < n) ? (gm ^ (xm ? (x0m ^ x1m) : 0u)) : 0u;
+        if (cout) *cout = co;
+        return x ^ y ^ cinw ^ Gsh;
     }
     // the record is complete: release the hash waves
     __device__ __forceinline__ void finish() {
@@ -412,23 +574,40 @@ gc_split_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *
     for (int k = 0; k < 11; k++) hc.rkl[k] = c_aes.rk[4 * k + c];
     hc.Rq = GARBLER ? (c == 0 ? R.x : c == 1 ? R.y : c == 2 ? R.z : R.w) : 0u;
     hc.sx = lds_sx;
+    hc.sxl = (__attribute__((address_space(3))) uint32_t *)lds_sx;
+    if (threadIdx.x == 0) lds_sx[kSplitZero] = 0u;          // (visible to every wave after the first hand-over barrier)
     hc.tabw = reinterpret_cast<uint32_t *>(tab);
     hc.launch_step0 = launch_step0;
     if (hc.wave >= 4) {
         // hash waves: serve the levels the glue waves post
+        const int q = hc.wave >> 2;
+        // the operand words of an addition's first AND lie at fixed places: wave q = 1 reads them together with the descriptor
+        const int g_ = 16 * (hc.wave & 3) + (hc.lane >> 2), pl_ = c * kSplitPlane;
+        SkPtrs first1;
+        sk_ptrs_own<1>(first1, hc.sxl, -1, g_, pl_);
+        sk_ptrs_oth<1>(first1, hc.sxl, -1, g_, GARBLER ? 0 : pl_);
         for (;;) {
             lds_barrier();
             typedef const __attribute__((address_space(3))) gc_u32x4 *lds4;
             const gc_u32x4 lo = ((lds4)(lds_sx + kSplitDesc))[0];
+            SkVals pre;
+            if (q == 1) pre = sk_load<GARBLER, 1>(first1);
             SplitDesc d;
-            d.kind = rfl(lo.x);
+            const uint32_t kn = rfl(lo.x);
+            d.kind = kn & 0xffu;
             if (d.kind == 0u) return;
+            d.step = ((uint64_t)rfl(lo.z) << 32) | rfl(lo.y);
+            if (d.kind == 3u) {
+                // a whole addition: its last level's barrier ends the job (the glue waves pick the results up themselves)
+                const int n = (int)(kn >> 8);
+                if (q == 1) split_sk_hash<GARBLER, 1>(hc, n, d.step, &pre);
+                else split_sk_side(hc, n);
+                continue;
+            }
             const gc_u32x4 hi = ((lds4)(lds_sx + kSplitDesc))[1];
-            d.act1 = ((uint64_t)rfl(lo.z) << 32) | rfl(lo.y);
-            d.act2 = ((uint64_t)rfl(hi.x) << 32) | rfl(lo.w);
-            d.step = ((uint64_t)rfl(hi.z) << 32) | rfl(hi.y);
-            if (d.kind == 3u) split_sk_add<GARBLER>(hc, d);
-            else split_hash_phase<GARBLER>(hc, d);
+            d.act1 = ((uint64_t)rfl(hi.x) << 32) | rfl(lo.w);
+            d.act2 = ((uint64_t)rfl(hi.z) << 32) | rfl(hi.y);
+            split_hash_phase<GARBLER>(hc, d);
             lds_barrier();
         }
     }
