@@ -237,15 +237,19 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4], con
     }
 }
 
-// ---- gate-hash option 1: the permutation of Chaskey-12 in the place of the fixed-key AES.
+// ---- gate-hash option 1: the permutation of Chaskey-12 in the place of the fixed-key AES.  An EXPERIMENT of round 3, frozen
+// since round 4 (include/linreg_gc.h, lgc_set_gate_hash): off by default, no new kernels, no bench leg.
 // CDNA4 has no AES instruction, so the fixed-key AES above is 160 LDS lookups per block and the LDS sets the pace of
-// every kernel of this engine.  The half-gates hash only needs a fixed PUBLIC permutation pi that is modelled as random
-// (ZRE15; Guo-Katz-Wang-Yu 2020 for H(x, t) = pi(sigma(x) ^ t) ^ sigma(x) ^ t) -- which is also exactly what the security
-// proof of the Chaskey MAC asks of its 128-bit ARX permutation (Mouha, Mennink, Van Herrewege, Watanabe, Preneel,
-// Verbauwhede, SAC 2014; Chaskey-12 = ISO/IEC 29192-6).  Twelve rounds of four additions, four XORs and six rotations
-// on 4 x 32-bit words: 168 integer instructions per block, no table, no LDS.  It is an OPTION (lgc_set_gate_hash(1), both
-// roles of a solve; default 0 = the reference's fixed-key AES): same circuits, same integers, a different instantiation
-// of the random permutation.  State word i = block word i (little-endian, as in the Chaskey reference code).
+// every kernel of this engine; twelve rounds of four additions, four XORs and six rotations on 4 x 32-bit words are 168
+// integer instructions per block, no table, no LDS (Mouha, Mennink, Van Herrewege, Watanabe, Preneel, Verbauwhede, SAC 2014;
+// Chaskey-12 = ISO/IEC 29192-6).  What it is NOT: the half-gates hash models pi as a fixed PUBLIC random permutation (ZRE15;
+// Guo-Katz-Wang-Yu 2020 for H(x, t) = pi(sigma(x) ^ t) ^ sigma(x) ^ t), whereas the Chaskey MAC's proof is Even-Mansour -- pi
+// sits between two XORs of a SECRET key and is never evaluated at inputs the adversary knows.  Used bare, this pi has
+// properties an ideal permutation lacks: no round constants, so pi(0) = 0 (chaskey12_permute_n maps the zero state to
+// itself) and rotational relations survive all twelve rounds; its designers do not claim otherwise.  No attack on garbling
+// is known from that, but "model pi as random" is here a heuristic of its own -- weaker than the reference's assumption
+// about fixed-key AES, and not the assumption of Chaskey's proof.  Same circuits, same integers; both roles of a solve
+// must ask for it.  State word i = block word i (little-endian, as in the Chaskey reference code).
 GC_HD void chaskey_round(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3) {
     v0 += v1; v1 = rotl32(v1, 5); v1 ^= v0; v0 = rotl32(v0, 16);
     v2 += v3; v3 = rotl32(v3, 8); v3 ^= v2;

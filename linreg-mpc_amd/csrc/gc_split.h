@@ -339,6 +339,7 @@ template <bool GARBLER, int Q>
 __device__ __forceinline__ void split_sk_hash(const SplitHashCtx &hc, int n, uint64_t st, const SkVals *pre) {
     const int r = hc.wave & 3, c = hc.lane & 3, g = 16 * r + (hc.lane >> 2);
     SkTrace tr;
+    (void)tr;
 #if GC_SPLIT_TRACE
     tr.on = blockIdx.x == 0 && (hc.wave == 0 || hc.wave == 4);
     tr.w = hc.wave == 4 ? 1 : 0;

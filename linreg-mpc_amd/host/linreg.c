@@ -98,21 +98,32 @@ static int create_rings(create_job *j) {                            /* the garbl
 /* The CSP and the Evaluator live until the end of the protocol.  When one of them is gone -- its connection hung up -- the
  * other normally notices in its next recv() and leaves through check(); but it may sit in a call that never returns once the
  * peer is dead (seen: hipIpcOpenMemHandle on the ring of a CSP killed a moment earlier; a test of tests/test_host.py hit that
- * window once in six runs).  A watchdog thread polls the connection and, five seconds after a hang-up that the main thread has
- * not dealt with, ends the process with the reference's exit code for every failure (src/cmd/linreg.c:206-211). */
+ * window once in six runs).  A watchdog thread polls the connection and ends the process with the reference's exit code for
+ * every failure (src/cmd/linreg.c:206-211) -- but only for a hang-up that is a FAILURE: the peer left before this party had
+ * everything it needs from it (g_peer_finished: set when the decode bits are in / out and the ring has been released), and
+ * the main thread has not moved for five seconds since (host_progress: every launch and every trace mark ticks).  A healthy
+ * CSP leaves before the Evaluator has printed its results, and POLLRDHUP fires on its FIN: a watchdog that only counted five
+ * seconds from the hang-up would kill a slow but healthy Evaluator (a shared GPU, a profiler, a blocked stdout). */
 static volatile int g_protocol_over;      /* 1: results are out, cleaning up; 2: main is about to return */
+static volatile int g_peer_finished;      /* nothing more is needed from the watched peer: its hang-up is not an event */
 typedef struct { int fd, party, peer; } watchdog_arg;
 static void *peer_watchdog(void *arg) {
     watchdog_arg *w = arg;
     struct pollfd pf = {w->fd, POLLRDHUP, 0};
     for (;;) {
-        if (g_protocol_over >= 2) return NULL;
+        if (g_protocol_over >= 2 || g_peer_finished) return NULL;
         pf.revents = 0;
         int r = poll(&pf, 1, 250);
         if (r > 0 && (pf.revents & (POLLRDHUP | POLLHUP | POLLERR | POLLNVAL))) break;
     }
-    for (int i = 0; i < 20 && g_protocol_over < 2; i++) usleep(250000);
-    if (g_protocol_over >= 2) return NULL;
+    unsigned long seen = host_progress();
+    for (int quiet = 0; quiet < 20;) {                               /* 20 x 250 ms without a sign of life */
+        if (g_protocol_over >= 2 || g_peer_finished) return NULL;
+        usleep(250000);
+        unsigned long now = host_progress();
+        if (now != seen) { seen = now; quiet = 0; } else quiet++;
+    }
+    if (g_protocol_over >= 2 || g_peer_finished) return NULL;
     if (g_protocol_over == 1) { fflush(stdout); _exit(0); }          /* the protocol was through: only the clean-up is stuck */
     fprintf(stderr, "party %d: party %d is gone and this party is stuck in a call that does not return; giving up\n", w->party, w->peer);
     _exit(1);
@@ -435,6 +446,9 @@ int main(int argc, char **argv) {
                 check(!send_blob(self, 2, dec, nr * 8), "could not send decode bits");
                 free(dec);
             }
+            /* the rings stay until the Evaluator has evaluated every launch of every block (table_link_finish) */
+            for (int k = 0; k < n_devices; k++) check(!table_link_finish(&jb[k].link, 1), "the Evaluator did not release table ring %d", k);
+            g_peer_finished = 1;
             for (int k = 0; k < n_devices; k++) close(fds[k]);
             goto done;
         }
@@ -446,6 +460,7 @@ int main(int argc, char **argv) {
         LGC(lgc_party_decode_bits(party_obj, dec));
         check(!send_blob(self, 2, dec, nr * 8), "could not send decode bits");
         free(dec);
+        g_peer_finished = 1;                                     /* (ring mode: tables_send returned with the ring released) */
     } else if (party == 2) {                                         /* Evaluator */
         double time_start = wall_clock();
         printf("\nAlgorithm: %s\n", algorithm);
@@ -503,6 +518,7 @@ int main(int argc, char **argv) {
             for (int k = 0; k < n_devices; k++) { pthread_join(jb[k].th, NULL); bad |= jb[k].rc; }
             check(!bad, "could not receive garbled tables");
             TRACE("tables evaluated");
+            for (int k = 0; k < n_devices; k++) check(!table_link_finish(&jb[k].link, 0), "could not release table ring %d", k);
             for (int k = 0; k < n_devices; k++) {
                 size_t lo, hi, nr = lgc_party_num_reveal(blocks[k]);
                 block_range(n_lambdas, (size_t)n_devices, (size_t)k, &lo, &hi);
@@ -514,6 +530,7 @@ int main(int argc, char **argv) {
                 total_gates += lgc_party_and_gates(blocks[k]) - (k ? lgc_party_prefix_and_gates(blocks[k]) : 0);
                 close(fds[k]);
             }
+            g_peer_finished = 1;                                  /* every block's decode bits are in: the CSP may go */
         } else {
             check(!programs_agree(self, 1, party_obj, 0), "program check failed");
             check(!tables_recv(self, 1, party_obj, ring_slots, kTableChunk, note_launch, &marks), "could not receive garbled tables");
@@ -521,6 +538,7 @@ int main(int argc, char **argv) {
             size_t nr = lgc_party_num_reveal(party_obj);
             uint64_t *dec = malloc((nr + 1) * 8);
             check(!recv_blob(self, 1, dec, nr * 8), "could not receive decode bits");
+            g_peer_finished = 1;                                  /* the CSP may go: nothing more comes from it */
             LGC(lgc_party_finish(party_obj, dec, beta, n_lambdas ? NULL : trace, n_lambdas ? NULL : ab));
             free(dec);
             total_gates = lgc_party_and_gates(party_obj);

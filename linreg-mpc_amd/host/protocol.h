@@ -50,6 +50,9 @@ int tables_ring_prepare(lgc_party *po, int ring_slots);   /* garbler, optional: 
 int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, int sending, int ring_slots, size_t start);
 int table_link_send_range(table_link *l, size_t lo, size_t hi);
 int table_link_recv_range(table_link *l, size_t lo, size_t hi, void (*after_launch)(size_t launch, void *ctx), void *ctx);
+int table_link_finish(table_link *l, int sending);      /* after the last range: the evaluator releases the ring with one byte, the garbler waits for it */
+void host_progress_tick(void);                          /* the main protocol moved (every launch, every trace mark) ... */
+unsigned long host_progress(void);                      /* ... read by the peer watchdog of bin/linreg */
 int run_trusted_initializer(node *self, config *c, int w1, int device);
 int run_party(node *self, config *c, int precision, int precision_p2, int w1, int w2, int use_ot, int device,
               uint64_t **res_A, uint64_t **res_b);

@@ -26,7 +26,12 @@
 #define TCHK(x) do { if ((x) != 0) { fprintf(stderr, "%s: %s\n", #x, lgc_last_error()); return 1; } } while (0)
 /* a trace mark of the host (LINREG_TRACE); in bin/linreg_testhooks also the place where LINREG_DIE_AT=<mark> makes this
  * party kill itself (tests/test_host.py: a party lost at a known point of the protocol) */
+/* something the main protocol did a moment ago: the peer watchdog of bin/linreg leaves a party alone while this moves */
+static volatile unsigned long g_host_progress;
+void host_progress_tick(void) { __atomic_add_fetch(&g_host_progress, 1, __ATOMIC_RELAXED); }
+unsigned long host_progress(void) { return __atomic_load_n(&g_host_progress, __ATOMIC_RELAXED); }
 void host_trace_mark(const char *what) {
+    host_progress_tick();
     lgc_trace_mark(what);
 #ifdef LINREG_TEST_HOOKS
     const char *die = getenv("LINREG_DIE_AT");
@@ -266,8 +271,8 @@ int table_link_send_range(table_link *l, size_t lo, size_t hi) {
     if (l->nslots == 0) {
         /* byte ring: launch i may overwrite its range once the launch lgc_party_ring_wait_for names has been evaluated
          * (launches before l->start never pass through this link).  The evaluator acknowledges the launches somebody will
-         * wait for -- those up to link_last_ack -- and no others: the garbler is through when its last launch is garbled,
-         * not when the evaluator is (its exit handlers then run beside the evaluator's tail instead of beside its exit) */
+         * wait for -- those up to link_last_ack -- and no others; that the evaluator is through with the ring altogether is
+         * ONE more byte at the very end (table_link_finish) */
         const int64_t last_ack = link_last_ack(l);
         for (size_t i = lo; i < hi; i++) {
             int64_t wf = lgc_party_ring_wait_for(l->po, i);
@@ -275,6 +280,7 @@ int table_link_send_range(table_link *l, size_t lo, size_t hi) {
             while (l->acked < need) { if (link_io(l, &tok, 1, 0)) return 1; l->acked++; }
             TCHK(lgc_party_garble_ring(l->po, i));
             if (i == 0) host_trace_mark("first table garbled");
+            host_progress_tick();
             tok = 1;
             if (link_io(l, &tok, 1, 1)) return 1;
         }
@@ -288,6 +294,7 @@ int table_link_send_range(table_link *l, size_t lo, size_t hi) {
         if (i - l->start >= l->nslots && link_io(l, &tok, 1, 0)) return 1;      /* slot is free again */
         TCHK(lgc_party_garble_ring(l->po, i));
         if (i == 0) host_trace_mark("first table garbled");
+        host_progress_tick();
         tok = 1;
         if (link_io(l, &tok, 1, 1)) return 1;
     }
@@ -298,9 +305,27 @@ int table_link_recv_range(table_link *l, size_t lo, size_t hi, void (*after_laun
     for (size_t i = lo; i < hi; i++) {
         if (link_io(l, &tok, 1, 0)) return 1;                                   /* launch i is in its slot */
         TCHK(lgc_party_evaluate_ring(l->po, i));
+        host_progress_tick();
         if (after_launch) after_launch(i, ctx);
         if ((l->nslots == 0 ? (int64_t)i <= link_last_ack(l) : i + l->nslots < l->end) && link_io(l, &tok, 1, 1)) return 1;
     }
+    return 0;
+}
+/* The end of a link.  The ring is the GARBLER's allocation, exported with hipIpcGetMemHandle and mapped by the evaluator:
+ * HIP leaves freeing it while the importer still has it open -- and is still reading the last launches -- undefined (it
+ * happens to work on this stack because the driver keeps the buffer alive).  So the evaluator says once, with one byte, that
+ * every launch of the link has been evaluated (lgc_party_evaluate_ring returns after the launch has run), and the garbler
+ * keeps its party object -- the ring -- until then.  Slot ring: the acknowledgements still on their way are drained first. */
+int table_link_finish(table_link *l, int sending) {
+    uint8_t tok = 0xE0;
+    if (!sending) return link_io(l, &tok, 1, 1);
+    if (l->nslots != 0) {
+        size_t n = l->end - l->start, due = n > l->nslots ? n - l->nslots : 0;      /* one ack per reused slot (table_link_send_range) */
+        (void)due;                                                                 /* (all of them were read there) */
+    }
+    if (link_io(l, &tok, 1, 0)) return 1;
+    if (tok != 0xE0) { fprintf(stderr, "table link: unexpected byte %02x where the evaluator's end-of-ring byte was due\n", tok); return 1; }
+    host_progress_tick();
     return 0;
 }
 
@@ -325,7 +350,7 @@ int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
     if (ring_slots > 0) {
         table_link l;
         if (table_link_open(&l, self, peer, -1, po, 1, ring_slots, 0)) return 1;
-        return table_link_send_range(&l, 0, nl);
+        return table_link_send_range(&l, 0, nl) || table_link_finish(&l, 1);
     }
     /* socket mode: launch i + 1 is garbled and copied out while launch i is on the wire */
     table_pipe tp;
@@ -340,6 +365,7 @@ int tables_send(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
         if (!tab) break;
         if (lgc_party_garble(po, i, tab) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); table_pipe_fail(&tp); break; }
         if (i == 0) host_trace_mark("first table garbled");
+        host_progress_tick();
         table_pipe_publish(&tp);
     }
     table_pipe_stop(&tp, th);
@@ -354,7 +380,7 @@ int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
     if (ring_slots > 0) {
         table_link l;
         if (table_link_open(&l, self, peer, -1, po, 0, ring_slots, 0)) return 1;
-        return table_link_recv_range(&l, 0, nl, after_launch, ctx);
+        return table_link_recv_range(&l, 0, nl, after_launch, ctx) || table_link_finish(&l, 0);
     }
     /* socket mode: launch i + 1 is read from the socket while launch i is copied in and evaluated */
     table_pipe tp;
@@ -368,6 +394,7 @@ int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
         if (!tab) break;
         if (lgc_party_evaluate(po, i, tab) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); table_pipe_fail(&tp); break; }
         table_pipe_release(&tp);
+        host_progress_tick();
         if (after_launch) after_launch(i, ctx);
     }
     table_pipe_stop(&tp, th);

@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -171,5 +172,5 @@ def load():
     csrc = os.path.join(ROOT, "linreg-mpc_amd", "csrc")
     src = [os.path.join(ODIR, "gc_cpu.cpp")] + [os.path.join(csrc, f) for f in ("gc_aes.h", "gc_circuits.h", "gc_exec.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
-        subprocess.check_call(["make", "-C", ODIR, "libgc_cpu.so"])
+        subprocess.check_call(["make", "-C", ODIR, "libgc_cpu.so"], stdout=sys.stderr)   # (stdout belongs to the caller: bench.py prints ONE line there)
     return GcCpu(C.CDLL(so))

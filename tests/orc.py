@@ -5,6 +5,7 @@ Test infrastructure only.  Builds the library with oracle/Makefile on demand.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -180,5 +181,5 @@ def load():
     so = os.path.join(ODIR, "liblinreg_oracle.so")
     src = [os.path.join(ODIR, f) for f in ("linreg_oracle.c", "linreg_oracle.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
-        subprocess.check_call(["make", "-C", ODIR, "liblinreg_oracle.so"])
+        subprocess.check_call(["make", "-C", ODIR, "liblinreg_oracle.so"], stdout=sys.stderr)
     return Oracle(C.CDLL(so))
