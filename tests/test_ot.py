@@ -164,3 +164,73 @@ def test_gpu_gilboa_mid_size_against_semantic_oracle(lgc, oracle, w, p):
             assert (int(ss[q]) + int(sr[q])) & mask == exp, (w, rep, q)
         assert len(set(int(v) for v in ss)) > npairs // 2     # the shares are masks, not the answers
     S.close(); R.close()
+
+
+def _openssl_aes_ctr(key, first_block, nblocks):
+    """AES-128-CTR keystream written over OpenSSL's block function: block c = AES_key(c as a little-endian 128-bit number)"""
+    import ctypes
+    import ctypes.util
+    crypto = ctypes.CDLL(ctypes.util.find_library("crypto") or "libcrypto.so.3")
+    sched = ctypes.create_string_buffer(256)                           # AES_KEY
+    assert crypto.AES_set_encrypt_key(bytes(key), 128, sched) == 0
+    out = bytearray()
+    inb, outb = ctypes.create_string_buffer(16), ctypes.create_string_buffer(16)
+    for c in range(first_block, first_block + nblocks):
+        ctypes.memmove(inb, int(c).to_bytes(16, "little"), 16)
+        crypto.AES_encrypt(inb, outb, sched)
+        out += outb.raw
+    return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+@pytest.mark.gpu
+def test_gpu_label_ot_against_openssl_and_numpy(lgc):
+    """The IKNP extension of the GPU (ot.hip) against a restatement that shares NOTHING with the product or with
+    oracle/gc_cpu.cpp (which is compiled from the product's headers): the column PRG is OpenSSL's AES-128 in counter mode
+    under each base-OT seed, the 128 x m bit-matrix transpose is numpy, the correlation-robust hash is
+    helpers.openssl_gate_hash (the gate hash from its definition over OpenSSL).  A 256-OT batch and a second, ragged one on
+    the same session (the PRG counter and the tweak counter advance): the receiver's message u, the sender's ciphertext
+    pairs e and the receiver's output labels, byte for byte.  Protocol as the reference's call sites use it
+    (src/input.c:28-44: one extended 1-of-2 OT per input bit, payloads = the two wire labels; src/phase1.c:58-65)."""
+    from helpers import openssl_gate_hash
+    rng = np.random.default_rng(77)
+    seeds0, seeds1, delta, seeds_s = _setup(rng)
+    dbits = np.unpackbits(delta, bitorder="little")
+    S = lgc.OtSender(delta.tobytes(), seeds_s); R = lgc.OtReceiver(seeds0, seeds1)
+    ctr = tw = 0
+    for m in (256, 131):
+        choice = rng.integers(0, 2, size=m, dtype=np.uint8)
+        m0 = rng.integers(0, 256, size=(m, 16), dtype=np.uint8); m1 = rng.integers(0, 256, size=(m, 16), dtype=np.uint8)
+        u = R.labels_start(choice)
+        e = S.labels(m0, m1, u)
+        out = R.labels_finish(e)
+        # ---- the restatement
+        m128 = (m + 127) // 128
+        cb = np.zeros(m128 * 16, dtype=np.uint8)
+        packed = np.packbits(choice, bitorder="little")
+        cb[:len(packed)] = packed
+        T = np.stack([_openssl_aes_ctr(seeds0[j], ctr, m128) for j in range(128)])          # receiver's columns t_j = G(k0_j)
+        G1 = np.stack([_openssl_aes_ctr(seeds1[j], ctr, m128) for j in range(128)])
+        U = T ^ G1 ^ cb[None, :]                                                            # u_j = G(k0_j) ^ G(k1_j) ^ c
+        # sender: it holds k_{delta_j}, so q_j = G(k_{delta_j}) ^ delta_j u_j  ( = t_j ^ delta_j c )
+        Gs = np.stack([_openssl_aes_ctr(seeds_s[j], ctr, m128) for j in range(128)])
+        Q = Gs ^ (U * dbits[:, None])
+        # bit-matrix transpose: row i holds bit i of every column, column j at bit j (LSB first in both directions)
+        tb = np.unpackbits(T, axis=1, bitorder="little")[:, :m]                             # (128, m)
+        qb = np.unpackbits(Q, axis=1, bitorder="little")[:, :m]
+        rows_t = np.packbits(tb.T, axis=1, bitorder="little")                               # (m, 16)
+        rows_q = np.packbits(qb.T, axis=1, bitorder="little")
+        assert np.array_equal(rows_q, rows_t ^ (delta[None, :] * choice[:, None]))          # the IKNP correlation itself
+        tweaks = np.arange(tw, tw + m, dtype=np.uint64)
+        e0 = m0 ^ openssl_gate_hash(rows_q, tweaks)
+        e1 = m1 ^ openssl_gate_hash(rows_q ^ delta[None, :], tweaks)
+        ht = openssl_gate_hash(rows_t, tweaks)
+        exp_out = np.where(choice[:, None] == 1, e1, e0) ^ ht
+        # ---- against the GPU
+        assert np.array_equal(np.asarray(u, dtype=np.uint8).reshape(-1), U.reshape(-1)), m
+        ge = np.asarray(e, dtype=np.uint8).reshape(m, 2, 16)
+        assert np.array_equal(ge[:, 0], e0) and np.array_equal(ge[:, 1], e1), m
+        assert np.array_equal(np.asarray(out, dtype=np.uint8).reshape(m, 16), exp_out), m
+        assert np.array_equal(exp_out, np.where(choice[:, None] == 1, m1, m0))              # and the chosen labels are delivered
+        ctr += m128
+        tw += m
+    S.close(); R.close()
