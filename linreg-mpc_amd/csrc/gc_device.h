@@ -87,6 +87,9 @@ __device__ __forceinline__ LdsTab2 lds_tab2_make(const uint32_t *lds) {
 // 32 lanes on 32 banks, so 32 replicas per entry are already conflict-free (lanes l and l + 32 share
 // a replica but never a cycle).  Row x (256 B) of the first half holds Te0[x] x 32 | Te1[x] x 32,
 // of the second half Te2[x] x 32 | Te3[x] x 32.  No rotates in the rounds.
+#ifndef GC_ADDR_BITOP3
+#define GC_ADDR_BITOP3 0
+#endif
 struct LdsTab4 {
     static const bool kTwoTables = false;
     static const bool kFourTables = true;
@@ -96,6 +99,11 @@ struct LdsTab4 {
     __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const { return lkt(0, word, k); }
     __device__ __forceinline__ uint32_t lk2(uint32_t word, int k) const { return lkt(2, word, k); }
     __device__ __forceinline__ uint32_t lkt(int t, uint32_t word, int k) const {
+#if GC_ADDR_BITOP3
+        // byte 1 of the state word already sits where the address wants it: (word & 0xff00) | c[t] is one v_bitop3_b32, a
+        // full-rate instruction, where v_perm_b32 issues at half rate (profiles/r4_valu_issue.txt): 40 of a block's 160 addresses
+        if (k == 1) return *reinterpret_cast<const uint32_t *>(base + __builtin_amdgcn_bitop3_b32(word, 0xff00u, c[t], 0xEA));
+#endif
         uint32_t off = __builtin_amdgcn_perm(word, c[t], (t >= 2 ? 0x0c020400u : 0x0c0c0400u) + ((uint32_t)k << 8));
         return *reinterpret_cast<const uint32_t *>(base + off);
     }

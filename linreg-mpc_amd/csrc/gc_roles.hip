@@ -476,6 +476,7 @@ static size_t default_ring_bytes(const Program &P) {
     size_t slack = largest / 2;
     if (slack < ((size_t)64 << 20)) slack = (size_t)64 << 20;
     if (slack > ((size_t)4 << 30)) slack = (size_t)4 << 30;
+    if (const char *e = getenv("LGC_PARTY_RING_SLACK_MB")) if (atol(e) > 0) slack = (size_t)atol(e) << 20;   // experiments (scripts/exp/two_proc_shape_ab.sh)
     return largest + slack + 4096;
 }
 extern "C" int lgc_party_ring_create_bytes(lgc_party *p, size_t ring_bytes, uint8_t handle_out[64], size_t *ring_bytes_out) {

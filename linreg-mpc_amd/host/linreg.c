@@ -359,9 +359,13 @@ int main(int argc, char **argv) {
     sys.num_iterations = num_iterations; sys.lambda = lambda; sys.nshares = (size_t)P;
     sys.normalize = 1; sys.reveal_inputs = 1; sys.trace = 1;
     if (n_lambdas) { sys.reveal_inputs = 0; sys.trace = 0; }       /* merged program of n_lambdas circuits: results only */
-    /* table bytes per launch: socket mode moves them through host buffers; ring mode keeps them
-     * in HBM (CSP and Evaluator on one node), so launches can be as large as the fused solver's */
-    const size_t kTableChunk = ring_slots > 0 ? (size_t)16 << 30 : (size_t)64 << 20;
+    /* table bytes per launch: socket mode moves them through host buffers; ring mode keeps them in HBM (CSP and Evaluator on
+     * one node), so launches are as large as the fused solver's: 2^25 gate steps = 64 GiB, i.e. a whole d = 500 matrix-vector
+     * product is ONE launch.  Rounds 2-4 cut at 16 GiB: the product then went out as seven launches of 4.4 rounds of the
+     * chip each, the garbler's launch k + 1 waited for the evaluation of launch k (4 GiB of run-ahead room), and the
+     * two-process solve ran 7-9 % behind the co-located one -- profiles/r5_timeline_d500_two_process.txt, and
+     * scripts/exp/two_proc_shape_ab.sh: 1.94 s at 16 GiB, 1.87 s at 32 GiB, 1.82 s at 64 GiB (co-located: 1.81 s) */
+    const size_t kTableChunk = ring_slots > 0 ? (size_t)64 << 30 : (size_t)64 << 20;
     cj.sys = sys; cj.device = device; cj.n_devices = n_devices; cj.devices = devices; cj.ring_slots = ring_slots;
     cj.table_chunk = kTableChunk; cj.n_lambdas = n_lambdas; cj.lambdas = lambdas; cj.blocks = blocks;
     cj.role = party == 1 ? LGC_ROLE_GARBLER : LGC_ROLE_EVALUATOR;

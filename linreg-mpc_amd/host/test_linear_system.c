@@ -8,6 +8,7 @@
  * --table_ring[=slots] (both parties on one node: garbled tables stay in HBM, shared by hipIpc). */
 #define _GNU_SOURCE
 #include <errno.h>
+#include <openssl/crypto.h>
 #include <openssl/rand.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,11 +37,13 @@ int main(int argc, char **argv) {
     int party = !strcmp(argv[2], "1") ? 1 : (!strcmp(argv[2], "2") ? 2 : 0);
     check(party > 0, "Party must be either 1 or 2.");
     int w = 64, ring_slots = 0;
+    long chunk_mb = 0;                       /* --table_chunk_mb=N: the largest launch's tables, in MiB (0: the default below) */
     const char *host = "localhost";
     for (int i = 7; i < argc; i++) {
         if (sscanf(argv[i], "--width=%i", &w) == 1) continue;
         if (!strcmp(argv[i], "--table_ring")) { ring_slots = TABLE_RING_BYTES; continue; }
         if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) continue;
+        if (sscanf(argv[i], "--table_chunk_mb=%ld", &chunk_mb) == 1 && chunk_mb > 0) continue;
         { int lanes = 0; if (sscanf(argv[i], "--table_lanes=%i", &lanes) == 1) { protocol_set_table_lanes(lanes); continue; } }
         if (!strncmp(argv[i], "--gate_hash=", 12)) {       /* aes128 (default, the reference's) | chaskey12; the same on both parties */
             int kind = -1;
@@ -161,7 +164,7 @@ int main(int argc, char **argv) {
     sys.d = d; sys.width = w; sys.precision = precision;
     sys.algorithm = !strcmp(algorithm, "cholesky") ? LGC_ALG_CHOLESKY : (!strcmp(algorithm, "ldlt") ? LGC_ALG_LDLT : LGC_ALG_CGD);
     sys.num_iterations = num_iterations; sys.nshares = 2; sys.normalize = 0; sys.trace = 1;
-    const size_t chunk = ring_slots > 0 ? (size_t)16 << 30 : (size_t)64 << 20;
+    const size_t chunk = chunk_mb > 0 ? (size_t)chunk_mb << 20 : ring_slots > 0 ? (size_t)64 << 30 : (size_t)64 << 20;   /* (host/linreg.c: kTableChunk) */
     if (party == 1) {
         uint8_t seed[16];
         check(RAND_bytes(seed, sizeof seed) == 1, "RAND_bytes failed");
@@ -175,10 +178,15 @@ int main(int argc, char **argv) {
         check(!recv_blob(self, 2, u, lgc_ot_u_bytes(bits)), "OT: could not receive u");
         LGC(lgc_ot_labels_send(S, m0, m1, bits, u, e));
         check(!send_blob(self, 2, e, bits * 32), "OT: could not send");
-        lgc_ot_sender_destroy(S);
-        free(lab); free(m0); free(m1); free(u); free(e);
+        host_trace_mark("input OT done");
         check(!programs_agree(self, 2, po, 1), "program check failed");
         check(!tables_send(self, 2, po, ring_slots, chunk), "could not stream the garbled tables");
+        /* the OT session (device and page-locked buffers) and the label pairs go AFTER the tables: released before them, as in
+         * rounds 1-4, their clean-up -- hundreds of MB at d = 500 -- ran on the Evaluator's iteration clock (cgd.oc:190-194)
+         * while the Evaluator waited for the first table */
+        lgc_ot_sender_destroy(S);
+        OPENSSL_cleanse(m0, bits * 16); OPENSSL_cleanse(m1, bits * 16);     /* both labels of every input bit: their XOR is R */
+        free(lab); free(m0); free(m1); free(u); free(e);
         size_t nr = lgc_party_num_reveal(po);
         uint64_t *dec = malloc((nr + 1) * 8);
         LGC(lgc_party_decode_bits(po, dec));

@@ -1,18 +1,31 @@
 """timeline of a kernel trace (rocprofv3 --kernel-trace --output-format csv): who runs beside the MAC launches.
-   python scripts/dbg/timeline.py <dir with *_kernel_trace.csv> [rows]"""
+   python scripts/dbg/timeline.py <dir with *_kernel_trace.csv> [<dir of a second process> ...] [rows]
+Several directories = several PROCESSES traced in one run (CSP and Evaluator of a two-process solve, scripts/exp/two_proc_trace.sh):
+their events are merged on the GPU's clock, the queue column then reads <process>.<queue>."""
 import csv, glob, os, sys
-d = sys.argv[1]
-rows_wanted = int(sys.argv[2]) if len(sys.argv) > 2 else 160
-f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[-1]
+dirs = [a for a in sys.argv[1:] if os.path.isdir(a)]
+rest = [a for a in sys.argv[1:] if not os.path.isdir(a)]
+rows_wanted = int(rest[0]) if rest else 160
 ev = []
-for r in csv.DictReader(open(f)):
-    n = r["Kernel_Name"]
-    short = n.split("(")[0].replace("void gc::", "").replace("gc::", "")
-    ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short, r.get("Queue_Id", "?")))
+files = []
+for pi, d in enumerate(dirs):
+    f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[-1]
+    files.append(f)
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        short = n.split("(")[0].replace("void gc::", "").replace("gc::", "")
+        q = r.get("Queue_Id", "?")
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short, q if len(dirs) == 1 else "%d.%s" % (pi + 1, q)))
 ev.sort()
-# last solve: events after the last gc_input_kernel
-starts = [i for i, e in enumerate(ev) if e[2].startswith("gc_input_kernel")]
-ev = ev[starts[-1]:]
+f = " + ".join(files)
+if len(dirs) == 1:
+    # last solve: events after the last gc_input_kernel
+    starts = [i for i, e in enumerate(ev) if e[2].startswith("gc_input_kernel")]
+    ev = ev[starts[-1]:]
+else:
+    # two processes: from the first MAC kernel's neighbourhood on (start-up kernels of both processes lie far apart)
+    firstm = [i for i, e in enumerate(ev) if "gc_mack_kernel" in e[2] or "gc_mac_kernel" in e[2]]
+    ev = ev[max(0, (firstm[0] if firstm else 0) - 40):]
 t0 = ev[0][0]
 def is_mack(e): return "gc_mack_kernel" in e[2]
 def role(e): return "G" if ("<true" in e[2] or "tabfill" in e[2]) else "E"
@@ -40,6 +53,6 @@ for r in ("G", "E"):
     beside = sum(overl(e, m) for e in mine for m in other)
     span_idle = 0
     print("small kernels of %s: %d, %.2f ms of durations, %.2f ms of them beside a MAC kernel of the other role" % (r, len(mine), dur / 1e6, beside / 1e6))
-print("%10s %10s %3s %s" % ("start_ms", "dur_ms", "q", "kernel"))
+print("%10s %10s %5s %s" % ("start_ms", "dur_ms", "q", "kernel"))
 for e in ev[:rows_wanted]:
-    print("%10.3f %10.3f %3s %s %s" % ((e[0] - t0) / 1e6, (e[1] - e[0]) / 1e6, e[3], role(e), e[2][:60]))
+    print("%10.3f %10.3f %5s %s %s" % ((e[0] - t0) / 1e6, (e[1] - e[0]) / 1e6, e[3], role(e), e[2][:60]))

@@ -3,7 +3,7 @@
 # needs a library built from the tree with scripts/exp/prio_streams.patch applied (git apply; LGC_PRIO is not in the product)
 # matrix-vector products, shorten the d = 500 solve?  (The small launches of one chain run beside the other chain's MAC kernel.)
 run() {
-  python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --no-e2e --no-sweep 2>/dev/null | python -c "import sys,json; o=json.load(open("bench_detail.json")); print('bench', o['value'], o['ms_per_step'], o['exact_vs_oracle'])"
+  python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --no-e2e --no-sweep >/dev/null 2>&1; python -c "import sys,json; o=json.load(open('bench_detail.json')); print('bench', o['value'], o['ms_per_step'], o['exact_vs_oracle'])"
 }
 for rep in 1 2; do
   unset LGC_PRIO LGC_RING_SLACK_MB

@@ -3,5 +3,5 @@ for v in "$@"; do
   if [ "$v" = "A" ]; then unset LGC_LIB; else export LGC_LIB=$PWD/scripts/exp/libs/lib_$v.so; fi
   echo "== variant $v"
   python scripts/gpu_launch_profile.py 500 cgd 2 2>&1 | grep -E "^d=|DIV|MAX"
-  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic --no-e2e --no-sweep 2>/dev/null | python -c "import sys,json; o=json.load(open("bench_detail.json")); print('bench', o['value'], o['ms_per_step'])"
+  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic --no-e2e --no-sweep >/dev/null 2>&1; python -c "import sys,json; o=json.load(open('bench_detail.json')); print('bench', o['value'], o['ms_per_step'])"
 done

@@ -58,6 +58,9 @@ if "trace" in args:
 if "trace500" in args:  # timeline of the two chains around the MAC launches (scripts/dbg/timeline.py reads the kernel trace)
     run(500, "cgd", 3)
     run(500, "cgd", 3)
+if "trace100" in args:
+    run(100, "cgd", 15)
+    run(100, "cgd", 15)
 if "w32big" in args:
     run(500, "cgd", 20, w=32, p=30)
     run(500, "cgd", 20, w=32, p=30)
