@@ -284,6 +284,16 @@ int lgc_party_ring_open_bytes(lgc_party *p, const uint8_t handle[64], size_t rin
 int64_t lgc_party_ring_wait_for(const lgc_party *p, size_t launch);
 int lgc_party_garble_ring(lgc_party *p, size_t launch);
 int lgc_party_evaluate_ring(lgc_party *p, size_t launch);
+/* lgc_party_garble_ring in two halves (round 5), for a garbler process that does not stop after every launch -- where the
+ * reference's Yao runtime keeps garbling while the bytes of earlier gates are still on their way (osend under
+ * execYaoProtocol, src/cmd/linreg.c:177): _begin(k) enqueues launch k behind launch k - 1 and returns at once (the table pass
+ * of a critical-path launch runs on a stream of its own, beside the next launches' record kernels; the zero-label stash
+ * alternates between two private buffers); _wait(k) returns once the tables of launch k are complete in the ring, i.e. when
+ * the evaluator may be told.  The ring discipline is the caller's as before (lgc_party_ring_wait_for(k) acknowledged before
+ * _begin(k)); launches are waited for in order, at most 63 of them begun and not yet waited for; _wait may be called from a
+ * second thread while the first goes on enqueueing (host/tables.c does).  What the ring ever holds is unchanged. */
+int lgc_party_garble_ring_begin(lgc_party *p, size_t launch);
+int lgc_party_garble_ring_wait(lgc_party *p, size_t launch);
 /* evaluator: the labels a data provider forwarded (dcsSendIntArray -> orecv, input.c:46, 84-92) */
 int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint8_t *labels);
 /* The same two hand-overs with the labels left in HBM (bin/linreg --input_ring: all parties on one node).  The garbler exports a

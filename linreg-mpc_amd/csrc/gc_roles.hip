@@ -29,6 +29,7 @@ using namespace gc;
         if (e_ != hipSuccess) return lgc_fail(LGC_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+enum { kPartyEvents = 64 };
 struct lgc_party {
     lgc_system sys;
     Program P;
@@ -52,6 +53,16 @@ struct lgc_party {
     std::vector<size_t> ring_off;
     std::vector<int64_t> ring_wait;
     size_t tab_bytes;      // size of the private buffer `tab`
+    // asynchronous garbling into the ring (lgc_party_garble_ring_begin / _wait): record kernels on the null stream, the table
+    // passes of critical-path launches on a stream of their own, two stashes in turn, one completion event per launch
+    hipStream_t s_pass;
+    hipEvent_t ev_rec[kPartyEvents], ev_done[kPartyEvents];
+    bool async_ready;
+    Lbl *stash2;
+    size_t stash2_bytes;
+    uint64_t n_crit;       // critical-path launches begun so far (stash = n_crit & 1)
+    int64_t stash_user[2]; // the launch whose table pass read stash k last (-1: none)
+    int64_t begun_hi;      // highest launch begun asynchronously (-1: none)
 };
 
 // (m0, m1) = (zero label, zero label ^ R) per input bit of one share: yaoKeyNewPair (input.c:94-101)
@@ -80,8 +91,27 @@ __global__ void gc_import_labels_kernel(Lbl *words, uint32_t base, uint32_t n, i
 extern "C" void lgc_party_destroy(lgc_party *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    if (p->role == LGC_ROLE_GARBLER) {
+        // the word file holds every wire's zero-label and the stashes the (a0, b0) of critical-path launches: any two of
+        // them with their counterparts give R.  Cleared before the memory goes back to the driver (which hands it to the
+        // next allocation of ANY process on this GPU as it is); R and the seed likewise on the host.
+        if (p->words) (void)hipMemset(p->words, 0, (size_t)p->P.n_words * 64 * sizeof(Lbl));
+        if (p->tab && p->tab_bytes) (void)hipMemset(p->tab, 0, p->tab_bytes);
+        if (p->stash2 && p->stash2_bytes) (void)hipMemset(p->stash2, 0, p->stash2_bytes);
+        (void)hipDeviceSynchronize();
+        volatile uint32_t *w = reinterpret_cast<volatile uint32_t *>(&p->R);
+        for (int i = 0; i < 4; i++) w[i] = 0;
+        w = reinterpret_cast<volatile uint32_t *>(&p->seed);
+        for (int i = 0; i < 4; i++) w[i] = 0;
+    }
+    if (p->async_ready) {
+        for (int i = 0; i < kPartyEvents; i++) { (void)hipEventDestroy(p->ev_rec[i]); (void)hipEventDestroy(p->ev_done[i]); }
+        (void)hipStreamDestroy(p->s_pass);
+    }
     if (p->words) (void)hipFree(p->words);
     if (p->tab) (void)hipFree(p->tab);
+    if (p->stash2) (void)hipFree(p->stash2);
     if (p->dec) (void)hipFree(p->dec);
     if (p->recs) (void)hipFree(p->recs);
     if (p->ring) { if (p->ring_imported) (void)hipIpcCloseMemHandle(p->ring); else (void)hipFree(p->ring); }
@@ -168,6 +198,8 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
     p->sys = *sys; p->device = device; p->role = role;
     p->words = 0; p->tab = 0; p->dec = 0; p->recs = 0; p->labels_ready = false;
     p->ring = 0; p->ring_slots = 0; p->ring_slot_bytes = 0; p->ring_imported = false; p->ring_bytes = 0; p->tab_bytes = 0;
+    p->s_pass = 0; p->async_ready = false; p->stash2 = 0; p->stash2_bytes = 0; p->n_crit = 0; p->stash_user[0] = p->stash_user[1] = -1;
+    p->begun_hi = -1;
     if (!max_launch_table_bytes) max_launch_table_bytes = (size_t)256 << 20;
     const uint64_t cap = max_launch_table_bytes / 2048 ? max_launch_table_bytes / 2048 : 1;
     if (lambdas) {
@@ -400,7 +432,10 @@ static hipError_t ipc_get_handle(hipIpcMemHandle_t *h, void *ptr) {
     hipError_t e = hipSuccess;
     for (int attempt = 0; attempt < 8; attempt++) {
         e = hipIpcGetMemHandle(h, ptr);
-        if (e == hipSuccess) return e;
+        if (e == hipSuccess) {
+            if (attempt) fprintf(stderr, "linreg_gc: hipIpcGetMemHandle succeeded at attempt %d (transient 'invalid argument' before)\n", attempt + 1);
+            return e;
+        }
         (void)hipGetLastError();
         struct timespec ts = {0, 2000000};
         nanosleep(&ts, 0);
@@ -409,7 +444,6 @@ static hipError_t ipc_get_handle(hipIpcMemHandle_t *h, void *ptr) {
 }
 static int ring_alloc_export(lgc_party *p, size_t bytes, uint8_t handle_out[64]) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
-    std::lock_guard<std::mutex> ipc_lock(ipc_mutex());
     RCHK(hipSetDevice(p->device));
     hipError_t e = hipMalloc(&p->ring, bytes);
     if (e != hipSuccess) return lgc_fail(LGC_ENOMEM, "hipMalloc(table ring, %zu bytes): %s", bytes, hipGetErrorString(e));
@@ -418,7 +452,11 @@ static int ring_alloc_export(lgc_party *p, size_t bytes, uint8_t handle_out[64])
     e = hipMemset(p->ring, 0, bytes);
     if (e != hipSuccess) { (void)hipFree(p->ring); p->ring = 0; return lgc_fail(LGC_EHIP, "hipMemset(table ring): %s", hipGetErrorString(e)); }
     hipIpcMemHandle_t h;
-    e = ipc_get_handle(&h, p->ring);
+    {   // (the lock covers the IPC call only: the allocation and the fill of a multi-GB ring above would serialise every
+        // other thread's IPC traffic -- the CSP's per-provider input rings -- behind them)
+        std::lock_guard<std::mutex> ipc_lock(ipc_mutex());
+        e = ipc_get_handle(&h, p->ring);
+    }
     if (e != hipSuccess) {
         (void)hipFree(p->ring); p->ring = 0;
         return lgc_fail(LGC_EHIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
@@ -518,6 +556,73 @@ extern "C" int lgc_party_garble_ring(lgc_party *p, size_t launch) {
     RCHK(hipSetDevice(p->device));
     RCHK(party_launch<true>(p, p->P.launches[launch], ring_slot(p, launch)));
     RCHK(hipDeviceSynchronize());      // kernel end = release: the tables are visible to the peer process
+    return LGC_OK;
+}
+// The same in two halves, so that a garbler process need not stop after every launch (profiles/r5_timeline_d100_two_process.txt:
+// with a device synchronisation and a token per launch the CSP's chain was its kernels PLUS their table passes PLUS ~22 us of
+// host time per launch -- 175 ms at d = 100 CGD-15 against 137 ms for the same kernels in the co-located solver, where the
+// table passes run on a third stream and nothing waits for the host):
+//   _begin(i)  enqueues launch i -- the record kernel on the null stream, behind launch i - 1; the table pass of a
+//              critical-path launch on a stream of its own, behind its record kernel -- and returns at once;
+//   _wait(i)   returns once the tables of launch i are complete in the ring (then the peer may be told).
+// The caller keeps the ring discipline (lgc_party_ring_wait_for before _begin) and waits for the launches in order; at most
+// kPartyEvents - 1 launches may be begun and not yet waited for.  The zero-label stash of critical-path launches alternates
+// between two private buffers: the record kernel of launch i + 1 runs beside the table pass of launch i.
+static int party_async_setup(lgc_party *p) {
+    if (p->async_ready) return LGC_OK;
+    RCHK(hipStreamCreateWithFlags(&p->s_pass, hipStreamNonBlocking));
+    for (int i = 0; i < kPartyEvents; i++) {
+        RCHK(hipEventCreateWithFlags(&p->ev_rec[i], hipEventDisableTiming));
+        RCHK(hipEventCreateWithFlags(&p->ev_done[i], hipEventDisableTiming));
+    }
+    const size_t sb = party_stash_bytes(p);
+    RCHK(party_need_tab(p, sb));
+    hipError_t e = hipMalloc(&p->stash2, sb);
+    if (e != hipSuccess) return lgc_fail(LGC_ENOMEM, "hipMalloc(second stash, %zu bytes): %s", sb, hipGetErrorString(e));
+    p->stash2_bytes = sb;
+    p->async_ready = true;
+    return LGC_OK;
+}
+extern "C" int lgc_party_garble_ring_begin(lgc_party *p, size_t launch) {
+    if (!p) return lgc_fail(LGC_EINVAL, "null party");
+    if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "not the garbler");
+    if (!p->ring) return lgc_fail(LGC_ESTATE, "lgc_party_ring_create has not been called");
+    if (launch >= p->P.launches.size()) return lgc_fail(LGC_EINVAL, "launch out of range");
+    RCHK(hipSetDevice(p->device));
+    int rc = party_async_setup(p);
+    if (rc) return rc;
+    const int slot = (int)(launch % kPartyEvents);
+    // the events of this slot belong to launch - kPartyEvents until that launch is through
+    if (launch >= (size_t)kPartyEvents) RCHK(hipEventSynchronize(p->ev_done[slot]));
+    const Launch &L = p->P.launches[launch];
+    Lbl *tab = ring_slot(p, launch);
+    bool crit = false;
+    const int k = (int)(p->n_crit & 1);
+    Lbl *stash = k ? p->stash2 : p->tab;
+    // (stage 0: nothing is launched, only the launch's mode is reported)
+    RCHK(gc_launch<true>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab, p->R, p->P.w, p->P.p, 0, stash, 0, &crit));
+    if (!crit) {
+        RCHK(gc_launch<true>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab, p->R, p->P.w, p->P.p, 0, (Lbl *)0, 3, (bool *)0));
+        RCHK(hipEventRecord(p->ev_done[slot], 0));
+    } else {
+        // this stash was last read by the table pass of an earlier launch: the record kernel must not overwrite it before
+        if (p->stash_user[k] >= 0) RCHK(hipStreamWaitEvent(0, p->ev_done[p->stash_user[k] % kPartyEvents], 0));
+        RCHK(gc_launch<true>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab, p->R, p->P.w, p->P.p, 0, stash, 1, (bool *)0));
+        RCHK(hipEventRecord(p->ev_rec[slot], 0));
+        RCHK(hipStreamWaitEvent(p->s_pass, p->ev_rec[slot], 0));
+        RCHK(gc_launch<true>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab, p->R, p->P.w, p->P.p, p->s_pass, stash, 2, (bool *)0));
+        RCHK(hipEventRecord(p->ev_done[slot], p->s_pass));
+        p->stash_user[k] = (int64_t)launch;
+        p->n_crit++;
+    }
+    if ((int64_t)launch > p->begun_hi) p->begun_hi = (int64_t)launch;
+    return LGC_OK;
+}
+extern "C" int lgc_party_garble_ring_wait(lgc_party *p, size_t launch) {
+    if (!p || !p->async_ready) return lgc_fail(LGC_ESTATE, "nothing was begun (lgc_party_garble_ring_begin)");
+    if ((int64_t)launch > p->begun_hi || (int64_t)launch + kPartyEvents <= p->begun_hi) return lgc_fail(LGC_EINVAL, "launch %zu is not in flight", launch);
+    // (no hipSetDevice: called from the notifier thread of the host while the main thread enqueues; events carry their device)
+    RCHK(hipEventSynchronize(p->ev_done[launch % kPartyEvents]));      // kernel end = release: the tables are visible to the peer process
     return LGC_OK;
 }
 // ---- test hooks (tests/test_gpu_roles.py): what the peer-mapped ring holds at a given moment

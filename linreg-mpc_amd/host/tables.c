@@ -265,6 +265,33 @@ static int64_t link_last_ack(table_link *l) {
     l->last_ack = m; l->last_ack_known = 1;
     return m;
 }
+/* the second thread of a garbling link (byte ring): waits for launch after launch to complete and sends its token */
+typedef struct { table_link *l; size_t lo, hi, begun; int failed; pthread_mutex_t mu; pthread_cond_t cv; } ring_notifier;
+static void ring_notifier_post(ring_notifier *n, size_t begun) {
+    pthread_mutex_lock(&n->mu); n->begun = begun; pthread_cond_broadcast(&n->cv); pthread_mutex_unlock(&n->mu);
+}
+static void ring_notifier_fail(ring_notifier *n) {
+    pthread_mutex_lock(&n->mu); n->failed = 1; pthread_cond_broadcast(&n->cv); pthread_mutex_unlock(&n->mu);
+}
+static int ring_notifier_failed(ring_notifier *n) {
+    pthread_mutex_lock(&n->mu); int f = n->failed; pthread_mutex_unlock(&n->mu); return f;
+}
+static void *ring_notify_main(void *arg) {
+    ring_notifier *n = arg;
+    for (size_t i = n->lo; i < n->hi; i++) {
+        pthread_mutex_lock(&n->mu);
+        while (n->begun <= i && !n->failed) pthread_cond_wait(&n->cv, &n->mu);
+        int stop = n->begun <= i;                                   /* failed before launch i was begun */
+        pthread_mutex_unlock(&n->mu);
+        if (stop) return NULL;
+        if (lgc_party_garble_ring_wait(n->l->po, i) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); ring_notifier_fail(n); return NULL; }
+        if (i == 0) host_trace_mark("first table garbled");
+        host_progress_tick();
+        uint8_t tok = 1;
+        if (link_io(n->l, &tok, 1, 1)) { ring_notifier_fail(n); return NULL; }
+    }
+    return NULL;
+}
 /* garbler: launches [lo, hi); launch i reuses the slot of launch i - nslots and waits for its ack */
 int table_link_send_range(table_link *l, size_t lo, size_t hi) {
     uint8_t tok = 0;
@@ -274,16 +301,56 @@ int table_link_send_range(table_link *l, size_t lo, size_t hi) {
          * wait for -- those up to link_last_ack -- and no others; that the evaluator is through with the ring altogether is
          * ONE more byte at the very end (table_link_finish) */
         const int64_t last_ack = link_last_ack(l);
-        for (size_t i = lo; i < hi; i++) {
+        /* The launches are ENQUEUED by this thread as fast as the ring discipline allows (lgc_party_garble_ring_begin returns at
+         * once), and a second thread tells the evaluator about each one when its tables are complete
+         * (lgc_party_garble_ring_wait): the garbler's stream never waits for the host, and the table passes of critical-path
+         * launches run beside the next launches (rounds 2-4: kernel, device synchronisation, token, next kernel). */
+        /* ... where that pays.  The asynchronous path costs a stream (a hardware queue: ~10 ms to create, and ~60 ms more at
+         * process exit when several parties leave together), 128 events and a second stash; it saves the table
+         * passes on the chain and ~10 us per launch.  scripts/exp/ring_async_ab.sh on one box: d = 20 Cholesky (166 launches)
+         * 0.274 s against 0.25 s with the synchronous loop, d = 100 CGD-15 (355 launches) 0.168-0.173 against 0.178-0.179,
+         * d = 200 Cholesky (1 600 launches) 1.54-1.72 against 1.73-1.79: from a thousand launches on.  LINREG_RING_ASYNC=1 / 0
+         * forces it on / off. */
+        const char *force = getenv("LINREG_RING_ASYNC");
+        const int use_async = force ? atoi(force) != 0 : (l->end - l->start >= 1000);
+        if (!use_async) {                      /* the loop of rounds 2-4: garble, synchronise, tell, next */
+            for (size_t i = lo; i < hi; i++) {
+                int64_t wf = lgc_party_ring_wait_for(l->po, i);
+                size_t need = wf >= (int64_t)l->start ? (size_t)(wf - (int64_t)l->start) + 1 : 0;
+                while (l->acked < need) { if (link_io(l, &tok, 1, 0)) return 1; l->acked++; }
+                TCHK(lgc_party_garble_ring(l->po, i));
+                if (i == 0) host_trace_mark("first table garbled");
+                host_progress_tick();
+                tok = 1;
+                if (link_io(l, &tok, 1, 1)) return 1;
+            }
+            size_t due0 = (last_ack >= (int64_t)l->start) ? (size_t)(last_ack - (int64_t)l->start) + 1 : 0;
+            if (due0 > hi - l->start) due0 = hi - l->start;
+            while (l->acked < due0) { if (link_io(l, &tok, 1, 0)) return 1; l->acked++; }
+            return 0;
+        }
+        ring_notifier nt;
+        memset(&nt, 0, sizeof nt);
+        nt.l = l; nt.lo = lo; nt.hi = hi; nt.begun = lo;
+        pthread_mutex_init(&nt.mu, NULL);
+        pthread_cond_init(&nt.cv, NULL);
+        pthread_t th;
+        if (pthread_create(&th, NULL, ring_notify_main, &nt)) { fprintf(stderr, "table link: could not start the notifier thread\n"); return 1; }
+        int bad = 0;
+        for (size_t i = lo; i < hi && !bad; i++) {
             int64_t wf = lgc_party_ring_wait_for(l->po, i);
             size_t need = wf >= (int64_t)l->start ? (size_t)(wf - (int64_t)l->start) + 1 : 0;
-            while (l->acked < need) { if (link_io(l, &tok, 1, 0)) return 1; l->acked++; }
-            TCHK(lgc_party_garble_ring(l->po, i));
-            if (i == 0) host_trace_mark("first table garbled");
-            host_progress_tick();
-            tok = 1;
-            if (link_io(l, &tok, 1, 1)) return 1;
+            while (l->acked < need && !bad) { if (link_io(l, &tok, 1, 0)) bad = 1; else l->acked++; }
+            if (!bad && ring_notifier_failed(&nt)) bad = 1;
+            if (!bad && lgc_party_garble_ring_begin(l->po, i) != 0) { fprintf(stderr, "%s\n", lgc_last_error()); bad = 1; }
+            if (!bad) ring_notifier_post(&nt, i + 1);
         }
+        if (bad) ring_notifier_fail(&nt);
+        pthread_join(th, NULL);
+        bad |= nt.failed;
+        pthread_mutex_destroy(&nt.mu);
+        pthread_cond_destroy(&nt.cv);
+        if (bad) return 1;
         /* acknowledgements of this range that are still on their way stay out of the next message on this channel */
         size_t due = (last_ack >= (int64_t)l->start) ? (size_t)(last_ack - (int64_t)l->start) + 1 : 0;
         if (due > hi - l->start) due = hi - l->start;

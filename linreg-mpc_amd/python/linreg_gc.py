@@ -102,6 +102,7 @@ def lib():
             ("lgc_party_finish", [vp, vp, vp, vp, vp]),
             ("lgc_party_ring_create", [vp, ci, vp, C.POINTER(sz)]), ("lgc_party_ring_open", [vp, vp, ci, sz]),
             ("lgc_party_garble_ring", [vp, sz]), ("lgc_party_evaluate_ring", [vp, sz]),
+            ("lgc_party_garble_ring_begin", [vp, sz]), ("lgc_party_garble_ring_wait", [vp, sz]),
             ("lgc_test_party_garble_ring_stage", [vp, sz, ci, C.POINTER(ci)]), ("lgc_test_party_ring_read", [vp, sz, vp, sz]),
             ("lgc_ot_sender_create", [C.POINTER(vp), ci, C.c_char_p, vp]),
             ("lgc_ot_receiver_create", [C.POINTER(vp), ci, vp, vp]),
@@ -434,6 +435,14 @@ class Party:
 
     def evaluate_ring(self, k):
         _chk(lib().lgc_party_evaluate_ring(self._h, k))
+
+    def garble_ring_begin(self, k):
+        """garbler: enqueue launch k into the ring and return at once (lgc_party_garble_ring_begin)"""
+        _chk(lib().lgc_party_garble_ring_begin(self._h, k))
+
+    def garble_ring_wait(self, k):
+        """garbler: return once the tables of launch k are complete in the ring"""
+        _chk(lib().lgc_party_garble_ring_wait(self._h, k))
 
     def test_garble_ring_stage(self, k, stage):
         """test hook: stage 1 = record kernel of launch k into the ring path, 2 = its table pass; returns True when the

@@ -114,6 +114,41 @@ def test_table_ring_holds_ciphertexts_only(lgc):
     G.close(); ref.close()
 
 
+def test_asynchronous_ring_garbling_gives_the_tables_of_the_socket_path(lgc):
+    """lgc_party_garble_ring_begin / _wait (what host/tables.c drives from two threads): two dozen launches of a Cholesky solve at a time are
+    enqueued without a single wait in between -- record kernels back to back on one stream, the table passes of the
+    critical-path launches on another, the zero-label stash alternating between two buffers -- and every launch, once waited
+    for, holds exactly the bytes the socket path sends for the same seed.  Several batches: slots, events and both stashes are reused."""
+    sysm = lgc.make_system(10, 64, 56, "cholesky", 0, 0.001, 2, 1)
+    seed = bytes(range(9, 25))
+    G = lgc.Party(sysm, lgc.GARBLER, seed=seed); ref = lgc.Party(sysm, lgc.GARBLER, seed=seed)
+    nslots, batch = 64, 24
+    G.ring_create(nslots)
+    n = G.num_launches
+    assert n > 2 * batch
+    with pytest.raises(lgc.LgcError):
+        G.garble_ring_wait(0)                                    # nothing was begun
+    checked = 0
+    for lo in range(0, n, batch):
+        hi = min(n, lo + batch)
+        for k in range(lo, hi):
+            G.garble_ring_begin(k)
+        with pytest.raises(lgc.LgcError):
+            G.garble_ring_wait(hi)                               # not begun yet
+        for k in range(lo, hi):
+            G.garble_ring_wait(k)
+            nb = G.table_bytes(k)
+            got, expect = G.test_ring_read(k, nb), ref.garble(k)
+            if k < nslots:
+                assert np.array_equal(got, expect), k
+            else:                                                # reused slot: lanes without a gate keep older ciphertexts
+                live = expect != 0
+                assert np.array_equal(got[live], expect[live]), k
+            checked += nb
+    assert checked > 10 << 20
+    G.close(); ref.close()
+
+
 def test_ti_ring_messages_are_truncated_to_32_bits(lgc, oracle):
     """--ti_ring --width_phase1=32: the masked vectors b + x and a - y are written to device memory the peer provider
     maps.  X is stored sign-extended to 64 bits, so the kernels must truncate to the protocol width: bits 32..63 of a

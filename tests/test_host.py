@@ -96,12 +96,12 @@ def _rewrite_ports(src, dst):
     return P
 
 
-def _run_all(infile, P, args, timeout=300, exe_name="linreg"):
+def _run_all(infile, P, args, timeout=300, exe_name="linreg", env=None):
     exe = os.path.join(HOST, "bin", exe_name)
     procs = []
     for party in range(1, P + 3):
         cmd = [exe, infile, args[0], str(party)] + args[1:]
-        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env))
     outs = [p.communicate(timeout=timeout) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join("party %d rc %s: %s" % (k + 1, p.returncode, e.decode()[-600:])
                                                             for k, (p, (o, e)) in enumerate(zip(procs, outs)))
@@ -149,6 +149,24 @@ def test_an_option_given_to_one_party_only_is_an_error_not_a_wrong_result(tmp_pa
     assert procs[0].returncode != 0 and procs[1].returncode != 0
     assert b"built different programs" in outs[0][1] and b"built different programs" in outs[1][1]
     assert b"Result:" not in outs[1][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg,iters,async_ring", [("cgd", "10", "1"), ("cholesky", "0", "1"), ("cholesky", "0", "0")])
+def test_five_process_ring_with_the_asynchronous_garbler(tmp_path, golden_dir, oracle, alg, iters, async_ring):
+    """--table_ring with the CSP's launches enqueued asynchronously (host/tables.c: a second thread sends the tokens; the
+    library runs the table passes of critical-path launches on a stream of their own, two stashes in turn) -- the path
+    programs of a thousand launches and more take by themselves, forced here on the README example (LINREG_RING_ASYNC=1),
+    and the synchronous loop forced the other way: same Result line"""
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    infile = str(tmp_path / "readme.in")
+    P = _rewrite_ports(os.path.join(golden_dir, "readme_example.in"), infile)
+    outs = _run_all(infile, P, ["56", alg, iters, "0.001", "--table_ring", "--input_ring"], env=dict(os.environ, LINREG_RING_ASYNC=async_ring))
+    got = re.findall("-?[0-9]+\\.[0-9]+", outs[1].strip().splitlines()[-1])
+    beta = oracle.linreg_file(os.path.join(golden_dir, "readme_example.in"), 56, -1, 64, 64, {"cholesky": 0, "cgd": 2}[alg], int(iters), 0.001)
+    assert got == ["%.15f" % (int(b) / 2.0 ** 56) for b in beta]
+    if alg == "cgd":
+        assert got == README_RESULT
 
 
 @pytest.mark.gpu
