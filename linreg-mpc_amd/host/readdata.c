@@ -130,8 +130,11 @@ static void *parse_main(void *arg) {
                     p = e;
                     j->Xq[row * j->d + col] = double_to_fixed(v / j->normalizer, j->precision, j->w2);
                 } else {
-                    if (!is_num_char((unsigned char)*p)) goto bad;       /* first character checked, the rest of the token skipped */
-                    while ((unsigned char)*p > ' ') p++;
+                    /* a column of another provider: not converted, but every character must be one a number is written
+                     * with and the token ends where pass 1's tokeniser (is_space) ends it -- a stray control byte or a
+                     * letter would otherwise shift every later row / column index silently */
+                    if (!is_num_char((unsigned char)*p)) goto bad;
+                    while (p < end && !is_space((unsigned char)*p)) { if (!is_num_char((unsigned char)*p)) goto bad; p++; }
                 }
                 if (++col == j->d) { col = 0; row++; }
             } else if (i == nd) {                       /* read_vector's length (src/linear.c:83-87) */
@@ -152,6 +155,7 @@ static void *parse_main(void *arg) {
         }
     }
     if (m < 0) goto bad;
+    if (i - j->first != j->ntok) goto bad;             /* pass 2 must have seen exactly the tokens pass 1 counted in this range */
 done:
     free(tmp);
     return 0;
