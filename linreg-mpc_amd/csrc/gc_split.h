@@ -349,36 +349,45 @@ __device__ __forceinline__ void split_sk_hash(const SplitHashCtx &hc, int n, uin
     lds_u32 *sx = hc.sxl;
     const int pl = c * kSplitPlane, plo = GARBLER ? 0 : pl;
     const int L = sk_levels(n);
-    // evaluator: the ciphertext row of a level is fetched one level ahead (every step index of the addition is known)
+    // evaluator: this lane's dword of a level's ciphertext row is fetched TWO levels ahead, into two registers in turn (every
+    // step index of the addition is known): the first AND and the odd levels use tA, the even levels tB; a register is
+    // reloaded right behind its use.  (Rounds 3-5a fetched one level ahead and copied `tg = tgn` at the head of the loop: a
+    // wait for a load issued one level -- ~1 900 cycles -- ago, right behind the barrier; the evaluator's levels were 200-380
+    // cycles longer than the garbler's, profiles/r5_split_trace.txt.)  The level loop is unrolled by two for that: no copies.
     uint32_t *row = split_row(hc, Q, st);
-    uint32_t tg = 0, tgn = 0;
+    uint32_t tA = 0, tB = 0;
     if (!GARBLER) {
-        tg = ld_u32_global(row);
-        if (L > 0) tgn = ld_u32_global(row + 512);
+        // (every load below is issued whether or not its level exists -- a level that does not exist reads the current row
+        // again: with a load on one path only, the wait in front of the OTHER register's use has to be for everything)
+        tA = ld_u32_global(row);
+        tB = ld_u32_global(row + (L > 0 ? 512 : 0));
     }
     // first AND: G = ((x ^ cin) & (y ^ cin)) ^ cin.  Results of level k go to buffer (k + 1) & 1; this step counts as level -1
     SkPlan cur = sk_plan<GARBLER, Q>(sx, -1, g, c, pl, plo, n, st), nxt;
     SkVals w = pre ? *pre : sk_load<GARBLER, Q>(cur.ptr);
-    sk_finish<GARBLER, Q>(hc, cur, w, sx + kSplitKs + Q * kSplitWord + pl + g, row, tg,
+    sk_finish<GARBLER, Q>(hc, cur, w, sx + kSplitKs + Q * kSplitWord + pl + g, row, tA,
                           [&](int rnd) { if (rnd >= 2 && rnd < 6) sk_plan_part<GARBLER, Q>(nxt, rnd - 2, sx, 0, g, c, pl, plo, n, st + 1); });
+    if (!GARBLER) tA = ld_u32_global(row + (L > 1 ? 2 * 512 : 0));                  // row of level 1
     st += 1;
     row += 512;
     SPLIT_STAMP(2)                                                                  /* first AND hashed, result stored */
     lds_barrier();
     SPLIT_STAMP(3)                                                                  /* past the barrier */
-    for (int k = 0; k < L; k++) {
+    auto level = [&](int k, uint32_t &tg) {
         cur = nxt;
         w = sk_load<GARBLER, Q>(cur.ptr);
-        tg = tgn;
-        if (!GARBLER && k + 1 < L) tgn = ld_u32_global(row + 512);                  // row of the next level
         sk_finish<GARBLER, Q>(hc, cur, w, sx + kSplitKs + (((k + 1) & 1) * 4 + Q) * kSplitWord + pl + g, row, tg,
                               [&](int rnd) { if (rnd >= 2 && rnd < 6) sk_plan_part<GARBLER, Q>(nxt, rnd - 2, sx, k + 1, g, c, pl, plo, n, st + 1); });
+        if (!GARBLER) tg = ld_u32_global(row + (k + 2 < L ? 2 * 512 : 0));          // row of level k + 2, into the register just used
         SPLIT_STAMP(5)                                                              /* hashed, result stored */
         st += 1;
         row += 512;
         lds_barrier();
         SPLIT_STAMP(3)
-    }
+    };
+    int k = 0;
+    for (; k + 1 < L; k += 2) { level(k, tB); level(k + 1, tA); }
+    if (k < L) level(k, tB);
 #if GC_SPLIT_TRACE
     if (tr.on && hc.lane == 0) g_split_trace_n[tr.w] = tr.i < 8192 ? tr.i : 8192;
 #endif

@@ -58,6 +58,9 @@ if "trace" in args:
 if "trace500" in args:  # timeline of the two chains around the MAC launches (scripts/dbg/timeline.py reads the kernel trace)
     run(500, "cgd", 3)
     run(500, "cgd", 3)
+if "chol250" in args:
+    for prof in (False, True, False):
+        run(250, "cholesky", 0, profile=prof)
 if "trace100" in args:
     run(100, "cgd", 15)
     run(100, "cgd", 15)
