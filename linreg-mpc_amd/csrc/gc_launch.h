@@ -159,6 +159,30 @@ static inline unsigned gc_num_cus() {
     }
     return (unsigned)cus;
 }
+#ifndef GC_MACK_ADAPT
+#define GC_MACK_ADAPT 0   /* experiment of round 5 (scripts/exp/mack_adapt_ab.sh) */
+#endif
+#ifndef GC_MACK_ADAPT_LO_G
+#define GC_MACK_ADAPT_LO_G 12
+#endif
+#ifndef GC_MACK_ADAPT_LO_E
+#define GC_MACK_ADAPT_LO_E 9
+#endif
+#ifndef GC_MACK_ADAPT_MAX_ROUNDS
+#define GC_MACK_ADAPT_MAX_ROUNDS 10
+#endif
+// waves per workgroup of a Karatsuba MAC launch of a few rounds: the count with the least rounds x waves
+static inline unsigned gc_mack_waves(uint32_t nrec, unsigned lo, unsigned hi) {
+    const uint64_t cus = gc_num_cus();
+    if (((uint64_t)nrec + hi - 1) / hi > (uint64_t)GC_MACK_ADAPT_MAX_ROUNDS * cus || nrec <= cus * lo) return hi;
+    unsigned best = hi;
+    uint64_t best_cost = ~0ull;
+    for (unsigned wv = hi; wv >= lo; wv--) {
+        uint64_t wgs = (nrec + wv - 1) / wv, rounds = (wgs + cus - 1) / cus, cost = rounds * wv;
+        if (cost < best_cost) { best_cost = cost; best = wv; }
+    }
+    return best;
+}
 static inline unsigned gc_mac_waves(uint32_t nrec, unsigned lo, unsigned hi) {
     if (!GC_MAC_ADAPT) return hi;
     const uint64_t cus = gc_num_cus();
