@@ -24,13 +24,13 @@ enum Op : uint32_t {
     OP_IPMAC,   // IpAcc = sum_{k<cnt} (a+k*sa)*(b+k*sb) exact; 4 words -> dst..dst+3
     OP_IPFIN,   // dst = wrap((sum of cnt IpAcc at a+4k) >> p)
     OP_IPMERGE, // IpAcc at dst..dst+3 = sum of cnt IpAcc at a+4k
-    OP_MUL,     // dst = mul(a, b)
+    OP_MUL,     // dst = mul(a, b); cnt = 2: also words[dst + sa] = hdiff(dst) (the record that makes a Karatsuba operand final forms its half differences)
     OP_MULSUB,  // dst = words[c] - mul(a, b)
     OP_ADD,     // dst = a + b
     OP_SUB,     // dst = a - b
     OP_ABS,     // dst = |a|
     OP_MAX,     // dst = max_{k<cnt} words[a+k*sa]   (ordering of Circ::gt)
-    OP_DIV,     // dst = div(a, b)
+    OP_DIV,     // dst = div(a, b); c != 0: words[c] = dst too (the mirrored entry of a symmetric matrix); cnt = 2: words[dst + sa] = hdiff(dst)
     OP_SQRT,    // dst = sqrt(a)
     OP_IDIVC,   // dst = tdiv(a, public constant c)   (linear.oc:52-65, normalizer)
     OP_CONST,   // dst = public constant (a = low 32 bits, b = high 32 bits)
@@ -120,9 +120,11 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
             be.store(r.dst + 2, A.HS); be.store(r.dst + 3, A.HC);
         }
     } break;
-    case OP_MUL:
-        be.store(r.dst, C::mul(be, be.load(r.a), be.load(r.b), w, p));
-        break;
+    case OP_MUL: {
+        W v = C::mul(be, be.load(r.a), be.load(r.b), w, p);
+        be.store(r.dst, v);
+        if (r.cnt == 2) be.store(r.dst + (uint32_t)r.sa, C::hdiff(be, v));
+    } break;
     case OP_MULSUB: {
         W X, Y;
         C::mul_xy(be, be.load(r.a), be.load(r.b), w, p, X, Y);
@@ -143,9 +145,15 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
         for (uint32_t k = 1; k < r.cnt; k++) m = C::vmax(be, be.load(r.a + (int32_t)k * r.sa), m, w);
         be.store(r.dst, m);
     } break;
-    case OP_DIV:
-        be.store(r.dst, C::div(be, be.load(r.a), be.load(r.b), w, p));
-        break;
+    case OP_DIV: {
+        // (round 5: the quotient's mirror and its half-difference word in the record that makes it final -- as launches of their
+        // own, OP_COPY / OP_HDIFF were one more dependent launch per column of a factorisation, each waiting for CUs beside
+        // the other role's MAC kernel)
+        W v = C::div(be, be.load(r.a), be.load(r.b), w, p);
+        be.store(r.dst, v);
+        if (r.c) be.store(r.c, v);
+        if (r.cnt == 2) be.store(r.dst + (uint32_t)r.sa, C::hdiff(be, v));
+    } break;
     case OP_SQRT:
         be.store(r.dst, C::vsqrt(be, be.load(r.a), w, p));
         break;

@@ -452,6 +452,7 @@ struct Program {
             case OP_REVEAL: upd(r.a); break;
             case OP_IDIVC: case OP_COPY: case OP_ABS: case OP_SQRT: case OP_HDIFF: upd(r.dst); upd(r.a); break;
             case OP_MULSUB: upd(r.dst); upd(r.a); upd(r.b); upd(r.c); break;
+            case OP_DIV: case OP_MUL: upd(r.dst); upd(r.a); upd(r.b); if (r.op == OP_DIV) upd(r.c); if (r.cnt == 2) upd((uint64_t)r.dst + (uint64_t)(uint32_t)r.sa); break;
             default: upd(r.dst); upd(r.a); upd(r.b); break;
             }
             if (hi >= n_words) return false;
@@ -723,14 +724,13 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
             }
             P.emit(Program::mk(OP_SQRT, Mi(j, j), Mi(j, j)));
             P.new_launch();
-            for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_DIV, Mi(k, j), Mi(k, j), Mi(j, j)));
-            P.emit(Program::mk(OP_DIV, y + (uint32_t)j, bv + (uint32_t)j, Mi(j, j)));                       // :75
-            P.new_launch();
-            for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_COPY, Mi(j, k), Mi(k, j)));
-            if (kdelta) {
-                for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_HDIFF, Mi(k, j) + kdelta, Mi(k, j)));
-                P.emit(Program::mk(OP_HDIFF, y + (uint32_t)j + kdelta, y + (uint32_t)j));
-            }
+            // the division record stores its quotient twice (L_kj and its mirror L^T_jk, read stride-1 by the back
+            // substitution) and, with Karatsuba products, its half-difference word: rounds 3-4 did both in a launch of
+            // their own behind the divisions -- one more dependent launch per column, each of which waits for CUs beside
+            // the other role's MAC kernel of that column
+            const uint32_t hc = kdelta ? 2u : 1u;
+            for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_DIV, Mi(k, j), Mi(k, j), Mi(j, j), Mi(j, k), hc, (int32_t)kdelta));
+            P.emit(Program::mk(OP_DIV, y + (uint32_t)j, bv + (uint32_t)j, Mi(j, j), 0, hc, (int32_t)kdelta));           // :75
             P.new_launch();
         }
         for (size_t ii = d; ii-- > 0;) {             // :79-87
@@ -756,13 +756,11 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         if (w == 64 && program_karatsuba() && (d / 2) * (d / 2 + 1) >= 2 * 4096) kdelta = P.alloc((size_t)(tv + D - M)) - M;
         for (size_t j = 0; j < d; j++) {             // ldlt.oc:50-64
             if (j > 0) {
-                for (size_t k = 0; k < j; k++) P.emit(Program::mk(OP_MUL, tv + (uint32_t)k, Mi(j, k), Mi(k, k)));
+                // t_k = L_jk D_k with its half-difference word from the same record; hdiff(b_{j-1}) (final since step j - 1 of
+                // the forward substitution) rides in the same launch: one launch where rounds 3-4 had two
+                for (size_t k = 0; k < j; k++) P.emit(Program::mk(OP_MUL, tv + (uint32_t)k, Mi(j, k), Mi(k, k), 0, kdelta ? 2u : 1u, (int32_t)kdelta));
+                if (kdelta) P.emit(Program::mk(OP_HDIFF, bv + (uint32_t)(j - 1) + kdelta, bv + (uint32_t)(j - 1)));
                 P.new_launch();
-                if (kdelta) {
-                    for (size_t k = 0; k < j; k++) P.emit(Program::mk(OP_HDIFF, tv + (uint32_t)k + kdelta, tv + (uint32_t)k));
-                    P.emit(Program::mk(OP_HDIFF, bv + (uint32_t)(j - 1) + kdelta, bv + (uint32_t)(j - 1)));
-                    P.new_launch();
-                }
                 std::vector<Program::DotJob> jobs;
                 for (size_t i = j; i < d; i++) {
                     Program::DotJob J = {Mi(i, j), Mi(i, j), Mi(i, 0), tv, (uint32_t)j, true, kdelta};
@@ -775,10 +773,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
                 jobs.push_back(F);
                 P.dots(jobs, sc_dot, x_fact_waves(), 4096);
             }
-            for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_DIV, Mi(k, j), Mi(k, j), Mi(j, j)));
-            P.new_launch();
-            for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_COPY, Mi(j, k), Mi(k, j)));
-            if (kdelta) for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_HDIFF, Mi(k, j) + kdelta, Mi(k, j)));
+            for (size_t k = j + 1; k < d; k++) P.emit(Program::mk(OP_DIV, Mi(k, j), Mi(k, j), Mi(j, j), Mi(j, k), kdelta ? 2u : 1u, (int32_t)kdelta));
             P.new_launch();
         }
         for (size_t i = 0; i < d; i++)               // :76-79

@@ -107,7 +107,12 @@ def test_karatsuba_lowering_plain_matches_oracle(lgc, gccpu, oracle, alg, d, ite
     sysm = lgc.make_system(d, w, p, alg, iters, 0.0, 2, 0, 0, 0)
     prog, dec = _plain(lgc, gccpu, sysm, shares)
     recs = np.frombuffer(prog.records().tobytes(), dtype=REC)
-    assert (recs["op"] == 20).sum() > 100 and (recs["op"] == 21).sum() >= d          # OP_MACK, OP_HDIFF
+    # OP_MACK records, and the half-difference words of their operands: OP_HDIFF records (cgd) or -- since round 5 -- formed
+    # by the division / multiplication record that makes a matrix entry final (cnt == 2: factorisations)
+    hd = (recs["op"] == 21).sum() + ((recs["cnt"] == 2) & ((recs["op"] == 13) | (recs["op"] == 7))).sum()
+    assert (recs["op"] == 20).sum() > 100 and hd >= d
+    if alg != "cgd":
+        assert (recs["op"] == 17).sum() == d * (d - 1) // 2          # OP_COPY: the input's mirror only -- no copy launch per column any more, the divider mirrors its quotient
     exp, _, _ = oracle_solve(oracle, A, b, d, w, p, alg, iters, 0.0, 0)
     got = sx(dec[prog.info.rv_beta:prog.info.rv_beta + d], w)
     assert got.tolist() == exp.tolist()
