@@ -306,11 +306,12 @@ int table_link_send_range(table_link *l, size_t lo, size_t hi) {
          * (lgc_party_garble_ring_wait): the garbler's stream never waits for the host, and the table passes of critical-path
          * launches run beside the next launches (rounds 2-4: kernel, device synchronisation, token, next kernel). */
         /* ... where that pays.  The asynchronous path costs a stream (a hardware queue: ~10 ms to create, and ~60 ms more at
-         * process exit when several parties leave together), 128 events and a second stash; it saves the table
-         * passes on the chain and ~10 us per launch.  scripts/exp/ring_async_ab.sh on one box: d = 20 Cholesky (166 launches)
-         * 0.274 s against 0.25 s with the synchronous loop, d = 100 CGD-15 (355 launches) 0.168-0.173 against 0.178-0.179,
-         * d = 200 Cholesky (1 600 launches) 1.54-1.72 against 1.73-1.79: from a thousand launches on.  LINREG_RING_ASYNC=1 / 0
-         * forces it on / off. */
+         * process exit when several parties leave together), 128 events and a second stash -- 25-30 ms of a
+         * short run's wall clock --; it takes the table passes off the chain and ~10 us off every launch.  The table phase
+         * itself, evaluator's marks, six runs each on one box (scripts/exp/ring_modes_ab.sh): d = 20 Cholesky (147 launches)
+         * 0.0436 s against 0.0448 s with the synchronous loop, d = 100 CGD-15 (355) 0.140 against 0.147, d = 200 Cholesky
+         * (1 400) 1.30 against 1.35: 3-5 % of a phase that is a tenth of a small run -- taken from a thousand launches on.
+         * LINREG_RING_ASYNC=1 / 0 forces it on / off. */
         const char *force = getenv("LINREG_RING_ASYNC");
         const int use_async = force ? atoi(force) != 0 : (l->end - l->start >= 1000);
         if (!use_async) {                      /* the loop of rounds 2-4: garble, synchronise, tell, next */

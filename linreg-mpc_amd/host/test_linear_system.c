@@ -20,6 +20,7 @@
 typedef struct { size_t n, next; const uint32_t *launch; double *time; double t0; } iter_marks;
 static void note_launch(size_t i, void *ctx) {
     iter_marks *m = ctx;
+    if (i == 0) host_trace_mark("first table evaluated");
     while (m->next < m->n && m->launch[m->next] == i) m->time[m->next++] = wall_clock() - m->t0;
 }
 
@@ -219,6 +220,7 @@ int main(int argc, char **argv) {
         iter_marks marks = {n_marks, 0, mark_launch, mark_time, t_iters};
         check(!programs_agree(self, 1, po, 0), "program check failed");
         check(!tables_recv(self, 1, po, ring_slots, chunk, note_launch, &marks), "could not receive garbled tables");
+        host_trace_mark("tables evaluated");
         size_t nr = lgc_party_num_reveal(po);
         uint64_t *dec = malloc((nr + 1) * 8);
         check(!recv_blob(self, 1, dec, nr * 8), "could not receive decode bits");
