@@ -383,14 +383,11 @@ int table_link_recv_range(table_link *l, size_t lo, size_t hi, void (*after_laun
  * HIP leaves freeing it while the importer still has it open -- and is still reading the last launches -- undefined (it
  * happens to work on this stack because the driver keeps the buffer alive).  So the evaluator says once, with one byte, that
  * every launch of the link has been evaluated (lgc_party_evaluate_ring returns after the launch has run), and the garbler
- * keeps its party object -- the ring -- until then.  Slot ring: the acknowledgements still on their way are drained first. */
+ * keeps its party object -- the ring -- until then. */
 int table_link_finish(table_link *l, int sending) {
     uint8_t tok = 0xE0;
     if (!sending) return link_io(l, &tok, 1, 1);
-    if (l->nslots != 0) {
-        size_t n = l->end - l->start, due = n > l->nslots ? n - l->nslots : 0;      /* one ack per reused slot (table_link_send_range) */
-        (void)due;                                                                 /* (all of them were read there) */
-    }
+    /* (every acknowledgement of the ranges has been read by table_link_send_range: this byte is the next on the channel) */
     if (link_io(l, &tok, 1, 0)) return 1;
     if (tok != 0xE0) { fprintf(stderr, "table link: unexpected byte %02x where the evaluator's end-of-ring byte was due\n", tok); return 1; }
     host_progress_tick();
