@@ -105,8 +105,13 @@ struct Program {
     uint32_t alloc(size_t n) { uint32_t r = n_words; n_words += (uint32_t)n; return r; }
     uint32_t alloc_reveal(size_t n) { uint32_t r = n_reveal; n_reveal += (uint32_t)n; return r; }
 
+    // (op, cnt) of the record costed last and its figures: consecutive records are mostly of one kind, and a merged sweep
+    // emits millions of them (two map lookups per record were most of the 0.2-0.3 s a 64-circuit program took to build)
+    uint32_t memo_op = ~0u, memo_cnt = 0;
+    uint64_t memo_steps = 0, memo_gates = 0, memo_xors = 0;
     void cost(const Rec &r, uint64_t &steps, uint64_t &gates) {
         // cost depends on (op, cnt) only (and on c for nothing: IDIVC uses a constant word)
+        if (r.op == memo_op && r.cnt == memo_cnt) { steps = memo_steps; gates = memo_gates; return; }
         std::pair<uint32_t, uint32_t> key(r.op, r.cnt);
         auto it = cost_cache.find(key);
         if (it == cost_cache.end()) {
@@ -117,6 +122,7 @@ struct Program {
         }
         steps = it->second.first;
         gates = it->second.second;
+        memo_op = r.op; memo_cnt = r.cnt; memo_steps = steps; memo_gates = gates; memo_xors = xor_cache[key];
     }
 
     void new_launch() { open = false; }
@@ -151,7 +157,7 @@ struct Program {
         step_cursor += s;
         total_steps += s;
         total_gates += g;
-        total_xors += xor_cache[std::make_pair(r.op, r.cnt)];
+        total_xors += memo_xors;                       // (cost(r) above left r's figures in the memo)
         if (L.steps > max_launch_steps) max_launch_steps = L.steps;
     }
 
