@@ -68,13 +68,33 @@ struct LdsTab2 {
     }
     __device__ __forceinline__ uint32_t lkt(int, uint32_t word, int k) const { return lk(word, k); }
 };
-__device__ __forceinline__ void lds_tab2_fill(uint32_t *lds) {
-    for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) {
-        uint32_t v = c_aes.te0[i >> 6];
-        lds[i] = v;
-        lds[kLdsTabWords + i] = (v << 16) | (v >> 16);
+// ---- staging the AES table image.  Row x of an image is 64 dwords that depend on Te0[x] and the position in the row only, so
+// wave w of a workgroup writes rows w, w + W, w + 2W, ...: Te0[x] is wave-uniform -- a SCALAR load, four in flight --, a row is
+// one ds_write_b32 of the whole wave, and nothing waits for vector memory.  (Rounds 1-4 had thread i write dwords i,
+// i + blockDim, ...: one vector load of Te0 per dword, each waited for before its store, sixteen times in a row.  Measured in
+// round 5: no difference in any launch profile -- those loads hit the L1 after the first workgroup -- so this is tidiness,
+// not speed.)
+template <class F>
+__device__ __forceinline__ void lds_tab_rows(F row) {
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), waves = blockDim.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    // four rows per trip, their four scalar loads issued together (indices clamped, stores guarded: no trip-count arithmetic)
+    for (uint32_t x = wave; x < 256u; x += 4u * waves) {
+        const uint32_t x1 = x + waves, x2 = x1 + waves, x3 = x2 + waves;
+        const uint32_t v0 = c_aes.te0[x], v1 = c_aes.te0[x1 < 256u ? x1 : 255u], v2 = c_aes.te0[x2 < 256u ? x2 : 255u],
+                       v3 = c_aes.te0[x3 < 256u ? x3 : 255u];
+        row(x, lane, v0);
+        if (x1 < 256u) row(x1, lane, v1);
+        if (x2 < 256u) row(x2, lane, v2);
+        if (x3 < 256u) row(x3, lane, v3);
     }
     __syncthreads();
+}
+__device__ __forceinline__ void lds_tab2_fill(uint32_t *lds) {
+    lds_tab_rows([lds](uint32_t x, uint32_t lane, uint32_t v) {
+        lds[x * 64 + lane] = v;
+        lds[kLdsTabWords + x * 64 + lane] = (v << 16) | (v >> 16);
+    });
 }
 __device__ __forceinline__ LdsTab2 lds_tab2_make(const uint32_t *lds) {
     LdsTab2 t;
@@ -109,13 +129,11 @@ struct LdsTab4 {
     }
 };
 __device__ __forceinline__ void lds_tab4_fill(uint32_t *lds) {
-    for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) {
-        uint32_t v = c_aes.te0[i >> 6];
-        const bool odd = (i >> 5) & 1;
-        lds[i] = odd ? ((v << 8) | (v >> 24)) : v;
-        lds[kLdsTabWords + i] = odd ? ((v << 24) | (v >> 8)) : ((v << 16) | (v >> 16));
-    }
-    __syncthreads();
+    lds_tab_rows([lds](uint32_t x, uint32_t lane, uint32_t v) {
+        const bool odd = lane >= 32u;            // second half of a row: the table rotated by one more byte
+        lds[x * 64 + lane] = odd ? ((v << 8) | (v >> 24)) : v;
+        lds[kLdsTabWords + x * 64 + lane] = odd ? ((v << 24) | (v >> 8)) : ((v << 16) | (v >> 16));
+    });
 }
 __device__ __forceinline__ LdsTab4 lds_tab4_make(const uint32_t *lds) {
     LdsTab4 t;
@@ -126,8 +144,7 @@ __device__ __forceinline__ LdsTab4 lds_tab4_make(const uint32_t *lds) {
 }
 
 __device__ __forceinline__ void lds_tab_fill(uint32_t *lds) {
-    for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) lds[i] = c_aes.te0[i >> 6];
-    __syncthreads();
+    lds_tab_rows([lds](uint32_t x, uint32_t lane, uint32_t v) { lds[x * 64 + lane] = v; });
 }
 __device__ __forceinline__ LdsTab lds_tab_make(const uint32_t *lds) {
     LdsTab t;
@@ -155,11 +172,7 @@ struct LdsTab2h {
     __device__ __forceinline__ uint32_t lkt(int, uint32_t word, int k) const { return lk(word, k); }
 };
 __device__ __forceinline__ void lds_tab2h_fill(uint32_t *lds) {
-    for (int i = threadIdx.x; i < kLdsTabWords; i += blockDim.x) {
-        uint32_t v = c_aes.te0[i >> 6];
-        lds[i] = ((i >> 5) & 1) ? ((v << 16) | (v >> 16)) : v;
-    }
-    __syncthreads();
+    lds_tab_rows([lds](uint32_t x, uint32_t lane, uint32_t v) { lds[x * 64 + lane] = (lane >= 32u) ? ((v << 16) | (v >> 16)) : v; });
 }
 __device__ __forceinline__ LdsTab2h lds_tab2h_make(const uint32_t *lds) {
     LdsTab2h t;
