@@ -186,9 +186,18 @@ struct SkTrace { bool on; int w; uint32_t i; };
         if (hc.lane == 0 && tr.i < 8192) g_split_trace[tr.w * 8192 + tr.i] = (t_ << 4) | (uint64_t)(tag);        \
         tr.i++;                                                                                                  \
     }
+// GC_SPLIT_TRACE == 2: stamps of the POSTED gate steps (AND / AND2: the multiplier's levels) instead of the adder levels
+#define SPLIT_STAMP2(wv, tag)                                                                                    \
+    if (GC_SPLIT_TRACE == 2 && blockIdx.x == 0) {                                                                \
+        uint64_t t_;                                                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_));                                         \
+        const uint32_t i_ = g_split_trace_n[wv];                                                                 \
+        if ((threadIdx.x & 63) == 0) { if (i_ < 8192) g_split_trace[(wv) * 8192 + i_] = (t_ << 4) | (uint64_t)(tag); g_split_trace_n[wv] = i_ + 1; } \
+    }
 #else
 struct SkTrace {};
 #define SPLIT_STAMP(tag)
+#define SPLIT_STAMP2(wv, tag)
 #endif
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -341,7 +350,7 @@ __device__ __forceinline__ void split_sk_hash(const SplitHashCtx &hc, int n, uin
     SkTrace tr;
     (void)tr;
 #if GC_SPLIT_TRACE
-    tr.on = blockIdx.x == 0 && (hc.wave == 0 || hc.wave == 4);
+    tr.on = GC_SPLIT_TRACE == 1 && blockIdx.x == 0 && (hc.wave == 0 || hc.wave == 4);
     tr.w = hc.wave == 4 ? 1 : 0;
     tr.i = tr.on ? g_split_trace_n[tr.w] : 0u;
     SPLIT_STAMP(1)                                                                  /* addition entered (after the hand-over barrier) */
@@ -514,16 +523,21 @@ struct SplitBackend {
     __device__ __forceinline__ void AND2(W a1, W b1, uint64_t act1, W a2, W b2, uint64_t act2, W &c1, W &c2) {
         SplitDesc d = {2u, act1, act2, step};
         step += 2;
+        if (wave == 0) { SPLIT_STAMP2(0, 6) }                                       /* dual step entered (glue of the row done) */
         publish(0, a1);
         publish(1, b1);
         publish(2, a2);
         publish(3, b2);
         post(d);
         lds_barrier();
+        if (wave == 0) { SPLIT_STAMP2(0, 7) }                                       /* posted, past the first barrier */
         split_hash_phase<GARBLER>(hc, d);
+        if (wave == 0) { SPLIT_STAMP2(0, 8) }                                       /* own hash done, result stored */
         lds_barrier();
+        if (wave == 0) { SPLIT_STAMP2(0, 9) }                                       /* past the second barrier */
         c1 = bit(act1) ? (result(0) ^ result(1)) : 0u;
         c2 = bit(act2) ? (result(2) ^ result(3)) : 0u;
+        if (wave == 0) { asm volatile("" :: "v"(c1), "v"(c2)); SPLIT_STAMP2(0, 10) }  /* results read */
     }
     // x + y + carry-in over lanes [0, n) as one posted job (Circ::add picks this up): same gate steps as Circ::add_generic.
     // One hand-over barrier, then one barrier per level; after the last one the results of the last level are visible to
@@ -617,8 +631,11 @@ gc_split_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *
             const gc_u32x4 hi = ((lds4)(lds_sx + kSplitDesc))[1];
             d.act1 = ((uint64_t)rfl(hi.x) << 32) | rfl(lo.w);
             d.act2 = ((uint64_t)rfl(hi.z) << 32) | rfl(hi.y);
+            if (hc.wave == 4) { SPLIT_STAMP2(1, 7) }                                /* descriptor decoded */
             split_hash_phase<GARBLER>(hc, d);
+            if (hc.wave == 4) { SPLIT_STAMP2(1, 8) }                                /* hashed, result stored */
             lds_barrier();
+            if (hc.wave == 4) { SPLIT_STAMP2(1, 9) }
         }
     }
     SplitBackend<GARBLER> be;

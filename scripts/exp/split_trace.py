@@ -33,7 +33,9 @@ for role in ("g", "e"):
         print("== %s, wave %d (%s): %d stamps" % ("garbler" if role == "g" else "evaluator", 4 * wv, "glue + hash 0" if wv == 0 else "hash 1", len(t)))
         names = {(3, 4): "barrier passed -> operands rebuilt", (4, 5): "operands -> level hashed, result stored", (5, 3): "stored -> past the barrier",
                  (1, 2): "entered -> first AND hashed", (2, 3): "first AND stored -> past the barrier", (3, 1): "last level -> next addition entered (glue of a quotient bit, 2 hand-over barriers)",
-                 (3, 3): "level without a gate of this wave", (1, 4): "entered -> first AND's operand rebuilt", (4, 2): "first AND: operand -> hashed, result stored"}
+                 (3, 3): "level without a gate of this wave",
+                 (6, 7): "dual step: publish + post + first barrier", (7, 8): "dual step: operands read + hash + result stored", (8, 9): "dual step: second barrier",
+                 (9, 10): "dual step: results read back", (10, 6): "dual step: glue of the multiplier row", (9, 7): "hash wave: barrier -> next descriptor decoded", (1, 4): "entered -> first AND's operand rebuilt", (4, 2): "first AND: operand -> hashed, result stored"}
         for k in sorted(seg):
             v = np.array(seg[k])
             print("   %-86s n %5d  median %6d  mean %7.0f  p90 %6d" % (names.get(k, str(k)), len(v), int(np.median(v)), v.mean(), int(np.percentile(v, 90))))
