@@ -34,6 +34,12 @@
 #endif
 #endif
 
+// OP_IDIVC (division by the public normalizer): 1 = multiplication by a precomputed constant (Circ::divc), 0 = the
+// divider with a constant divisor word (Circ::divc_long, rounds 1-4)
+#ifndef GC_IDIVC_MAGIC
+#define GC_IDIVC_MAGIC 1
+#endif
+
 namespace gc {
 
 GC_HD uint64_t lanes(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1)); }
@@ -551,12 +557,82 @@ struct Circ {
         W Q = div_mag(be, ua, ub, w, p, true);
         return condneg(be, Q, be.XOR(sa, sb), w);
     }
-    // tdiv(a, c) for a public constant c > 0 (the normalizer of linear.oc:52-65)
-    static GC_HD W divc(B &be, W a, uint64_t c, int w) {
+    // tdiv(a, c) for a public constant c > 0 (the normalizer of linear.oc:52-65), the long way: the divider above with a
+    // constant divisor word (rounds 1-4; kept for A/B runs, GC_IDIVC_MAGIC=0)
+    static GC_HD W divc_long(B &be, W a, uint64_t c, int w) {
         W sa = be.bcast(a, w - 1);
         W ua = condneg(be, a, sa, w);
         W Q = div_mag(be, ua, be.sel(lanes(w), be.konst(c), be.zero()), w, 0, false);
         return condneg(be, Q, sa, w);
+    }
+    // The same quotient by a multiplication with a public constant (Granlund & Montgomery, "Division by invariant
+    // integers using multiplication", PLDI 1994, theorem 4.2 at precision w-1): with l = ceil(log2 c) and
+    //     m = floor(2^(w-1+l) / c) + 1        (2^(w-1) < m < 2^w; idivc_magic in gc_program.h, on the host)
+    // floor(n / c) = floor(m n / 2^(w-1+l)) for every 0 <= n <= 2^(w-1) and c >= 2: m c = 2^(w-1+l) + e with 1 <= e <= c,
+    // so m n / 2^(w-1+l) = n/c + n e / (c 2^(w-1+l)) and the excess is at most 2^-l <= 1/c -- reached only by a power of
+    // two c at n = 2^(w-1), where n/c is whole.  |a| <= 2^(w-1) covers INT_MIN.  c = 1 is a copy.
+    // The product |a| m is a sum of popcount(m) shifted copies of |a| (m is public: which copies is wiring), kept in
+    // carry-save form.  w = 64: the 128-bit accumulator is two words (low L, high H); the copy |a| << j lies in lanes
+    // j..63 of L and lanes 0..j-1 of H -- a ROTATION of |a| -- so ONE 64-lane gate step adds it to both: lanes j.. work on
+    // L, lanes ..j-1 on H, and the lanes of either word that the copy does not reach keep their sum and carry bits
+    // (S + C is what counts, not a canonical split).  The carry out of lane j-1 of the H half lands in lane j of H's carry
+    // word, which is still zero: copies are taken in ascending j and the running sum is below 2^(64+j').  w = 32: one
+    // word holds the 64-bit product, a step works on the 32 lanes of its copy.
+    // Steps: 2 conditional negates + popcount(m) - 2 + the final addition(s): about 58 at w = 64 (the divider: 882).
+    static GC_HD W divc(B &be, W a, uint64_t m, int l, int w) {
+        const uint64_t act = lanes(w);
+        if (l == 0) return be.sel(act, a, be.zero());                      // c == 1
+        W sa = be.bcast(a, w - 1);
+        W ua = be.sel(act, condneg(be, a, sa, w), be.zero());
+        W q;
+        int seen = 0;
+        if (w == 64) {
+            W LS = be.zero(), LC = be.zero(), HS = be.zero(), HC = be.zero();
+            for (int j = 0; j < 64; j++) {
+                if (!((m >> j) & 1ull)) continue;
+                W lo = be.shl(ua, j), hi = j ? be.shr(ua, 64 - j) : be.zero();
+                if (seen == 0) { LS = lo; HS = hi; }
+                else if (seen == 1) { LC = lo; HC = hi; }
+                else {
+                    const uint64_t hl = lanes(j);                          // lanes that work on H in this step
+                    W X = be.sel(hl, hi, lo);
+                    W S = be.sel(hl, HS, LS), C = be.sel(hl, HC, LC);
+                    W t = be.AND(be.XOR(S, X), be.XOR(C, X), ~0ull);
+                    W carry = be.XOR(t, X);                                // maj(S, C, X)
+                    W sum = be.XOR(be.XOR(S, C), X);
+                    W cup = be.shl(carry, 1);
+                    LS = be.sel(hl, LS, sum);
+                    HS = be.sel(hl, sum, HS);
+                    LC = be.sel(hl, LC, be.sel(~lanes(j + 1), cup, be.zero()));                  // lane j: consumed
+                    HC = be.sel(lanes(j + 1), be.sel(1ull, be.shr(carry, 63), cup), HC);         // lane 0: L's carry out
+                }
+                seen++;
+            }
+            W cl;
+            (void)add(be, LS, LC, 64, be.zero(), &cl);
+            W h = add(be, HS, HC, 64, be.sel(1ull, cl, be.zero()), (W *)0);
+            q = be.shr(h, l - 1);
+        } else {
+            W S = be.zero(), C = be.zero();
+            for (int j = 0; j < w; j++) {
+                if (!((m >> j) & 1ull)) continue;
+                W X = be.shl(ua, j);
+                if (seen == 0) S = X;
+                else if (seen == 1) C = X;
+                else {
+                    const uint64_t on = act << j;
+                    W t = be.AND(be.XOR(S, X), be.XOR(C, X), on);
+                    W carry = be.XOR(t, X);
+                    W sum = be.XOR(be.XOR(S, C), X);
+                    S = be.sel(on, sum, S);
+                    C = be.sel(on << 1, be.shl(carry, 1), be.sel(on, be.zero(), C));
+                }
+                seen++;
+            }
+            W full = add(be, S, C, 2 * w, be.zero(), (W *)0);
+            q = be.sel(act, be.shr(full, w + l - 1), be.zero());
+        }
+        return condneg(be, q, sa, w);
     }
 
     // ---- square root.  w = 64: floor(sqrt(a_u * 2^p)); w = 32: the explicit loop of

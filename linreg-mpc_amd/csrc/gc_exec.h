@@ -52,6 +52,18 @@ struct Rec {
     uint64_t step0;   // global index of this record's first gate step
 };
 
+// the record dst = tdiv(a, c) for a public c > 0 with the constants of Circ::divc: m = floor(2^(w-1+l) / c) + 1,
+// l = ceil(log2 c) (host side: a 128-bit division)
+inline Rec idivc_rec(uint32_t dst, uint32_t a, uint32_t c, int w) {
+    int l = 0;
+    while (l < 32 && (1ull << l) < (uint64_t)c) l++;
+    const uint64_t m = c > 1 ? (uint64_t)((((unsigned __int128)1) << (w - 1 + l)) / c) + 1 : 0;
+    Rec r;
+    r.op = OP_IDIVC; r.cnt = 1; r.dst = dst; r.a = a; r.b = (uint32_t)m; r.c = c; r.sa = l; r.sb = (int32_t)(uint32_t)(m >> 32);
+    r.step0 = 0;
+    return r;
+}
+
 // number of gate steps / active AND gates of one record (host side)
 inline void rec_cost(const Rec &r, int w, int p, uint64_t &steps, uint64_t &gates, uint64_t *xors);
 
@@ -158,7 +170,9 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
         be.store(r.dst, C::vsqrt(be, be.load(r.a), w, p));
         break;
     case OP_IDIVC:
-        be.store(r.dst, C::divc(be, be.load(r.a), (uint64_t)r.c, w));
+        // c: the divisor; b | sb << 32: its multiplier m and sa: l = ceil(log2 c) (idivc_rec below)
+        if (GC_IDIVC_MAGIC) be.store(r.dst, C::divc(be, be.load(r.a), (uint64_t)r.b | ((uint64_t)(uint32_t)r.sb << 32), (int)r.sa, w));
+        else be.store(r.dst, C::divc_long(be, be.load(r.a), (uint64_t)r.c, w));
         break;
     case OP_CONST:
         be.store(r.dst, be.sel(lanes(w), be.konst((uint64_t)r.a | ((uint64_t)r.b << 32)), be.zero()));

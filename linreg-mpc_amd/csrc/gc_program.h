@@ -110,9 +110,10 @@ struct Program {
     uint32_t memo_op = ~0u, memo_cnt = 0;
     uint64_t memo_steps = 0, memo_gates = 0, memo_xors = 0;
     void cost(const Rec &r, uint64_t &steps, uint64_t &gates) {
-        // cost depends on (op, cnt) only (and on c for nothing: IDIVC uses a constant word)
-        if (r.op == memo_op && r.cnt == memo_cnt) { steps = memo_steps; gates = memo_gates; return; }
-        std::pair<uint32_t, uint32_t> key(r.op, r.cnt);
+        // cost depends on (op, cnt) only -- for OP_IDIVC (cnt is 1) on the divisor: its multiplier's set bits are the steps
+        const uint32_t cnt = r.op == OP_IDIVC ? r.c : r.cnt;
+        if (r.op == memo_op && cnt == memo_cnt) { steps = memo_steps; gates = memo_gates; return; }
+        std::pair<uint32_t, uint32_t> key(r.op, cnt);
         auto it = cost_cache.find(key);
         if (it == cost_cache.end()) {
             uint64_t s, g, x = 0;
@@ -122,7 +123,7 @@ struct Program {
         }
         steps = it->second.first;
         gates = it->second.second;
-        memo_op = r.op; memo_cnt = r.cnt; memo_steps = steps; memo_gates = gates; memo_xors = xor_cache[key];
+        memo_op = r.op; memo_cnt = cnt; memo_steps = steps; memo_gates = gates; memo_xors = xor_cache[key];
     }
 
     void new_launch() { open = false; }
@@ -593,9 +594,9 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         for (size_t i = 0; i < d; i++)
             for (size_t j = 0; j <= i; j++) {
                 if (i == j) P.emit(Program::mk(OP_ADD, Mi(i, j), S + idx(i, j), lam));
-                else P.emit(Program::mk(OP_IDIVC, Mi(i, j), S + idx(i, j), 0, D));
+                else P.emit(idivc_rec(Mi(i, j), S + idx(i, j), D, w));
             }
-        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_IDIVC, bv + (uint32_t)i, S + (uint32_t)(T + i), 0, D));
+        for (size_t i = 0; i < d; i++) P.emit(idivc_rec(bv + (uint32_t)i, S + (uint32_t)(T + i), D, w));
         P.new_launch();
     }
     // mirror the lower triangle

@@ -209,6 +209,7 @@ uint64_t gcc_plain_op(uint32_t op, int w, int p, uint32_t c, int paired, const u
         words[0] = 0; words[1] = a[i]; words[2] = b[i]; words[3] = 0;
         Rec r;
         r.op = op; r.cnt = 1; r.dst = 3; r.a = 1; r.b = 2; r.c = c; r.sa = 1; r.sb = 1; r.step0 = 0;
+        if (op == OP_IDIVC) r = idivc_rec(3, 1, c, w);
         if (paired) { PlainMachinePaired m(words, 0); exec_record(m, r, w, p); steps = m.steps; }
         else { PlainMachine m(words, 0); exec_record(m, r, w, p); steps = m.steps; }
         out[i] = words[3];

@@ -49,13 +49,34 @@ def test_div_matches_oracle(gccpu, oracle, w, paired):
 
 @pytest.mark.parametrize("w", [64, 32])
 def test_idivc_matches_oracle(gccpu, oracle, w):
+    """division by the public normalizer (a multiplication by a precomputed constant, Circ::divc) against tdiv: every
+    divisor shape (1, powers of two, odd, just above / below a power of two, the largest ones) on random numerators, the
+    extremes (0, +-1, INT_MAX, INT_MIN and its neighbours) and the numerators next to multiples of the divisor"""
     rng = np.random.default_rng(200 + w)
-    for c in (1, 2, 3, 5, 20, 100, 500, 4096):
+    top = (1 << (w - 1))
+    mask = (1 << w) - 1
+    big = [(1 << 31) - 1, (1 << 31) + 1, (1 << 32) - 1] if w == 64 else [(1 << 30) + 1, (1 << 31) - 1]
+    steps_of = {}
+    for c in [1, 2, 3, 5, 7, 20, 100, 127, 128, 129, 500, 641, 4096, 65535, 65537, 1000003] + big:
         a, _ = _operands(rng, w, 100)
-        got, _ = gccpu.plain_op(OP["IDIVC"], w, 7, a, None, c=c)
+        edge = [0, 1, mask, top - 1, top, top + 1, top - 2, 2, mask - 1]
+        near = []
+        for k in (1, 2, 3, (top - 1) // c, top // c, max(1, (top // c) - 1), int(rng.integers(1, 1 << 20))):
+            for e in (-1, 0, 1):
+                v = k * c + e
+                if 0 <= v <= top:
+                    near += [v, (-v) & mask]
+        a = np.concatenate([a, np.array(edge + near, dtype=np.uint64)])
+        got, steps = gccpu.plain_op(OP["IDIVC"], w, 7, a, None, c=c)
+        steps_of[c] = steps
         for x, g in zip(a, got):
-            exp = oracle.div(_signed(x, w), c, 0, w) & ((1 << w) - 1)
-            assert int(g) == exp, (w, c, hex(int(x)))
+            exp = oracle.div(_signed(int(x), w), c, 0, w) & mask
+            assert int(g) == exp, (w, c, hex(int(x)), hex(int(g)), hex(exp))
+    assert steps_of[1] == 0
+    # two conditional negates, one gate step per set bit of the multiplier beyond the first two, the final addition(s)
+    adder = 1 + (6 if w == 64 else 5)
+    assert max(steps_of.values()) <= 2 * adder + (w - 2) + 2 * 7
+    assert steps_of[500] <= (64 if w == 64 else 40), steps_of
 
 
 @pytest.mark.parametrize("w", [64, 32])
