@@ -402,6 +402,10 @@ int main(int argc, char **argv) {
         check(!cj.rc, "%s", cj.err);
         party_obj = cj.party_obj;
         check(!create_rings(&cj), "%s", cj.err);
+        if (!n_devices) {                                            /* the Evaluator maps the ring during the label OT */
+            check(!programs_agree(self, 2, party_obj, 1), "program check failed");
+            check(!tables_ring_meet(self, 2, party_obj, 1, ring_slots), "could not offer the table ring");
+        }
         input_ot_job *jobs = calloc((size_t)P, sizeof *jobs);
         check(jobs != NULL, "out of memory");
         int started_ot = 0, bad_ot = 0;
@@ -456,7 +460,6 @@ int main(int argc, char **argv) {
             for (int k = 0; k < n_devices; k++) close(fds[k]);
             goto done;
         }
-        check(!programs_agree(self, 2, party_obj, 1), "program check failed");
         check(!tables_send(self, 2, party_obj, ring_slots, kTableChunk), "could not stream the garbled tables");
         TRACE("tables sent");
         size_t nr = lgc_party_num_reveal(party_obj);
@@ -470,6 +473,10 @@ int main(int argc, char **argv) {
         printf("\nAlgorithm: %s\n", algorithm);
         size_t bits = lgc_party_input_bits(party_obj);
         uint8_t *labels = malloc(bits * 16);
+        if (!n_devices) {                                         /* (see the CSP's side above) */
+            check(!programs_agree(self, 1, party_obj, 0), "program check failed");
+            check(!tables_ring_meet(self, 1, party_obj, 0, ring_slots), "could not map the table ring");
+        }
         printf("party %d listening for %d inputs", party, P);
         for (int k = 3; k <= c->num_parties; k++) {
             if (input_ring) {                                     /* the provider's label buffer, mapped; one byte back when it may go */
@@ -536,7 +543,6 @@ int main(int argc, char **argv) {
             }
             g_peer_finished = 1;                                  /* every block's decode bits are in: the CSP may go */
         } else {
-            check(!programs_agree(self, 1, party_obj, 0), "program check failed");
             check(!tables_recv(self, 1, party_obj, ring_slots, kTableChunk, note_launch, &marks), "could not receive garbled tables");
             TRACE("tables evaluated");
             size_t nr = lgc_party_num_reveal(party_obj);

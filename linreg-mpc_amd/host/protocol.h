@@ -47,6 +47,8 @@ void host_trace_mark(const char *what);       /* lgc_trace_mark, and the LINREG_
 enum { TABLE_RING_BYTES = 65 };
 typedef struct { node *self; int peer, fd; lgc_party *po; size_t start, end, nslots, acked; int64_t last_ack; int last_ack_known; } table_link;   /* nslots 0: byte ring */
 int tables_ring_prepare(lgc_party *po, int ring_slots);   /* garbler, optional: create the ring before tables_send / table_link_open need it */
+/* both, optional, over the party connection: the ring's hello ahead of tables_send / tables_recv (the evaluator maps the ring here) */
+int tables_ring_meet(node *self, int peer, lgc_party *po, int sending, int ring_slots);
 int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, int sending, int ring_slots, size_t start);
 int table_link_send_range(table_link *l, size_t lo, size_t hi);
 int table_link_recv_range(table_link *l, size_t lo, size_t hi, void (*after_launch)(size_t launch, void *ctx), void *ctx);

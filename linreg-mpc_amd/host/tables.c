@@ -204,7 +204,7 @@ static int link_io(table_link *l, void *buf, size_t n, int wr) {
  * the label OT): a device allocation of tens of GB takes from 0.1 s to seconds, and taken inside tables_send it is on the
  * evaluator's clock.  A prepared ring is picked up by table_link_open. */
 enum { kMaxPrepared = 16 };
-static struct { lgc_party *po; ring_hello h; } g_prepared[kMaxPrepared];
+static struct { lgc_party *po; ring_hello h; int met; } g_prepared[kMaxPrepared];   /* met: the hello has been exchanged already */
 static pthread_mutex_t g_prepared_mu = PTHREAD_MUTEX_INITIALIZER;
 static int ring_create(lgc_party *po, int ring_slots, ring_hello *h) {
     size_t sb = 0;
@@ -227,29 +227,61 @@ int tables_ring_prepare(lgc_party *po, int ring_slots) {
     (void)sb;
     pthread_mutex_lock(&g_prepared_mu);
     int ok = 0;
-    for (int i = 0; i < kMaxPrepared && !ok; i++) if (!g_prepared[i].po) { g_prepared[i].po = po; g_prepared[i].h = h; ok = 1; }
+    for (int i = 0; i < kMaxPrepared && !ok; i++) if (!g_prepared[i].po) { g_prepared[i].po = po; g_prepared[i].h = h; g_prepared[i].met = 0; ok = 1; }
     pthread_mutex_unlock(&g_prepared_mu);
     return ok ? 0 : 1;
 }
+/* 0: nothing kept for this party object; 1: a created ring; 2: a ring whose hello both sides have seen */
 static int take_prepared(lgc_party *po, ring_hello *h) {
     int found = 0;
     pthread_mutex_lock(&g_prepared_mu);
-    for (int i = 0; i < kMaxPrepared && !found; i++) if (g_prepared[i].po == po) { *h = g_prepared[i].h; g_prepared[i].po = NULL; found = 1; }
+    for (int i = 0; i < kMaxPrepared && !found; i++)
+        if (g_prepared[i].po == po) { *h = g_prepared[i].h; g_prepared[i].po = NULL; found = 1 + g_prepared[i].met; }
     pthread_mutex_unlock(&g_prepared_mu);
     return found;
+}
+static int keep_met(lgc_party *po, const ring_hello *h) {
+    int ok = 0;
+    pthread_mutex_lock(&g_prepared_mu);
+    for (int i = 0; i < kMaxPrepared && !ok; i++) if (!g_prepared[i].po) { g_prepared[i].po = po; g_prepared[i].h = *h; g_prepared[i].met = 1; ok = 1; }
+    pthread_mutex_unlock(&g_prepared_mu);
+    return ok ? 0 : 1;
+}
+static int ring_open_hello(lgc_party *po, const ring_hello *h) {
+    if (h->nslots == 0) TCHK(lgc_party_ring_open_bytes(po, h->handle, (size_t)h->slot_bytes));
+    else TCHK(lgc_party_ring_open(po, h->handle, (int)h->nslots, (size_t)h->slot_bytes));
+    return 0;
+}
+/* The hello of the party connection ahead of the tables: the garbler names its ring as soon as it exists, the evaluator
+ * maps it while the data providers are still in the label OT -- hipIpcOpenMemHandle on a ring of tens of GB takes 20 ms
+ * (config 4; 3.6 ms for config 3's), which tables_recv would spend with every input label in and the garbler waiting.
+ * tables_send / tables_recv pick the ring up from here (table_link_open). */
+int tables_ring_meet(node *self, int peer, lgc_party *po, int sending, int ring_slots) {
+    if (ring_slots <= 0) return 0;
+    ring_hello h;
+    memset(&h, 0, sizeof h);
+    if (sending) {
+        if (!take_prepared(po, &h) && ring_create(po, ring_slots, &h)) return 1;
+        if (send_blob(self, peer, &h, sizeof h)) return 1;
+    } else {
+        if (recv_blob(self, peer, &h, sizeof h)) return 1;
+        if (ring_open_hello(po, &h)) return 1;
+    }
+    return keep_met(po, &h);
 }
 int table_link_open(table_link *l, node *self, int peer, int fd, lgc_party *po, int sending, int ring_slots, size_t start) {
     memset(l, 0, sizeof *l);
     l->self = self; l->peer = peer; l->fd = fd; l->po = po; l->start = start; l->end = lgc_party_num_launches(po);
     ring_hello h;
     memset(&h, 0, sizeof h);
-    if (sending) {
-        if (!take_prepared(po, &h) && ring_create(po, ring_slots, &h)) return 1;
+    const int kept = take_prepared(po, &h);
+    if (kept == 2) {                                                /* tables_ring_meet has been here */
+    } else if (sending) {
+        if (!kept && ring_create(po, ring_slots, &h)) return 1;
         if (link_io(l, &h, sizeof h, 1)) return 1;
     } else {
         if (link_io(l, &h, sizeof h, 0)) return 1;
-        if (h.nslots == 0) TCHK(lgc_party_ring_open_bytes(po, h.handle, (size_t)h.slot_bytes));
-        else TCHK(lgc_party_ring_open(po, h.handle, (int)h.nslots, (size_t)h.slot_bytes));
+        if (ring_open_hello(po, &h)) return 1;
     }
     l->nslots = (size_t)h.nslots;
     return 0;
@@ -319,6 +351,7 @@ int table_link_send_range(table_link *l, size_t lo, size_t hi) {
                 int64_t wf = lgc_party_ring_wait_for(l->po, i);
                 size_t need = wf >= (int64_t)l->start ? (size_t)(wf - (int64_t)l->start) + 1 : 0;
                 while (l->acked < need) { if (link_io(l, &tok, 1, 0)) return 1; l->acked++; }
+                if (i == 0) host_trace_mark("first launch begins");
                 TCHK(lgc_party_garble_ring(l->po, i));
                 if (i == 0) host_trace_mark("first table garbled");
                 host_progress_tick();
