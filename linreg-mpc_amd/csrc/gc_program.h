@@ -584,6 +584,12 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
                            (uint32_t)nshares, (int32_t)(T + d)));
     P.new_launch();
     if (normalize) {
+        // the division by the public normalizer (linear.oc:57-65) does not depend on lambda either: in place on the share
+        // sums, still in the prefix -- a sweep divides once, not once per circuit (1.5 % of a d = 100 CGD-15 circuit)
+        for (size_t i = 0; i < d; i++)
+            for (size_t j = 0; j < i; j++) P.emit(idivc_rec(S + idx(i, j), S + idx(i, j), D, w));
+        for (size_t i = 0; i < d; i++) P.emit(idivc_rec(S + (uint32_t)(T + i), S + (uint32_t)(T + i), D, w));
+        P.new_launch();
         P.shared_end = S + (uint32_t)(T + d);
         P.prefix_launches = (uint32_t)P.launches.size();
         P.prefix_steps = P.total_steps;
@@ -591,18 +597,22 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.lam_rec = (uint32_t)P.recs.size();
         P.emit(Program::mk(OP_CONST, lam, (uint32_t)lambda_fixed, (uint32_t)(lambda_fixed >> 32)));
         P.new_launch();
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_ADD, Mi(i, i), S + idx(i, i), lam));     // linear.oc:54-56
+        P.new_launch();
+        // the circuit's own copy of the rest, both triangles (the factorisations work in place)
         for (size_t i = 0; i < d; i++)
-            for (size_t j = 0; j <= i; j++) {
-                if (i == j) P.emit(Program::mk(OP_ADD, Mi(i, j), S + idx(i, j), lam));
-                else P.emit(idivc_rec(Mi(i, j), S + idx(i, j), D, w));
+            for (size_t j = 0; j < i; j++) {
+                P.emit(Program::mk(OP_COPY, Mi(i, j), S + idx(i, j)));
+                P.emit(Program::mk(OP_COPY, Mi(j, i), S + idx(i, j)));
             }
-        for (size_t i = 0; i < d; i++) P.emit(idivc_rec(bv + (uint32_t)i, S + (uint32_t)(T + i), D, w));
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_COPY, bv + (uint32_t)i, S + (uint32_t)(T + i)));
+        P.new_launch();
+    } else {
+        // mirror the lower triangle
+        for (size_t i = 0; i < d; i++)
+            for (size_t j = 0; j < i; j++) P.emit(Program::mk(OP_COPY, Mi(j, i), Mi(i, j)));
         P.new_launch();
     }
-    // mirror the lower triangle
-    for (size_t i = 0; i < d; i++)
-        for (size_t j = 0; j < i; j++) P.emit(Program::mk(OP_COPY, Mi(j, i), Mi(i, j)));
-    P.new_launch();
     if (reveal_ab) {
         P.rv_ab = P.alloc_reveal(T + d);
         for (size_t i = 0; i < d; i++)

@@ -86,6 +86,34 @@ def test_extreme_operand_values(lgc, oracle):
             _check(lgc, oracle, A, b, d, w, p, "cgd", 2, 2, 0, 0.0, rng)
 
 
+@pytest.mark.parametrize("w,p", [(64, 56), (32, 30)])
+@pytest.mark.parametrize("d", [2, 3, 7, 16, 33])
+def test_normalizer_on_extreme_sums(lgc, oracle, w, p, d):
+    """division by the public normalizer d (linear.oc:52-65; Circ::divc multiplies by a precomputed constant) on the sums
+    that stress it: INT_MIN and its neighbours, +-1, multiples of d and their neighbours, arbitrary words -- through the
+    narrow kernels (d < 32) and the one-wave-per-record kernel (d = 33: 594 records)"""
+    rng = np.random.default_rng(w + d)
+    T = d * (d + 1) // 2
+    m = (1 << w) - 1
+    top = 1 << (w - 1)
+    special = [top, top + 1, top - 1, m, 1, 0, 2, m - 1]
+    for k in (1, 5, top // d, top // d - 1, int(rng.integers(1, 1 << 20))):
+        for e in (-1, 0, 1):
+            v = k * d + e
+            if 0 <= v <= top:
+                special += [v, (-v) & m]
+    vals = np.array(special, dtype=np.uint64)
+    A = rng.integers(0, 2 ** 63, size=T, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=T, dtype=np.uint64)
+    b = rng.integers(0, 2 ** 63, size=d, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=d, dtype=np.uint64)
+    A &= np.uint64(m); b &= np.uint64(m)
+    off = [i * (i + 1) // 2 + j for i in range(d) for j in range(i)]          # the normalizer divides these (and b)
+    for t, v in zip(off, vals):
+        A[t] = v
+    for i in range(d):
+        b[i] = vals[(len(off) + i) % len(vals)]
+    _check(lgc, oracle, A, b, d, w, p, "cgd", 1, 3, 1, 0.25, rng)
+
+
 def test_parked_table_ring_is_reused_and_released(lgc, oracle):
     """a closed solver parks its table ring for the next one (gc_engine.hip: RingCache): a larger system after a smaller
     one, a smaller one after a larger one and a solve after lgc_release_cached_memory() all give the oracle's result"""

@@ -227,11 +227,17 @@ def test_sweep_program_matches_oracle_per_lambda(lgc, gccpu, oracle, w, p, alg):
     base = lgc.Program(lgc.make_system(d, w, p, alg, iters, lams[0], nsh, 1, 0, 0))
     prog = lgc.Program(sysm, lambdas=lams)
     info = prog.info
-    # shared prefix: the constant zero, the input words and the share sums exist once (lambda enters
-    # after the summation, linear.oc:52-57); everything else is per circuit
+    # shared prefix: the constant zero, the input words and the share sums -- divided by the public normalizer in place,
+    # off the diagonal and in b -- exist once (lambda enters on the diagonal, linear.oc:52-57); everything else is per
+    # circuit: two prefix launches, the sums and the normalizer
     T = d * (d + 1) // 2
     se = info.shared_end
-    assert se == base.info.shared_end == 1 + (nsh + 1) * (T + d) and info.prefix_launches == base.info.prefix_launches == 1
+    assert se == base.info.shared_end == 1 + (nsh + 1) * (T + d) and info.prefix_launches == base.info.prefix_launches == 2
+    recs = np.frombuffer(base.records().tobytes(), dtype=np.dtype([("op", "<u4"), ("cnt", "<u4"), ("dst", "<u4"), ("a", "<u4"), ("b", "<u4"), ("c", "<u4"), ("sa", "<i4"), ("sb", "<i4"), ("step0", "<u8")]))
+    l1 = base.launches()[1]
+    norm = recs[l1["first_rec"]:l1["first_rec"] + l1["nrec"]]
+    assert (norm["op"] == 15).all() and len(norm) == T and (norm["dst"] == norm["a"]).all() and (norm["dst"] < se).all()   # OP_IDIVC
+    assert not (recs[l1["first_rec"] + l1["nrec"]:]["op"] == 15).any()
     assert info.replicas == len(lams) and 0 < info.word_stride <= base.info.n_words - se    # (a merged circuit needs fewer, longer records)
     assert info.reveal_stride == base.info.n_reveal and info.n_reveal == len(lams) * base.info.n_reveal
     assert info.n_words == se + len(lams) * (base.info.n_words - se)
