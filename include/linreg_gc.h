@@ -294,6 +294,11 @@ int lgc_party_evaluate_ring(lgc_party *p, size_t launch);
  * second thread while the first goes on enqueueing (host/tables.c does).  What the ring ever holds is unchanged. */
 int lgc_party_garble_ring_begin(lgc_party *p, size_t launch);
 int lgc_party_garble_ring_wait(lgc_party *p, size_t launch);
+/* streams = 1: table passes stay on the record kernels' stream (no second queue to create, no second stash): all that is
+ * left of the asynchronous path is that the garbler's stream does not wait for the host between launches -- the form for
+ * short programs, where creating a queue costs more than overlapping the passes gains.  2 (default): as above.  Before the
+ * first _begin. */
+int lgc_party_garble_ring_streams(lgc_party *p, int streams);
 /* evaluator: the labels a data provider forwarded (dcsSendIntArray -> orecv, input.c:46, 84-92) */
 int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint8_t *labels);
 /* The same two hand-overs with the labels left in HBM (bin/linreg --input_ring: all parties on one node).  The garbler exports a

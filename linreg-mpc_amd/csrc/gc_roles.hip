@@ -58,6 +58,7 @@ struct lgc_party {
     hipStream_t s_pass;
     hipEvent_t ev_rec[kPartyEvents], ev_done[kPartyEvents];
     bool async_ready;
+    bool one_stream;                 // lgc_party_garble_ring_streams(p, 1): table passes on the record kernels' stream
     Lbl *stash2;
     size_t stash2_bytes;
     uint64_t n_crit;       // critical-path launches begun so far (stash = n_crit & 1)
@@ -107,7 +108,7 @@ extern "C" void lgc_party_destroy(lgc_party *p) {
     }
     if (p->async_ready) {
         for (int i = 0; i < kPartyEvents; i++) { (void)hipEventDestroy(p->ev_rec[i]); (void)hipEventDestroy(p->ev_done[i]); }
-        (void)hipStreamDestroy(p->s_pass);
+        if (p->s_pass) (void)hipStreamDestroy(p->s_pass);
     }
     if (p->words) (void)hipFree(p->words);
     if (p->tab) (void)hipFree(p->tab);
@@ -198,7 +199,7 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
     p->sys = *sys; p->device = device; p->role = role;
     p->words = 0; p->tab = 0; p->dec = 0; p->recs = 0; p->labels_ready = false;
     p->ring = 0; p->ring_slots = 0; p->ring_slot_bytes = 0; p->ring_imported = false; p->ring_bytes = 0; p->tab_bytes = 0;
-    p->s_pass = 0; p->async_ready = false; p->stash2 = 0; p->stash2_bytes = 0; p->n_crit = 0; p->stash_user[0] = p->stash_user[1] = -1;
+    p->s_pass = 0; p->async_ready = false; p->one_stream = false; p->stash2 = 0; p->stash2_bytes = 0; p->n_crit = 0; p->stash_user[0] = p->stash_user[1] = -1;
     p->begun_hi = -1;
     if (!max_launch_table_bytes) max_launch_table_bytes = (size_t)256 << 20;
     const uint64_t cap = max_launch_table_bytes / 2048 ? max_launch_table_bytes / 2048 : 1;
@@ -570,17 +571,30 @@ extern "C" int lgc_party_garble_ring(lgc_party *p, size_t launch) {
 // between two private buffers: the record kernel of launch i + 1 runs beside the table pass of launch i.
 static int party_async_setup(lgc_party *p) {
     if (p->async_ready) return LGC_OK;
-    RCHK(hipStreamCreateWithFlags(&p->s_pass, hipStreamNonBlocking));
+    if (!p->one_stream) RCHK(hipStreamCreateWithFlags(&p->s_pass, hipStreamNonBlocking));
     for (int i = 0; i < kPartyEvents; i++) {
         RCHK(hipEventCreateWithFlags(&p->ev_rec[i], hipEventDisableTiming));
         RCHK(hipEventCreateWithFlags(&p->ev_done[i], hipEventDisableTiming));
     }
     const size_t sb = party_stash_bytes(p);
     RCHK(party_need_tab(p, sb));
-    hipError_t e = hipMalloc(&p->stash2, sb);
-    if (e != hipSuccess) return lgc_fail(LGC_ENOMEM, "hipMalloc(second stash, %zu bytes): %s", sb, hipGetErrorString(e));
-    p->stash2_bytes = sb;
+    if (!p->one_stream) {            // (one stream: every kernel in order, one stash)
+        hipError_t e = hipMalloc(&p->stash2, sb);
+        if (e != hipSuccess) return lgc_fail(LGC_ENOMEM, "hipMalloc(second stash, %zu bytes): %s", sb, hipGetErrorString(e));
+        p->stash2_bytes = sb;
+    }
     p->async_ready = true;
+    return LGC_OK;
+}
+// streams == 1: the table pass of a critical-path launch stays on the record kernels' stream (no second hardware queue to
+// create -- ~10 ms, and more when the process exits --, no second stash): what is left of the asynchronous path is that the
+// garbler's stream never waits for the host between launches.  streams == 2 (default): as described above.  Before the first
+// lgc_party_garble_ring_begin.
+extern "C" int lgc_party_garble_ring_streams(lgc_party *p, int streams) {
+    if (!p || (streams != 1 && streams != 2)) return lgc_fail(LGC_EINVAL, "bad argument");
+    if (p->role != LGC_ROLE_GARBLER) return lgc_fail(LGC_ESTATE, "not the garbler");
+    if (p->async_ready) return lgc_fail(LGC_ESTATE, "launches have been begun already");
+    p->one_stream = streams == 1;
     return LGC_OK;
 }
 extern "C" int lgc_party_garble_ring_begin(lgc_party *p, size_t launch) {
@@ -598,7 +612,7 @@ extern "C" int lgc_party_garble_ring_begin(lgc_party *p, size_t launch) {
     Lbl *tab = ring_slot(p, launch);
     bool crit = false;
     const int k = (int)(p->n_crit & 1);
-    Lbl *stash = k ? p->stash2 : p->tab;
+    Lbl *stash = (k && p->stash2) ? p->stash2 : p->tab;
     // (stage 0: nothing is launched, only the launch's mode is reported)
     RCHK(gc_launch<true>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab, p->R, p->P.w, p->P.p, 0, stash, 0, &crit));
     if (!crit) {

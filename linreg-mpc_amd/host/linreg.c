@@ -465,6 +465,7 @@ int main(int argc, char **argv) {
         size_t nr = lgc_party_num_reveal(party_obj);
         uint64_t *dec = malloc((nr + 1) * 8);
         LGC(lgc_party_decode_bits(party_obj, dec));
+        TRACE("decode bits read");
         check(!send_blob(self, 2, dec, nr * 8), "could not send decode bits");
         free(dec);
         g_peer_finished = 1;                                     /* (ring mode: tables_send returned with the ring released) */

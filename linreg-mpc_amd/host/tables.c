@@ -204,6 +204,15 @@ static int link_io(table_link *l, void *buf, size_t n, int wr) {
  * the label OT): a device allocation of tens of GB takes from 0.1 s to seconds, and taken inside tables_send it is on the
  * evaluator's clock.  A prepared ring is picked up by table_link_open. */
 enum { kMaxPrepared = 16 };
+#ifndef LINREG_RING_ASYNC_SHORT
+#define LINREG_RING_ASYNC_SHORT 0      /* how a garbling link of fewer than 1000 launches drives them: 0 sync loop, 2 one-stream asynchronous.
+                                          Measured at the end of round 5 (scripts/exp/ring_modes3_ab.sh, six runs each on one box): the table
+                                          phase of d = 100 CGD-15 0.1489 s (0) / 0.1443 (1) / 0.1457 (2), d = 20 Cholesky 0.0447 / 0.0427 /
+                                          0.0436, d = 5 CGD-10 0.0333 / 0.0321 / 0.0319 -- and in bin/linreg the CSP's first blocking copy after
+                                          the tables (the decode bits) then takes 9 ms instead of 0.1 (config 3; not in a stand-alone garbler,
+                                          scripts/exp/decode_after_async.py), so the Evaluator leaves no earlier: 0 stays */
+#endif
+enum { kRingAsyncShort = LINREG_RING_ASYNC_SHORT };
 static struct { lgc_party *po; ring_hello h; int met; } g_prepared[kMaxPrepared];   /* met: the hello has been exchanged already */
 static pthread_mutex_t g_prepared_mu = PTHREAD_MUTEX_INITIALIZER;
 static int ring_create(lgc_party *po, int ring_slots, ring_hello *h) {
@@ -345,7 +354,10 @@ int table_link_send_range(table_link *l, size_t lo, size_t hi) {
          * (1 400) 1.30 against 1.35: 3-5 % of a phase that is a tenth of a small run -- taken from a thousand launches on.
          * LINREG_RING_ASYNC=1 / 0 forces it on / off. */
         const char *force = getenv("LINREG_RING_ASYNC");
-        const int use_async = force ? atoi(force) != 0 : (l->end - l->start >= 1000);
+        const int use_async = force ? atoi(force) : (l->end - l->start >= 1000 ? 1 : kRingAsyncShort);
+        /* 2: the same with the table passes left on the record kernels' stream (lgc_party_garble_ring_streams(po, 1)): no
+         * queue to create, and still no host round trip between the garbler's launches */
+        if (use_async == 2 && lo == l->start) TCHK(lgc_party_garble_ring_streams(l->po, 1));
         if (!use_async) {                      /* the loop of rounds 2-4: garble, synchronise, tell, next */
             for (size_t i = lo; i < hi; i++) {
                 int64_t wf = lgc_party_ring_wait_for(l->po, i);

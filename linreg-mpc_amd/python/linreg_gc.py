@@ -103,6 +103,7 @@ def lib():
             ("lgc_party_ring_create", [vp, ci, vp, C.POINTER(sz)]), ("lgc_party_ring_open", [vp, vp, ci, sz]),
             ("lgc_party_garble_ring", [vp, sz]), ("lgc_party_evaluate_ring", [vp, sz]),
             ("lgc_party_garble_ring_begin", [vp, sz]), ("lgc_party_garble_ring_wait", [vp, sz]),
+            ("lgc_party_garble_ring_streams", [vp, C.c_int]),
             ("lgc_test_party_garble_ring_stage", [vp, sz, ci, C.POINTER(ci)]), ("lgc_test_party_ring_read", [vp, sz, vp, sz]),
             ("lgc_ot_sender_create", [C.POINTER(vp), ci, C.c_char_p, vp]),
             ("lgc_ot_receiver_create", [C.POINTER(vp), ci, vp, vp]),
@@ -439,6 +440,10 @@ class Party:
     def garble_ring_begin(self, k):
         """garbler: enqueue launch k into the ring and return at once (lgc_party_garble_ring_begin)"""
         _chk(lib().lgc_party_garble_ring_begin(self._h, k))
+
+    def garble_ring_streams(self, n):
+        """1: table passes on the record kernels' stream (before the first garble_ring_begin); 2: a stream of their own"""
+        _chk(lib().lgc_party_garble_ring_streams(self._h, n))
 
     def garble_ring_wait(self, k):
         """garbler: return once the tables of launch k are complete in the ring"""

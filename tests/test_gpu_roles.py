@@ -114,8 +114,10 @@ def test_table_ring_holds_ciphertexts_only(lgc):
     G.close(); ref.close()
 
 
-def test_asynchronous_ring_garbling_gives_the_tables_of_the_socket_path(lgc):
-    """lgc_party_garble_ring_begin / _wait (what host/tables.c drives from two threads): two dozen launches of a Cholesky solve at a time are
+@pytest.mark.parametrize("streams", [2, 1])
+def test_asynchronous_ring_garbling_gives_the_tables_of_the_socket_path(lgc, streams):
+    """(streams = 1, lgc_party_garble_ring_streams: the table passes stay on the record kernels' stream, one stash.)
+    lgc_party_garble_ring_begin / _wait (what host/tables.c drives from two threads): two dozen launches of a Cholesky solve at a time are
     enqueued without a single wait in between -- record kernels back to back on one stream, the table passes of the
     critical-path launches on another, the zero-label stash alternating between two buffers -- and every launch, once waited
     for, holds exactly the bytes the socket path sends for the same seed.  Several batches: slots, events and both stashes are reused."""
@@ -128,6 +130,10 @@ def test_asynchronous_ring_garbling_gives_the_tables_of_the_socket_path(lgc):
     assert n > 2 * batch
     with pytest.raises(lgc.LgcError):
         G.garble_ring_wait(0)                                    # nothing was begun
+    with pytest.raises(lgc.LgcError):
+        G.garble_ring_streams(3)
+    if streams == 1:
+        G.garble_ring_streams(1)
     checked = 0
     for lo in range(0, n, batch):
         hi = min(n, lo + batch)
@@ -146,6 +152,8 @@ def test_asynchronous_ring_garbling_gives_the_tables_of_the_socket_path(lgc):
                 assert np.array_equal(got[live], expect[live]), k
             checked += nb
     assert checked > 10 << 20
+    with pytest.raises(lgc.LgcError):
+        G.garble_ring_streams(2)                                 # launches have been begun
     G.close(); ref.close()
 
 

@@ -152,12 +152,12 @@ def test_an_option_given_to_one_party_only_is_an_error_not_a_wrong_result(tmp_pa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("alg,iters,async_ring", [("cgd", "10", "1"), ("cholesky", "0", "1"), ("cholesky", "0", "0")])
+@pytest.mark.parametrize("alg,iters,async_ring", [("cgd", "10", "1"), ("cholesky", "0", "1"), ("cholesky", "0", "0"), ("cgd", "10", "2"), ("cholesky", "0", "2")])
 def test_five_process_ring_with_the_asynchronous_garbler(tmp_path, golden_dir, oracle, alg, iters, async_ring):
     """--table_ring with the CSP's launches enqueued asynchronously (host/tables.c: a second thread sends the tokens; the
     library runs the table passes of critical-path launches on a stream of their own, two stashes in turn) -- the path
     programs of a thousand launches and more take by themselves, forced here on the README example (LINREG_RING_ASYNC=1),
-    and the synchronous loop forced the other way: same Result line"""
+    the synchronous loop forced the other way (0), and the asynchronous path on ONE stream (2): same Result line"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     infile = str(tmp_path / "readme.in")
     P = _rewrite_ports(os.path.join(golden_dir, "readme_example.in"), infile)
