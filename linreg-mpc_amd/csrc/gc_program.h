@@ -845,6 +845,11 @@ inline bool replicate_program(Program &P, const Program &P0, size_t count, const
         return false;
     size_t next_iter = 0;
     const uint32_t shared_end = P0.shared_end;
+    {   // 6.4 M records (257 MB) for 64 circuits of d = 100 CGD-15: grown by doubling, the vector copied itself twice over
+        size_t npre = 0;
+        for (size_t li = 0; li < P0.prefix_launches && li < P0.launches.size(); li++) npre += P0.launches[li].nrec;
+        P.recs.reserve(npre + (P0.recs.size() - npre) * count);
+    }
     for (size_t li = 0; li < P0.launches.size(); li++) {
         const Launch &L = P0.launches[li];
         const bool prefix = li < P0.prefix_launches;
