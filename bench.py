@@ -767,7 +767,7 @@ def main():
                          # allocated; the broadcast itself as rank 0 sees it; this rank's block; the result gather
                          **dict(zip(phase_keys, phases)),
                          "collectives": ("broadcast(seed, garbled prefix) + all_gather(results) over %s" % backend) if world > 1 else None,
-                         "sharding": "contiguous blocks of %d lambdas per rank; prefix (input labels + share-summation tables) garbled once on rank 0" % ((nl + world - 1) // world)}
+                         "sharding": "contiguous blocks of %d lambdas per rank; prefix (input labels + share-summation and normalizer tables) garbled once on rank 0" % ((nl + world - 1) // world)}
             sweep_res["block_lambdas"] = (nl + world - 1) // world
             sweep_check = (stot, sT, sd, sit, lams, sres, nl)      # compared with the oracle in the cpu_baseline leg
             if world > 1:
