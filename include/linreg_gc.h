@@ -118,8 +118,9 @@ int lgc_solver_run(lgc_solver *s, int profile);
 
 /* Per-lambda sweep (BASELINE config 5): `count` circuits that differ only in the public
  * regularisation constant added to the diagonal (src/linear.oc:52-57), garbled and evaluated as one
- * program.  lambda enters AFTER the shares are summed, so the input labels and the garbled
- * share-summation launches -- the shared prefix -- exist once for the whole sweep (a data provider
+ * program.  lambda enters AFTER the shares are summed, so the input labels, the garbled
+ * share-summation launches and the division by the public normalizer (off the diagonal and in b:
+ * linear.oc:57-65) -- the shared prefix -- exist once for the whole sweep (a data provider
  * runs one label OT whatever the number of lambdas); the launches of all circuits are merged, so the
  * latency-bound stages (dividers, reveals) of different circuits fill the GPU together.
  * sys->lambda is ignored; sys->normalize must be 1, trace and reveal_inputs 0.  All circuits read
@@ -131,13 +132,13 @@ size_t lgc_solver_num_circuits(const lgc_solver *s);
 /* One rank's block of a sweep sharded over several GPUs: circuits
  * [first, first + count) of the whole sweep.  All ranks use the SAME seed: they share the prefix, hence
  * the garbler's offset R, and `first` keeps the gate ids of different ranks' circuits disjoint.
- *   rank 0:     lgc_solver_set_shares; lgc_solver_prefix_garble        (input labels + prefix tables)
+ *   rank 0:     lgc_solver_set_shares; lgc_solver_prefix_garble        (input labels; the prefix garbled AND evaluated)
  *               lgc_solver_prefix_export(dev_buf)                      -> broadcast (RCCL over xGMI)
- *   every rank: lgc_solver_prefix_import(dev_buf); lgc_solver_run      (evaluates the prefix from the
- *               broadcast tables, then garbles + evaluates its own circuits)
+ *   every rank: lgc_solver_prefix_import(dev_buf); lgc_solver_run      (garbles + evaluates its own circuits on the
+ *               words the prefix left; the prefix launches are not run again -- rounds 2-5 shipped their tables too)
  * dev_buf: device memory of lgc_solver_prefix_bytes() bytes on the solver's GPU, owned by the caller
  * (e.g. a torch tensor handed to torch.distributed.broadcast).  Layout: garbler words of the shared
- * region | evaluator words of the shared region | tables of the prefix launches, in launch order. */
+ * region | evaluator words of the shared region, both as the prefix leaves them. */
 int lgc_solver_create_sweep_at(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16],
                                size_t count, const double *lambdas, size_t first);
 size_t lgc_solver_prefix_bytes(const lgc_solver *s);
@@ -177,7 +178,7 @@ typedef struct {
     uint32_t replicas, word_stride, reveal_stride;   /* sweep programs: circuit t uses words x + t * word_stride
                                                         (x >= shared_end) and decode slots r + t * reveal_stride */
     uint32_t shared_end, prefix_launches;            /* words [0, shared_end) and launches [0, prefix_launches) are */
-    uint64_t prefix_steps;                           /* the lambda-independent prefix (inputs, share sums) */
+    uint64_t prefix_steps;                           /* the lambda-independent prefix (inputs, share sums, normalizer) */
     uint64_t total_xors;                             /* XOR gates a flat gate list of this circuit would hold (word XORs x width): */
                                                      /* reporting only (bytes = 192 N_AND + 128 N_XOR)            */
     int gate_hash;                                   /* the gate hash the program was built for (lgc_set_gate_hash) */
@@ -229,7 +230,7 @@ size_t lgc_party_num_circuits(const lgc_party *p);
  * src/cmd/linreg.c:145-199 runs one execYaoProtocol per circuit): each device gets ONE party object holding the
  * contiguous block [first, first + count) of the sweep's circuits.  All garbler blocks share the seed -- one set
  * of input labels, one label OT per data provider -- and `first` keeps the gate ids of different blocks disjoint.
- * The prefix launches [0, lgc_party_prefix_launches) (share summation; lambda enters after it) are garbled /
+ * The prefix launches [0, lgc_party_prefix_launches) (share summation, normalizer; lambda enters after them) are garbled /
  * evaluated by the first block only; lgc_party_share_prefix copies the words they produce to another block of the
  * same role (another GPU: over xGMI), which then runs the launches from lgc_party_prefix_launches on. */
 int lgc_party_create_sweep_at(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],

@@ -425,7 +425,7 @@ struct lgc_solver {
     std::vector<hipEvent_t> ev_iter;     // end of each cgd iteration on the evaluator chain
     std::vector<double> t_iter;
     bool have_shares, ran;
-    bool prefix_ready;    // sweep: input labels and prefix tables are in place (garbled here or imported)
+    bool prefix_ready;    // sweep: the words of the shared region are in place for both roles (prefix run here, or imported)
     bool prefix_imported = false;
     lgc_stats st;
     lgc_solver() : wordsG(0), wordsE(0), tab(0), decG(0), decE(0), vals(0), recs(0), stream(0), streamE(0), streamT(0), ev0(0), ev1(0), ev_in(0), ring_bytes(0), tab_alloc_bytes(0),
@@ -641,7 +641,7 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
     size_t next_iter = 0;
     HIPCHK(hipEventRecord(s->ev0, sG));
     // sweep block whose shared prefix is already in place (lgc_solver_prefix_garble / _import): the words of
-    // the shared region and the prefix tables stay; only the evaluator runs the prefix launches
+    // the shared region stay, for both roles; the prefix launches are not run again
     const bool pre = s->prefix_ready && P.prefix_launches > 0;
     const size_t keep = pre ? (size_t)P.shared_end * 64 * sizeof(Lbl) : 0;
     HIPCHK(hipMemsetAsync(reinterpret_cast<char *>(s->wordsG) + keep, 0, wbytes - keep, sG));
@@ -690,12 +690,13 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
             HIPCHK(hipEventRecord(s->evG[i], s->streamT));
         }
         if (!profile) HIPCHK(hipStreamWaitEvent(sE, s->evG[i], 0));
+        const bool done_e = pre && i < P.prefix_launches;                     // evaluated with the prefix
         if (profile) {
-            HIPCHK(gc_launch<false>(s->recs, L, P.gate_hash, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
+            if (!done_e) HIPCHK(gc_launch<false>(s->recs, L, P.gate_hash, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
             HIPCHK(hipEventRecord(s->evs[3 * i + 2], sE));
         } else {
             if (L.mac_only) HIPCHK(hipEventRecord(s->evs[3 * i + 2], sE));   // start of the evaluate kernel
-            HIPCHK(gc_launch<false>(s->recs, L, P.gate_hash, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
+            if (!done_e) HIPCHK(gc_launch<false>(s->recs, L, P.gate_hash, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
             HIPCHK(hipEventRecord(s->evE[i], sE));
         }
         while (next_iter < P.iter_launch.size() && P.iter_launch[next_iter] == i)
@@ -746,16 +747,17 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
         s->t_iter[t] = e * 1e-3;
     }
     s->ran = true;
-    s->prefix_ready = false;      // the ring regions of the prefix tables have been reused since
+    s->prefix_ready = false;      // (one run per prefix: an importing rank holds no shares to make it again)
     return LGC_OK;
 }
 
 // ---- shared prefix of a sweep block (multi-GPU sweep: garbled on one rank, broadcast to the others)
 extern "C" size_t lgc_solver_prefix_bytes(const lgc_solver *s) {
     if (!s) return 0;
-    size_t b = 2 * (size_t)s->P.shared_end * 64 * sizeof(Lbl);
-    for (uint32_t i = 0; i < s->P.prefix_launches; i++) b += (size_t)s->P.launches[i].steps * 128 * sizeof(Lbl);
-    return b;
+    // both roles' words of the shared region AFTER the prefix has run: the prefix is garbled and evaluated once, on the rank
+    // that holds the shares, and nobody else needs its tables (rounds 2-5 shipped the tables and let every rank evaluate them:
+    // 116 MB for 64 lambdas of d = 100, and 726 MB once the division by the normalizer had joined the prefix; now 32 MB)
+    return 2 * (size_t)s->P.shared_end * 64 * sizeof(Lbl);
 }
 extern "C" int lgc_solver_prefix_garble(lgc_solver *s) {
     if (!s) return lgc_fail(LGC_EINVAL, "null solver");
@@ -772,6 +774,7 @@ extern "C" int lgc_solver_prefix_garble(lgc_solver *s) {
     for (uint32_t i = 0; i < P.prefix_launches; i++) {
         Lbl *tab = reinterpret_cast<Lbl *>(reinterpret_cast<char *>(s->tab) + s->tab_off[i]);
         HIPCHK(gc_launch<true>(s->recs, P.launches[i], P.gate_hash, s->wordsG, s->decG, tab, s->R, P.w, P.p, s->stream));
+        HIPCHK(gc_launch<false>(s->recs, P.launches[i], P.gate_hash, s->wordsE, s->decE, tab, s->R, P.w, P.p, s->stream));
     }
     HIPCHK(hipStreamSynchronize(s->stream));
     s->prefix_ready = true;
@@ -786,12 +789,6 @@ static int prefix_copy(lgc_solver *s, char *buf, bool out) {
     };
     HIPCHK(cp(s->wordsG, buf, sbytes));
     HIPCHK(cp(s->wordsE, buf + sbytes, sbytes));
-    size_t off = 2 * sbytes;
-    for (uint32_t i = 0; i < P.prefix_launches; i++) {
-        size_t n = (size_t)P.launches[i].steps * 128 * sizeof(Lbl);
-        if (n) HIPCHK(cp(reinterpret_cast<char *>(s->tab) + s->tab_off[i], buf + off, n));
-        off += n;
-    }
     HIPCHK(hipStreamSynchronize(s->stream));
     return LGC_OK;
 }

@@ -2,9 +2,10 @@
 
 A single solve is one dependent chain and stays on one GPU.  The circuits of a regularisation sweep
 differ only in lambda, a public constant added to the diagonal AFTER the data providers' shares are
-summed (reference src/linear.oc:52-57), so they share a prefix: the input wire labels and the
-garbled share-summation launches.  shared_prefix_sweep garbles that prefix ONCE, on rank 0,
-broadcasts it (RCCL over xGMI: input-label words + prefix tables), and every rank then garbles and
+summed (reference src/linear.oc:52-57), so they share a prefix: the input wire labels, the
+share-summation launches and the division by the public normalizer.  shared_prefix_sweep garbles and evaluates
+that prefix ONCE, on rank 0, broadcasts what it leaves (RCCL over xGMI: both roles' words of the shared region --
+no tables), and every rank then garbles and
 evaluates its contiguous block of lambdas as one merged program; an all_gather collects the d-word
 results.  One process per GPU (torch.distributed; backend "nccl" = RCCL on GPUs, "gloo" in the CPU
 tests and single-GPU dry runs).  lambda_sweep is the collective-free variant (independent circuits,
@@ -94,8 +95,8 @@ def gpu_block_solver_factory(d, width, precision, algorithm, num_iterations, nsh
 def shared_prefix_sweep(shares, lambdas, d, make_solver, dist=None, tensor_device="cpu", seed=None, stats=None):
     """One circuit per lambda with the lambda-independent prefix garbled once.
 
-    shares: (nshares, T + d) uint64, needed on rank 0 only (the other ranks receive the garbled
-    prefix, not the inputs).  make_solver(block_of_lambdas, first_index, seed16) returns an object with
+    shares: (nshares, T + d) uint64, needed on rank 0 only (the other ranks receive the words
+    the garbled and evaluated prefix left for both roles, not the inputs and not its tables).  make_solver(block_of_lambdas, first_index, seed16) returns an object with
     set_shares / prefix_bytes / prefix_garble / prefix_export(ptr) / prefix_import(ptr) / run / beta /
     close (linreg_gc.Solver).  Returns the (len(lambdas), d) int64 results on every rank.
     stats (dict, optional) receives this rank's wall-clock per phase: create_s (program + device memory, all ranks at

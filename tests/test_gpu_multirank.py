@@ -88,7 +88,7 @@ def test_bench_eight_ranks_rehearse_the_full_sweep_on_one_gpu(tmp_path, oracle):
     assert (sw["n_gpus"], sw["lambdas"], sw["d"], sw["iterations"]) == (8, 64, 100, 15)
     for k in ("seconds", "create_s", "prefix_garble_s", "broadcast_s", "block_s", "gather_s"):
         assert sw[k] >= 0.0, k
-    assert sw["prefix_bytes_broadcast"] > 100e6 and sw["block_s"] > 0 and sw["block_lambdas"] == 8
+    assert sw["prefix_bytes_broadcast"] > 10e6 and sw["block_s"] > 0 and sw["block_lambdas"] == 8
     # the N = 1 model's prediction for eight GPUs rides in the same line (profiles/sweep_model.json here: no N = 1 run
     # left a detail file in this directory), so the first real 8-GPU run shows measured / predicted
     assert sw["predicted_seconds"] > 0 and sw["measured_over_predicted"] == pytest.approx(sw["seconds"] / sw["predicted_seconds"], rel=1e-3)
