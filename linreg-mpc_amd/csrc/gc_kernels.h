@@ -73,7 +73,7 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
         // records (waves) per workgroup: as few as keep the launch within one workgroup per CU, at most TPB / 64 --
         // a launch of 800 dividers runs as 200 workgroups of 4 waves, one round, instead of 67 CUs with 12 waves each
         unsigned per = (L.nrec + gc_num_cus() - 1) / gc_num_cus();
-        if (per > (unsigned)kTpbWide / 64) per = kTpbWide / 64;
+        if (per > (unsigned)kTpbWide / 64) per = gc_wide_waves(L.nrec, kTpbWide / 64);
         if (!GC_WIDE_ADAPT) per = kTpbWide / 64;
         hipLaunchKernelGGL((gc_exec_kernel<G, false, HK == 1 ? 0 : 4, kTpbWide>), dim3((L.nrec + per - 1) / per), dim3(per * 64), 0, st,
                            recs + L.first_rec, L.nrec, words, tab, dec, L.step0, R, w, p);

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <vector>
 
 #include "gc_aes.h"
@@ -175,6 +176,26 @@ static inline unsigned gc_num_cus() {
 static inline unsigned gc_mack_waves(uint32_t nrec, unsigned lo, unsigned hi) {
     const uint64_t cus = gc_num_cus();
     if (((uint64_t)nrec + hi - 1) / hi > (uint64_t)GC_MACK_ADAPT_MAX_ROUNDS * cus || nrec <= cus * lo) return hi;
+    unsigned best = hi;
+    uint64_t best_cost = ~0ull;
+    for (unsigned wv = hi; wv >= lo; wv--) {
+        uint64_t wgs = (nrec + wv - 1) / wv, rounds = (wgs + cus - 1) / cus, cost = rounds * wv;
+        if (cost < best_cost) { best_cost = cost; best = wv; }
+    }
+    return best;
+}
+// ... and of a wide launch (one wave per generic record) of a few rounds.  Records of one launch are mostly of one length and
+// the workgroups are bound by the LDS lookups of their waves together, so a round of w-wave workgroups takes about w / hi of a
+// full one: 6 400 dividers (64 circuits x d = 100) are 3 rounds of 12 waves -- the third almost empty -- or 3 rounds of 9.
+// GC_WIDE_ADAPT_LO: the fewest waves tried (LGC_WIDE_LO in the environment overrides it for A/B runs; 12 = off).
+#ifndef GC_WIDE_ADAPT_LO
+#define GC_WIDE_ADAPT_LO 12
+#endif
+static inline unsigned gc_wide_waves(uint32_t nrec, unsigned hi) {
+    static const unsigned lo_env = [] { const char *e = getenv("LGC_WIDE_LO"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : (unsigned)GC_WIDE_ADAPT_LO; }();
+    const unsigned lo = lo_env < hi ? lo_env : hi;
+    const uint64_t cus = gc_num_cus();
+    if (((uint64_t)nrec + hi - 1) / hi > 12 * cus) return hi;
     unsigned best = hi;
     uint64_t best_cost = ~0ull;
     for (unsigned wv = hi; wv >= lo; wv--) {
