@@ -511,11 +511,17 @@ struct Circ {
     // restoring form needs an eighth for the remainder mux.  b == 0 is unspecified upstream
     // (fixed.oc:174-180); oracle and circuit define an all-ones magnitude (-1 for a >= 0, +1 for a < 0),
     // forced here by a zero detector on |b| (zcheck; not needed for a public non-zero divisor).
-    static GC_HD W div_mag(B &be, W ua, W ub, int w, int p, bool zcheck) {
+    // bounded: the caller guarantees |a| <= |b| (CGD's g_i / max_j |g_j|, cgd.oc:104-106, 153-155: the divisor IS the
+    // largest of the magnitudes, formed by this circuit with the same abs and an unsigned compare at w = 64).  The quotient
+    // is then at most 2^p, its bits above p are zero, and the first w - 1 steps of the recurrence -- which shift the top
+    // w - 1 bits of |a| into the remainder while it stays below |b| -- are replaced by that state: R = |a| >> 1 (< |b| for
+    // |b| >= 1), s = 0; p + 1 quotient bits instead of w + p.  |b| = 0 (then |a| = 0 too) is the zero detector's case as before.
+    static GC_HD W div_mag(B &be, W ua, W ub, int w, int p, bool zcheck, bool bounded = false) {
         const int M = w + p;
         const uint64_t act = lanes(w);
         W R = be.zero(), Q = be.zero(), s = be.zero();
-        for (int k = M - 1; k >= 0; k--) {
+        if (bounded) R = be.sel(act, be.shr(ua, 1), be.zero());
+        for (int k = bounded ? p : M - 1; k >= 0; k--) {
             W rtop = be.bcast(R, w - 1);
             W X = be.sel(act, be.shl(R, 1), be.zero());
             if (k >= p) X = be.XOR(X, be.sel(1ull, be.bcast(ua, k - p), be.zero()));
@@ -551,10 +557,10 @@ struct Circ {
         }
         return be.sel(1ull, be.NOTm(nz, 1ull), be.zero());
     }
-    static GC_HD W div(B &be, W a, W b, int w, int p) {
+    static GC_HD W div(B &be, W a, W b, int w, int p, bool bounded = false) {
         W sa = be.bcast(a, w - 1), sb = be.bcast(b, w - 1);
         W ua = condneg(be, a, sa, w), ub = condneg(be, b, sb, w);
-        W Q = div_mag(be, ua, ub, w, p, true);
+        W Q = div_mag(be, ua, ub, w, p, true, bounded);
         return condneg(be, Q, be.XOR(sa, sb), w);
     }
     // tdiv(a, c) for a public constant c > 0 (the normalizer of linear.oc:52-65), the long way: the divider above with a

@@ -42,6 +42,7 @@ enum Op : uint32_t {
                 // hdiff(x) of both operand vectors lie c words above the operands: (a + k*sa) + c, (b + k*sb) + c
     OP_HDIFF,   // dst = hdiff(a): |hi32(a) - lo32(a)| and its sign, for OP_MACK
     OP_EQ,      // dst = [a == b] in lane 0 (other lanes 0): the comparison of the two parties' dimensions, src/linear.oc:109-114
+    OP_DIVB,    // dst = div(a, b) where the program guarantees |a| <= |b| (w = 64 only): p + 1 quotient bits, Circ::div_mag
     OP_COUNT_
 };
 
@@ -166,6 +167,9 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
         if (r.c) be.store(r.c, v);
         if (r.cnt == 2) be.store(r.dst + (uint32_t)r.sa, C::hdiff(be, v));
     } break;
+    case OP_DIVB:
+        be.store(r.dst, C::div(be, be.load(r.a), be.load(r.b), w, p, true));
+        break;
     case OP_SQRT:
         be.store(r.dst, C::vsqrt(be, be.load(r.a), w, p));
         break;

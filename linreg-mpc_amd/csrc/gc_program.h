@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <utility>
 #include <vector>
@@ -459,6 +460,7 @@ struct Program {
             case OP_REVEAL: upd(r.a); break;
             case OP_IDIVC: case OP_COPY: case OP_ABS: case OP_SQRT: case OP_HDIFF: upd(r.dst); upd(r.a); break;
             case OP_MULSUB: upd(r.dst); upd(r.a); upd(r.b); upd(r.c); break;
+            case OP_DIVB: upd(r.dst); upd(r.a); upd(r.b); break;
             case OP_DIV: case OP_MUL: upd(r.dst); upd(r.a); upd(r.b); if (r.op == OP_DIV) upd(r.c); if (r.cnt == 2) upd((uint64_t)r.dst + (uint64_t)(uint32_t)r.sa); break;
             default: upd(r.dst); upd(r.a); upd(r.b); break;
             }
@@ -540,6 +542,11 @@ static inline size_t x_fact_waves() {     // records per column step of the fact
 // Karatsuba products in the matrix-vector launches of CGD (64-bit; Circ::mack2).  Process-wide switch for A/B runs
 // (lgc_set_karatsuba); garbler and evaluator must agree, as on everything else that shapes the program.
 inline int &program_karatsuba() { static int on = 1; return on; }
+// OP_DIVB for CGD's g / max|g| at w = 64 (LGC_BOUNDED_DIV=0 in the environment: the full divider, for A/B runs)
+inline int &program_bounded_div() {
+    static int on = [] { const char *e = getenv("LGC_BOUNDED_DIV"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }();
+    return on;
+}
 // Gate hash of the programs built from now on (lgc_set_gate_hash): process-wide, the two roles of a solve must agree.
 inline int &program_gate_hash() { static int kind = 0; return kind; }
 
@@ -660,7 +667,11 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.new_launch();
         for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_ABS, tabs + (uint32_t)i, g + (uint32_t)i));
         P.max_tree(ng, tabs, d, sc_max);
-        for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_DIV, pv + (uint32_t)i, g + (uint32_t)i, ng));
+        // g_i / max_j |g_j|: a quotient of at most 2^p.  At w = 64 the maximum is an UNSIGNED maximum of the very magnitudes
+        // the divider forms (Circ::vabs, Circ::gt), so |g_i| <= |ng| holds for every input and the divider may skip the
+        // quotient bits above p (OP_DIVB); at w = 32 the compare is signed (fixed.oc:78-88) and |INT_MIN| escapes it
+        const uint32_t op_divb = (w == 64 && program_bounded_div()) ? OP_DIVB : OP_DIV;
+        for (size_t i = 0; i < d; i++) P.emit(Program::mk(op_divb, pv + (uint32_t)i, g + (uint32_t)i, ng));
         P.new_launch();
         for (int it = 0; it < iters; it++) {
             // pA = A p  (cgd.oc:119-125)
@@ -690,7 +701,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
             for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_ABS, tabs + (uint32_t)i, g + (uint32_t)i));
             P.max_tree(ng, tabs, d, sc_max);         // :140,146-149
             for (size_t i = 0; i < d; i++)           // :153-155
-                P.emit(Program::mk(OP_DIV, gscl + (uint32_t)i, g + (uint32_t)i, ng));
+                P.emit(Program::mk(op_divb, gscl + (uint32_t)i, g + (uint32_t)i, ng));
             P.new_launch();
             P.inner(gAp, pA, gscl, d, sc_ip);        // :157
             P.emit(Program::mk(OP_DIV, gamma, gAp, q));  // :159

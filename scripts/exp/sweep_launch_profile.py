@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python"))
 import numpy as np
 import linreg_gc as lgc
-OPS = "NOP MAC SUM SUBSUM IPMAC IPFIN IPMERGE MUL MULSUB ADD SUB ABS MAX DIV SQRT IDIVC CONST COPY REVEAL MAC2 MACK HDIFF EQ".split()
+OPS = "NOP MAC SUM SUBSUM IPMAC IPFIN IPMERGE MUL MULSUB ADD SUB ABS MAX DIV SQRT IDIVC CONST COPY REVEAL MAC2 MACK HDIFF EQ DIVB".split()
 d, nl, it = 100, int(sys.argv[1]) if len(sys.argv) > 1 else 64, 15
 rng = np.random.default_rng(0)
 T = d * (d + 1) // 2

@@ -4,7 +4,7 @@ command line accepts (src/cmd/linreg.c:85-88), in both step orders the GPU kerne
 import numpy as np
 import pytest
 
-OP = dict(MUL=7, ADD=9, SUB=10, ABS=11, DIV=13, SQRT=14, IDIVC=15)
+OP = dict(MUL=7, ADD=9, SUB=10, ABS=11, DIV=13, SQRT=14, IDIVC=15, DIVB=23)
 
 
 def _operands(rng, w, n):
@@ -45,6 +45,40 @@ def test_div_matches_oracle(gccpu, oracle, w, paired):
             assert int(g) == exp, (w, p, hex(int(x)), hex(int(y)), hex(int(g)), hex(exp))
         # 7 dependent levels / 12 gate steps per quotient bit + three conditional negates + zero detector
         assert steps <= 12 * (w + p) + 3 * 12 + 8
+
+
+@pytest.mark.parametrize("p", [0, 1, 30, 56, 63])
+def test_bounded_division_is_the_division_when_the_dividend_is_no_larger(gccpu, oracle, p):
+    """OP_DIVB (CGD's g_i / max|g|, 64 bit): p + 1 quotient bits instead of 64 + p -- equal to tdiv(a << p, b), and to the
+    full divider, for every |a| <= |b|: random pairs, equal magnitudes of either sign, zero dividend, the divisor 1,
+    INT_MIN as divisor and as both, neighbours of the divisor, and 0 / 0 (the zero detector's all-ones magnitude)"""
+    w = 64
+    rng = np.random.default_rng(500 + p)
+    mask = (1 << w) - 1
+    top = 1 << 63
+    a, b = [], []
+    for _ in range(300):
+        y = int(rng.integers(1, 1 << 62)) >> int(rng.integers(0, 60))
+        y = max(y, 1)
+        x = int(rng.integers(0, y + 1))
+        for sx_ in (1, -1):
+            for sy in (1, -1):
+                a.append((sx_ * x) & mask); b.append((sy * y) & mask)
+    for y in (1, 2, 3, top - 1, top, 12345, (1 << 56) + 1):
+        for x in (0, 1, y - 1, y, y // 2, y // 2 + 1):
+            if 0 <= x <= y:
+                for sx_ in (1, -1):
+                    for sy in (1, -1):
+                        a.append((sx_ * x) & mask); b.append((sy * y) & mask)
+    a.append(0); b.append(0)
+    a = np.array(a, dtype=np.uint64); b = np.array(b, dtype=np.uint64)
+    got, steps = gccpu.plain_op(OP["DIVB"], w, p, a, b)
+    full, steps_full = gccpu.plain_op(OP["DIV"], w, p, a, b)
+    assert np.array_equal(got, full)
+    for x, y, g in zip(a[:400], b[:400], got[:400]):
+        exp = oracle.div(_signed(int(x), w), _signed(int(y), w), p, w) & mask
+        assert int(g) == exp, (p, hex(int(x)), hex(int(y)), hex(int(g)), hex(exp))
+    assert steps == steps_full - 7 * (w - 1)
 
 
 @pytest.mark.parametrize("w", [64, 32])
