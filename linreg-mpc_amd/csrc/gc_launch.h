@@ -139,14 +139,22 @@ inline std::atomic<int> &gc_split_enabled(bool garbler) {
 #ifndef GC_MAC_PERSIST_MAX_ROUNDS
 #define GC_MAC_PERSIST_MAX_ROUNDS 8
 #endif
+// Waves per workgroup of a plain MAC launch of a few rounds (gc_mac_waves).  Round 2 let it go down to 10 (garbler) / 8
+// (evaluator) waves: -5 % on a serialised d = 100 matrix-vector product, +10 % beside the evaluator chain, and it was switched
+// off.  With a floor of 12 waves it pays (end of round 5, scripts/exp/mac_adapt12_ab.sh, A B A B on one box): the 10 000
+// records of a d = 100 product run as three rounds of 14 waves instead of 16 + 16 + 7 -- d = 100 CGD-15 0.1335 -> 0.1277 s,
+// d = 40 0.062 -> 0.058, 32-bit d = 100 0.0575 -> 0.0528, Cholesky d = 100 0.328 -> 0.324; d = 64 / 120 / 180 / 200 / 250 and
+// the 32-bit d = 300 within +-1 %.  (The floor of 10 picks 10 waves x 4 rounds at d = 100 and is 6 % SLOWER: a round's time
+// stops falling with its waves below a dozen, and every round pays a table fill.)  Launches of more than eight rounds are
+// left alone; the Karatsuba launches have their own switch (GC_MACK_ADAPT, off: measured slower).
 #ifndef GC_MAC_ADAPT_LO_G
-#define GC_MAC_ADAPT_LO_G 10
+#define GC_MAC_ADAPT_LO_G 12
 #endif
 #ifndef GC_MAC_ADAPT_LO_E
-#define GC_MAC_ADAPT_LO_E 8
+#define GC_MAC_ADAPT_LO_E 12
 #endif
 #ifndef GC_MAC_ADAPT
-#define GC_MAC_ADAPT 0   /* measured: -5 % on a serialised d=100 matvec, +10 % when it overlaps the evaluator chain */
+#define GC_MAC_ADAPT 1
 #endif
 static inline unsigned gc_num_cus() {
     static int cus = 0;
