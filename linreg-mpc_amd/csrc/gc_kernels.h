@@ -59,11 +59,10 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
         // HK = 1: no table image limits the workgroups of a CU; kMackPadH1 bytes of unused dynamic LDS per workgroup do (see gc_launch.h)
         unsigned per = TPB / 64;
 #if GC_MACK_ADAPT
-        // One workgroup per CU, every record the same length: the launch runs in rounds of (CUs x waves) records, and a
-        // column step of a d = 500 factorisation is 4-5 rounds of which the last is half empty.  An LDS-bound workgroup of w
-        // waves takes about w / 16 of the time of a full one: with fewer waves per workgroup the SAME number of rounds
-        // costs less (17 857 records: 5 rounds of 14 waves instead of 5 of 16, 4.98 of them filled).  Only for launches of
-        // a few rounds (the matrix-vector products of CGD are 30 rounds and more), and HK = 0 only.
+        // One workgroup per CU, every record the same length: the launch runs in rounds of (CUs x waves) records.  An
+        // LDS-bound workgroup of w waves takes about w / 16 of the time of a full one: with fewer waves per workgroup the SAME
+        // number of rounds costs less (5 000 pairs: 2 rounds of 12 waves instead of 16 + 3.5).  Only for launches of at most
+        // GC_MACK_ADAPT_MAX_ROUNDS rounds (gc_launch.h has the measurements), and HK = 0 only.
         if (HK == 0) per = gc_mack_waves(L.nrec, G ? GC_MACK_ADAPT_LO_G : GC_MACK_ADAPT_LO_E, TPB / 64);
 #endif
         hipLaunchKernelGGL((gc_mack_kernel<G, TPB, HK>), dim3((L.nrec + per - 1) / per), dim3(per * 64), HK == 1 ? kMackPadH1 : 0, st,

@@ -168,17 +168,23 @@ static inline unsigned gc_num_cus() {
     }
     return (unsigned)cus;
 }
+// Round 5 tried this on launches of up to ten rounds with 12 (garbler) / 9 (evaluator) waves at least
+// (scripts/exp/mack_adapt_ab.sh): the serialised MAC time of a d = 500 factorisation fell and the overlapped run got slower
+// (11.7 -> 12.2 s) -- a column's MAC launch runs beside the other role's chain, and a partly filled round is CUs for that
+// chain.  On for launches of at most THREE rounds and the garbler only (the evaluator's workgroups are twelve waves already):
+// what is left are the matrix-vector products of small CGD systems, which their chain waits for (scripts/exp/kara_small_ab.sh:
+// d = 100 CGD-15 0.128 -> 0.122 s together with Karatsuba records at that size, d = 250 Cholesky 1.97 -> 1.96 s).
 #ifndef GC_MACK_ADAPT
-#define GC_MACK_ADAPT 0   /* experiment of round 5 (scripts/exp/mack_adapt_ab.sh) */
+#define GC_MACK_ADAPT 1
 #endif
 #ifndef GC_MACK_ADAPT_LO_G
 #define GC_MACK_ADAPT_LO_G 12
 #endif
 #ifndef GC_MACK_ADAPT_LO_E
-#define GC_MACK_ADAPT_LO_E 9
+#define GC_MACK_ADAPT_LO_E 12
 #endif
 #ifndef GC_MACK_ADAPT_MAX_ROUNDS
-#define GC_MACK_ADAPT_MAX_ROUNDS 10
+#define GC_MACK_ADAPT_MAX_ROUNDS 3
 #endif
 // waves per workgroup of a Karatsuba MAC launch of a few rounds: the count with the least rounds x waves
 static inline unsigned gc_mack_waves(uint32_t nrec, unsigned lo, unsigned hi) {

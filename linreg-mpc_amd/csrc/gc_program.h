@@ -524,7 +524,10 @@ struct Program {
 // themselves lose nothing (d = 500 CGD-15: 1.99 -> 1.81 s, d = 300: 0.78 -> 0.71 s; scripts/exp/shape_ab*.sh).  The price is
 // more partial sums to merge (+1 % gate steps at d = 500).  kTargetWaves still decides WHERE Karatsuba records are used
 // (batches of more than that many products), so programs of small systems are what they were.
-static const size_t kTargetWaves = 12288;
+// (End of round 5: 8 192 instead of 12 288 -- d = 91 ... 110 get Karatsuba records too -- now that a Karatsuba launch of up to
+// three rounds picks its waves per workgroup, gc_mack_waves: d = 100 CGD-15 0.128 -> 0.122 s, scripts/exp/kara_small_ab.sh;
+// with sixteen-wave workgroups the 5 000 pairs of d = 100 were rounds of 16 + 3.5 waves and 3 % SLOWER than 10 000 plain records.)
+static const size_t kTargetWaves = 8192;
 static const size_t kMvRecords64 = 131072;       // matrix-vector products of CGD, 64-bit (chunk floor: one Karatsuba pair)
 static const size_t kMvRecords32 = 65536;        // ... 32-bit (two-chunk OP_MAC2 records; 131 072 costs 5 % more steps)
 static const size_t kFactRecords = 65536;        // a column step of Cholesky / LDL^T (d = 500: 12.6 -> 12.0 s)
