@@ -341,7 +341,29 @@ def phase12_wall(*a, **kw):
         r = phase12_wall_once(*a, **kw)
         r["attempts"] = 2
         r["first_error"] = first
+        return r
+    # ... and sometimes the wipe outlasts the second above (seen once in a dozen bench runs of round 5: every party of
+    # config 2 waited 2.1 s, of config 1 5.1 s, between "hip runtime up" and its first kernel dispatch -- tens of GB freed by
+    # the legs before them).  That is the box, not the path: run the configuration again, once, and say so.
+    stall = _first_dispatch_stall(r)
+    if stall is not None and stall > 1.0:
+        first_wall = r.get("phase12_wall_s")
+        r = phase12_wall_once(*a, **kw)
+        r["attempts"] = 2
+        r["first_attempt"] = {"phase12_wall_s": first_wall, "first_dispatch_stall_s": stall,
+                              "why": "every party's first kernel dispatch waited for the driver (device memory of the previous leg being wiped)"}
     return r
+
+
+def _first_dispatch_stall(r):
+    """seconds between the CSP's 'hip runtime up' and its first kernel dispatch (LINREG_TRACE marks), None without marks"""
+    try:
+        marks = r["timeline"]["marks"]["p1"]
+        up = [t for t, m in marks if "hip runtime up" in m]
+        fd = [t for t, m in marks if "first dispatch done" in m]
+        return (fd[0] - up[0]) if up and fd else None
+    except (KeyError, TypeError, IndexError):
+        return None
 
 
 def phase12_wall_once(np, name, n, d, starts, alg, iters, extra, device_index, prec=56, source=None, exe_name="linreg", env_extra=None,
