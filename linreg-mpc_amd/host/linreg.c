@@ -655,6 +655,11 @@ int main(int argc, char **argv) {
 done:
     g_protocol_over = 1;
     TRACE("protocol done");
+    {   /* experiment (scripts/exp/provider_linger.sh): a data provider's exit -- its HIP runtime going away -- falls into the
+         * table phase of parties 1 and 2; LINREG_PROVIDER_LINGER_MS makes the providers wait that long before they leave */
+        const char *lg = getenv("LINREG_PROVIDER_LINGER_MS");
+        if (lg && party > 2 && atoi(lg) > 0) usleep((useconds_t)atoi(lg) * 1000u);
+    }
     for (int k = 1; k < n_devices; k++) if (blocks[k]) lgc_party_destroy(blocks[k]);
     if (party_obj) lgc_party_destroy(party_obj);           /* (wipes label material before its memory is released) */
     node_destroy(&self);
