@@ -25,7 +25,7 @@ enum Op : uint32_t {
     OP_IPFIN,   // dst = wrap((sum of cnt IpAcc at a+4k) >> p)
     OP_IPMERGE, // IpAcc at dst..dst+3 = sum of cnt IpAcc at a+4k
     OP_MUL,     // dst = mul(a, b); cnt = 2: also words[dst + sa] = hdiff(dst) (the record that makes a Karatsuba operand final forms its half differences)
-    OP_MULSUB,  // dst = words[c] - mul(a, b)
+    OP_MULSUB,  // dst = words[c] - mul(a, b); cnt = 2: also words[dst + sa] = |dst|; cnt = 3: words[dst + sa] = hdiff(dst)
     OP_ADD,     // dst = a + b
     OP_SUB,     // dst = a - b
     OP_ABS,     // dst = |a|
@@ -142,7 +142,12 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
         W X, Y;
         C::mul_xy(be, be.load(r.a), be.load(r.b), w, p, X, Y);
         W v = C::add(be, X, Y, w);
-        be.store(r.dst, C::sub(be, be.load(r.c), v, w));
+        v = C::sub(be, be.load(r.c), v, w);
+        be.store(r.dst, v);
+        // (end of round 5: what the next launch would have formed from this word alone, in the record that makes it -- one
+        // dependent launch less per CGD iteration each: |g_i| for the maximum, hdiff(p_i) for the Karatsuba products)
+        if (r.cnt == 2) be.store(r.dst + (uint32_t)r.sa, C::vabs(be, v, w));
+        else if (r.cnt == 3) be.store(r.dst + (uint32_t)r.sa, C::hdiff(be, v));
     } break;
     case OP_ADD:
         be.store(r.dst, C::add(be, be.load(r.a), be.load(r.b), w));

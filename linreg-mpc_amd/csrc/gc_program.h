@@ -188,7 +188,13 @@ struct Program {
             buf += (uint32_t)groups;
             cnt = groups;
         }
-        // last level also folds in the initial ng = 0 (cgd.oc:98-101,140)
+        // the initial ng = 0 (cgd.oc:98-101,140): at w = 64 the compare is unsigned (obig_cmp) and max(x, 0) is x -- nothing
+        // to fold in; at w = 32 it is signed and a magnitude of INT_MIN loses against the zero: one more record
+        if (w == 64) {
+            emit(mk(OP_MAX, dst, cur, 0, 0, (uint32_t)cnt));
+            new_launch();
+            return;
+        }
         uint32_t tmp = buf;
         emit(mk(OP_MAX, tmp, cur, 0, 0, (uint32_t)cnt));
         new_launch();
@@ -459,7 +465,7 @@ struct Program {
             case OP_CONST: upd(r.dst); break;
             case OP_REVEAL: upd(r.a); break;
             case OP_IDIVC: case OP_COPY: case OP_ABS: case OP_SQRT: case OP_HDIFF: upd(r.dst); upd(r.a); break;
-            case OP_MULSUB: upd(r.dst); upd(r.a); upd(r.b); upd(r.c); break;
+            case OP_MULSUB: upd(r.dst); upd(r.a); upd(r.b); upd(r.c); if (r.cnt >= 2) upd((uint64_t)r.dst + (uint64_t)(uint32_t)r.sa); break;
             case OP_DIVB: upd(r.dst); upd(r.a); upd(r.b); break;
             case OP_DIV: case OP_MUL: upd(r.dst); upd(r.a); upd(r.b); if (r.op == OP_DIV) upd(r.c); if (r.cnt == 2) upd((uint64_t)r.dst + (uint64_t)(uint32_t)r.sa); break;
             default: upd(r.dst); upd(r.a); upd(r.b); break;
@@ -678,7 +684,7 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         P.new_launch();
         for (int it = 0; it < iters; it++) {
             // pA = A p  (cgd.oc:119-125)
-            if (kdelta) {
+            if (kdelta && it == 0) {                 // (later iterations: the record that makes p_i forms hdiff(p_i), below)
                 for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_HDIFF, pv + (uint32_t)i + kdelta, pv + (uint32_t)i));
                 P.new_launch();
             }
@@ -698,11 +704,10 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
             P.new_launch();
             for (size_t i = 0; i < d; i++) {         // :141-145
                 P.emit(Program::mk(OP_MULSUB, x + (uint32_t)i, pv + (uint32_t)i, eta, x + (uint32_t)i));
-                P.emit(Program::mk(OP_MULSUB, g + (uint32_t)i, eta, pA + (uint32_t)i, g + (uint32_t)i));
+                // ... and |g_i| with it (cnt = 2): the maximum below starts from these
+                P.emit(Program::mk(OP_MULSUB, g + (uint32_t)i, eta, pA + (uint32_t)i, g + (uint32_t)i, 2, (int32_t)(tabs - g)));
             }
-            P.new_launch();
-            for (size_t i = 0; i < d; i++) P.emit(Program::mk(OP_ABS, tabs + (uint32_t)i, g + (uint32_t)i));
-            P.max_tree(ng, tabs, d, sc_max);         // :140,146-149
+            P.max_tree(ng, tabs, d, sc_max);         // :140,146-149  (opens a launch of its own)
             for (size_t i = 0; i < d; i++)           // :153-155
                 P.emit(Program::mk(op_divb, gscl + (uint32_t)i, g + (uint32_t)i, ng));
             P.new_launch();
@@ -710,7 +715,8 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
             P.emit(Program::mk(OP_DIV, gamma, gAp, q));  // :159
             P.new_launch();
             for (size_t i = 0; i < d; i++)           // :162-165
-                P.emit(Program::mk(OP_MULSUB, pv + (uint32_t)i, pv + (uint32_t)i, gamma, gscl + (uint32_t)i));
+                P.emit(Program::mk(OP_MULSUB, pv + (uint32_t)i, pv + (uint32_t)i, gamma, gscl + (uint32_t)i, kdelta ? 3u : 1u,
+                                   kdelta ? (int32_t)kdelta : 1));
             P.new_launch();
             if (trace) {                             // reveals at :167-189
                 uint32_t base = P.rv_trace + (uint32_t)((size_t)it * (d + 4));
