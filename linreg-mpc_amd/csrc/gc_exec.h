@@ -10,6 +10,7 @@
 // Words live in a "word file": word id -> 64 labels (1 KiB, lane-major), so a
 // wave loads/stores a word as one coalesced 1 KiB access (global_load_dwordx4).
 #pragma once
+#include <assert.h>
 #include <stdint.h>
 
 #include "gc_circuits.h"
@@ -55,7 +56,9 @@ struct Rec {
 
 // the record dst = tdiv(a, c) for a public c > 0 with the constants of Circ::divc: m = floor(2^(w-1+l) / c) + 1,
 // l = ceil(log2 c) (host side: a 128-bit division)
+// c >= 1: the only caller divides by the system's dimension (check_system rejects d < 1); c = 0 has no meaning here
 inline Rec idivc_rec(uint32_t dst, uint32_t a, uint32_t c, int w) {
+    assert(c >= 1);
     int l = 0;
     while (l < 32 && (1ull << l) < (uint64_t)c) l++;
     const uint64_t m = c > 1 ? (uint64_t)((((unsigned __int128)1) << (w - 1 + l)) / c) + 1 : 0;

@@ -465,9 +465,9 @@ struct Program {
             case OP_CONST: upd(r.dst); break;
             case OP_REVEAL: upd(r.a); break;
             case OP_IDIVC: case OP_COPY: case OP_ABS: case OP_SQRT: case OP_HDIFF: upd(r.dst); upd(r.a); break;
-            case OP_MULSUB: upd(r.dst); upd(r.a); upd(r.b); upd(r.c); if (r.cnt >= 2) upd((uint64_t)r.dst + (uint64_t)(uint32_t)r.sa); break;
+            case OP_MULSUB: upd(r.dst); upd(r.a); upd(r.b); upd(r.c); if (r.cnt >= 2) upd((uint32_t)(r.dst + (uint32_t)r.sa)); break;   // the second store's offset wraps in 32 bits, as in exec_record
             case OP_DIVB: upd(r.dst); upd(r.a); upd(r.b); break;
-            case OP_DIV: case OP_MUL: upd(r.dst); upd(r.a); upd(r.b); if (r.op == OP_DIV) upd(r.c); if (r.cnt == 2) upd((uint64_t)r.dst + (uint64_t)(uint32_t)r.sa); break;
+            case OP_DIV: case OP_MUL: upd(r.dst); upd(r.a); upd(r.b); if (r.op == OP_DIV) upd(r.c); if (r.cnt == 2) upd((uint32_t)(r.dst + (uint32_t)r.sa)); break;
             default: upd(r.dst); upd(r.a); upd(r.b); break;
             }
             if (hi >= n_words) return false;

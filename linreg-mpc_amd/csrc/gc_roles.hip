@@ -63,7 +63,7 @@ struct lgc_party {
     size_t stash2_bytes;
     uint64_t n_crit;       // critical-path launches begun so far (stash = n_crit & 1)
     int64_t stash_user[2]; // the launch whose table pass read stash k last (-1: none)
-    int64_t begun_hi;      // highest launch begun asynchronously (-1: none)
+    std::atomic<int64_t> begun_hi;   // highest launch begun asynchronously (-1: none); written by the enqueuing thread, read by the host's notifier thread
 };
 
 // (m0, m1) = (zero label, zero label ^ R) per input bit of one share: yaoKeyNewPair (input.c:94-101)
@@ -610,31 +610,37 @@ extern "C" int lgc_party_garble_ring_begin(lgc_party *p, size_t launch) {
     if (launch >= (size_t)kPartyEvents) RCHK(hipEventSynchronize(p->ev_done[slot]));
     const Launch &L = p->P.launches[launch];
     Lbl *tab = ring_slot(p, launch);
-    bool crit = false;
     const int k = (int)(p->n_crit & 1);
     Lbl *stash = (k && p->stash2) ? p->stash2 : p->tab;
-    // (stage 0: nothing is launched, only the launch's mode is reported)
-    RCHK(gc_launch<true>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab, p->R, p->P.w, p->P.p, 0, stash, 0, &crit));
+    // the launch's mode is decided ONCE (it reads a run-time switch): record kernel and table pass cannot disagree
+    const LaunchMode m = gc_launch_mode(L, true, p->P.gate_hash);
+    const bool crit = gc_mode_is_crit(m, L);
     if (!crit) {
-        RCHK(gc_launch<true>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab, p->R, p->P.w, p->P.p, 0, (Lbl *)0, 3, (bool *)0));
+        RCHK(gc_launch_records<true>(m, p->P.gate_hash, p->recs, L, p->words, p->dec, tab, p->R, p->P.w, p->P.p, 0));
         RCHK(hipEventRecord(p->ev_done[slot], 0));
     } else {
         // this stash was last read by the table pass of an earlier launch: the record kernel must not overwrite it before
         if (p->stash_user[k] >= 0) RCHK(hipStreamWaitEvent(0, p->ev_done[p->stash_user[k] % kPartyEvents], 0));
-        RCHK(gc_launch<true>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab, p->R, p->P.w, p->P.p, 0, stash, 1, (bool *)0));
+        RCHK(gc_launch_records<true>(m, p->P.gate_hash, p->recs, L, p->words, p->dec, stash, p->R, p->P.w, p->P.p, 0));
         RCHK(hipEventRecord(p->ev_rec[slot], 0));
         RCHK(hipStreamWaitEvent(p->s_pass, p->ev_rec[slot], 0));
-        RCHK(gc_launch<true>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab, p->R, p->P.w, p->P.p, p->s_pass, stash, 2, (bool *)0));
+        RCHK(gc_launch_tabfill(L, stash, tab, p->R, p->s_pass));
         RCHK(hipEventRecord(p->ev_done[slot], p->s_pass));
         p->stash_user[k] = (int64_t)launch;
         p->n_crit++;
     }
-    if ((int64_t)launch > p->begun_hi) p->begun_hi = (int64_t)launch;
+    if ((int64_t)launch > p->begun_hi.load(std::memory_order_relaxed)) p->begun_hi.store((int64_t)launch, std::memory_order_release);
     return LGC_OK;
 }
 extern "C" int lgc_party_garble_ring_wait(lgc_party *p, size_t launch) {
     if (!p || !p->async_ready) return lgc_fail(LGC_ESTATE, "nothing was begun (lgc_party_garble_ring_begin)");
-    if ((int64_t)launch > p->begun_hi || (int64_t)launch + kPartyEvents <= p->begun_hi) return lgc_fail(LGC_EINVAL, "launch %zu is not in flight", launch);
+    const int64_t hi = p->begun_hi.load(std::memory_order_acquire);
+    if ((int64_t)launch > hi) return lgc_fail(LGC_EINVAL, "launch %zu has not been begun", launch);
+    // Its event slot has been handed to launch + kPartyEvents already: _begin synchronised on this launch's completion event
+    // before it reused the slot, so the launch is complete.  (The enqueuing thread is throttled by the GPU, not by the
+    // thread that waits: after a long launch the short ones behind it complete back to back and a waiter that is a
+    // few microseconds late finds its slot reused.  ADVICE r5.)
+    if ((int64_t)launch + kPartyEvents <= hi) return LGC_OK;
     // (no hipSetDevice: called from the notifier thread of the host while the main thread enqueues; events carry their device)
     RCHK(hipEventSynchronize(p->ev_done[launch % kPartyEvents]));      // kernel end = release: the tables are visible to the peer process
     return LGC_OK;
