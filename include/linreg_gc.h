@@ -22,6 +22,13 @@
  *   lgc_ot_*                honest[Correlated]OTExt{Send,Recv}1Of2 (IKNP) as used at
  *                           src/phase1.c:58-65,84-89 and src/input.c:44,108
  *
+ * INTEGRATION.md names the reference call behind every one of the 70 entry points of this header.  Two more headers
+ * complete the library's exports and are NOT part of the drop-in surface:
+ *   linreg_gc_sweep.h   the per-lambda sweep (BASELINE config 5): one program for many regularisation
+ *                       values, its shared prefix, the blocks of a sweep sharded over several GPUs
+ *   linreg_gc_debug.h   tracing, introspection of the lowered program, start-up and tuning hints, test hooks,
+ *                       micro-benchmarks
+ *
  * The library fails loudly (LGC_ENODEVICE) when no HIP device is present:
  * there is no CPU fallback.
  */
@@ -52,24 +59,6 @@ extern "C" {
 
 const char *lgc_last_error(void);
 int lgc_device_count(void);
-/* version / build string */
-const char *lgc_version(void);
-/* LINREG_TRACE=1 in the environment: wall-clock marks on stderr, one line each, "LGCT <tag> <CLOCK_MONOTONIC seconds> <what>"
- * -- the library marks its own start-up steps (HIP runtime, device context, program lowered, buffers, table ring), a host
- * adds its protocol steps with the same call, and since the clock is system-wide the marks of all parties of a run line up
- * (bench.py: `phase12[].timeline`).  Replaces nothing in the reference; it is how the start-up of src/cmd/linreg.c:100-199
- * is broken down here.  Without the variable both calls do nothing. */
-void lgc_trace_set_tag(const char *tag);
-void lgc_trace_mark(const char *what);
-/* Brings the HIP runtime and the context of `device` up and issues a first dispatch (60-250 ms when several parties start
- * together, 20-50 ms for the first dispatch); all of it is process-wide, so a host may call this from a thread while it
- * parses its input and connects (bin/linreg does). */
-int lgc_device_warm(int device);
-/* Loads code objects and creates streams ahead of their first use (a code object is otherwise loaded inside the first launch of
- * one of its kernels, 5-10 ms; a stream costs ~10 ms): what & 1 the phase-1 kernels, what & 2 the OT kernels, what & 4 two
- * streams for the pool the OT sessions draw from.  lgc_party_create* preloads the record kernels of its program by itself. */
-int lgc_preload(int device, int what);
-
 /* ------------------------------------------------------------------ phase 2 */
 
 /* counterpart of linear_system_t (src/linear.h:16-26) */
@@ -116,97 +105,16 @@ int lgc_solver_set_shares(lgc_solver *s, const uint64_t *shares);
  * profile != 0 brackets every kernel with HIP events (slower; fills the per-kernel times). */
 int lgc_solver_run(lgc_solver *s, int profile);
 
-/* Per-lambda sweep (BASELINE config 5): `count` circuits that differ only in the public
- * regularisation constant added to the diagonal (src/linear.oc:52-57), garbled and evaluated as one
- * program.  lambda enters AFTER the shares are summed, so the input labels, the garbled
- * share-summation launches and the division by the public normalizer (off the diagonal and in b:
- * linear.oc:57-65) -- the shared prefix -- exist once for the whole sweep (a data provider
- * runs one label OT whatever the number of lambdas); the launches of all circuits are merged, so the
- * latency-bound stages (dividers, reveals) of different circuits fill the GPU together.
- * sys->lambda is ignored; sys->normalize must be 1, trace and reveal_inputs 0.  All circuits read
- * the shares given to lgc_solver_set_shares; lgc_solver_get_beta returns count x d words
- * (circuit-major). */
-int lgc_solver_create_sweep(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16],
-                            size_t count, const double *lambdas);
-size_t lgc_solver_num_circuits(const lgc_solver *s);
-/* One rank's block of a sweep sharded over several GPUs: circuits
- * [first, first + count) of the whole sweep.  All ranks use the SAME seed: they share the prefix, hence
- * the garbler's offset R, and `first` keeps the gate ids of different ranks' circuits disjoint.
- *   rank 0:     lgc_solver_set_shares; lgc_solver_prefix_garble        (input labels; the prefix garbled AND evaluated)
- *               lgc_solver_prefix_export(dev_buf)                      -> broadcast (RCCL over xGMI)
- *   every rank: lgc_solver_prefix_import(dev_buf); lgc_solver_run      (garbles + evaluates its own circuits on the
- *               words the prefix left; the prefix launches are not run again -- rounds 2-5 shipped their tables too)
- * dev_buf: device memory of lgc_solver_prefix_bytes() bytes on the solver's GPU, owned by the caller
- * (e.g. a torch tensor handed to torch.distributed.broadcast).  Layout: garbler words of the shared
- * region | evaluator words of the shared region, both as the prefix leaves them. */
-int lgc_solver_create_sweep_at(lgc_solver **out, int device, const lgc_system *sys, const uint8_t seed[16],
-                               size_t count, const double *lambdas, size_t first);
-size_t lgc_solver_prefix_bytes(const lgc_solver *s);
-int lgc_solver_prefix_garble(lgc_solver *s);
-int lgc_solver_prefix_export(lgc_solver *s, void *dev_buf);
-int lgc_solver_prefix_import(lgc_solver *s, const void *dev_buf);
-
 /* Results (sign-extended to int64 when width == 32).  beta: d (sweep: count x d).
  * trace: num_iterations x (d + 4) (x, gamma, eta, q, ng), inputs: T + d. */
 int lgc_solver_get_beta(lgc_solver *s, int64_t *beta);
 int lgc_solver_get_trace(lgc_solver *s, int64_t *trace);
 int lgc_solver_get_inputs(lgc_solver *s, int64_t *ab);
 int lgc_solver_get_stats(lgc_solver *s, lgc_stats *st);
-/* per-launch kernel times of the last profiled run (seconds; n = number of launches) */
-int lgc_solver_get_profile(lgc_solver *s, double *garble_s, double *eval_s, size_t n);
 /* cgd only, n = num_iterations: AND gates emitted and device seconds elapsed (since the start of
  * lgc_solver_run) when iteration t's reveals were evaluated -- the values cgd.oc:190-194 prints as
  * "Iteration t gate count" / "Iteration t time".  Either output pointer may be NULL. */
 int lgc_solver_get_iterations(lgc_solver *s, uint64_t *and_gates, double *seconds, size_t n);
-
-/* Introspection (host only, no GPU needed): the lowered program.  Used by the
- * CPU test-suite to run the very same records on the CPU checker. */
-typedef struct {
-    uint32_t op, cnt, dst, a, b, c;
-    int32_t sa, sb;
-    uint64_t step0;
-} lgc_record;
-typedef struct {
-    uint32_t first_rec, nrec;
-    uint64_t step0, steps, gates;
-    int mac_only;
-} lgc_launch;
-typedef struct {
-    size_t n_records, n_launches;
-    uint32_t n_words, n_reveal, in_base, rv_beta, rv_trace, rv_inputs;
-    uint64_t total_steps, total_gates, max_launch_steps;
-    uint32_t replicas, word_stride, reveal_stride;   /* sweep programs: circuit t uses words x + t * word_stride
-                                                        (x >= shared_end) and decode slots r + t * reveal_stride */
-    uint32_t shared_end, prefix_launches;            /* words [0, shared_end) and launches [0, prefix_launches) are */
-    uint64_t prefix_steps;                           /* the lambda-independent prefix (inputs, share sums, normalizer) */
-    uint64_t total_xors;                             /* XOR gates a flat gate list of this circuit would hold (word XORs x width): */
-                                                     /* reporting only (bytes = 192 N_AND + 128 N_XOR)            */
-    int gate_hash;                                   /* the gate hash the program was built for (lgc_set_gate_hash) */
-} lgc_program_info;
-typedef struct lgc_program lgc_program;
-int lgc_program_build(lgc_program **out, const lgc_system *sys);
-int lgc_program_build_sweep(lgc_program **out, const lgc_system *sys, size_t count, const double *lambdas);
-/* the block [first, first + count) of a larger sweep (gate ids offset by `first` circuits) */
-int lgc_program_build_sweep_at(lgc_program **out, const lgc_system *sys, size_t count, const double *lambdas, size_t first);
-void lgc_program_destroy(lgc_program *p);
-int lgc_program_info_get(const lgc_program *p, lgc_program_info *info);
-const lgc_record *lgc_program_records(const lgc_program *p);
-const lgc_launch *lgc_program_launches(const lgc_program *p);
-/* The co-located solver's garbled-table ring for this program: launch i owns bytes
- * [offsets[i], offsets[i] + 2048 * steps_i) (rounded up to 4 KiB) of a ring of *ring_bytes_out; the
- * garbler may overwrite that range once launch wait_for[i] (-1: nobody) has been evaluated.
- * ring_bytes = 0 asks for the solver's own choice (twice the largest launch).  Arrays: n_launches. */
-int lgc_program_ring_plan(const lgc_program *p, size_t ring_bytes, size_t *ring_bytes_out, size_t *offsets, int64_t *wait_for);
-
-/* The gate count the REFERENCE's own circuit has for this solve (two-party input path; exact fits to every
- * result file under experiments/results/phase2_32 and phase2_64) -- this build's circuits are smaller, so results files and
- * rates carry both counts (bin/test_linear_system prints it, python/results.py writes it as an extra column).
- * cgd: the cumulative count after `iterations` iterations.  LGC_EINVAL for ldlt (nothing published).  Host only. */
-int lgc_reference_gate_count(int algorithm, int width, size_t d, int iterations, uint64_t *gates);
-
-/* One-shot convenience: create + set + run + get + destroy. */
-int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[16], const uint64_t *shares,
-              int64_t *beta, int64_t *trace, lgc_stats *stats);
 
 /* ----------------------------------------- phase 2 with the two roles apart */
 /* CSP (party 1, garbler) and Evaluator (party 2) as separate objects, possibly in different
@@ -219,25 +127,6 @@ int lgc_solve(int device, const lgc_system *sys, const uint8_t seed[16], const u
 typedef struct lgc_party lgc_party;
 int lgc_party_create(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
                      size_t max_launch_table_bytes);
-/* The per-lambda sweep with the roles apart (see lgc_solver_create_sweep): ONE set of input labels and
- * one garbled share summation for all `count` circuits, so every data provider runs its label OT
- * (lgc_ot_labels_*, src/input.c:37-50) once whatever the number of lambdas; lgc_party_finish then
- * returns count x d words of beta (circuit-major).  Both sides pass the same count and lambdas. */
-int lgc_party_create_sweep(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
-                           size_t max_launch_table_bytes, size_t count, const double *lambdas);
-size_t lgc_party_num_circuits(const lgc_party *p);
-/* The sweep on several GPUs of one CSP / Evaluator process (bin/linreg --lambdas --devices=...; SURVEY.md 8(e),
- * src/cmd/linreg.c:145-199 runs one execYaoProtocol per circuit): each device gets ONE party object holding the
- * contiguous block [first, first + count) of the sweep's circuits.  All garbler blocks share the seed -- one set
- * of input labels, one label OT per data provider -- and `first` keeps the gate ids of different blocks disjoint.
- * The prefix launches [0, lgc_party_prefix_launches) (share summation, normalizer; lambda enters after them) are garbled /
- * evaluated by the first block only; lgc_party_share_prefix copies the words they produce to another block of the
- * same role (another GPU: over xGMI), which then runs the launches from lgc_party_prefix_launches on. */
-int lgc_party_create_sweep_at(lgc_party **out, int device, const lgc_system *sys, int role, const uint8_t seed[16],
-                              size_t max_launch_table_bytes, size_t count, const double *lambdas, size_t first);
-size_t lgc_party_prefix_launches(const lgc_party *p);
-uint64_t lgc_party_prefix_and_gates(const lgc_party *p);
-int lgc_party_share_prefix(lgc_party *dst, const lgc_party *src);
 void lgc_party_destroy(lgc_party *p);
 size_t lgc_party_num_launches(const lgc_party *p);
 size_t lgc_party_table_bytes(const lgc_party *p, size_t launch);
@@ -245,8 +134,8 @@ size_t lgc_party_input_bits(const lgc_party *p);      /* (T + d) * width, per sh
 size_t lgc_party_num_reveal(const lgc_party *p);
 uint64_t lgc_party_and_gates(const lgc_party *p);
 /* 32 bytes over everything the two roles of a solve must have in common (records incl. lambda and gate-step numbers, launch
- * boundaries, width, precision, gate hash).  The host binaries exchange and compare it before the first table moves, so that
- * an option given to one party only (--gate_hash, --lambdas, --prec_phase2 ...) is an error message instead of a wrong
+ * boundaries, width, precision).  The host binaries exchange and compare it before the first table moves, so that
+ * an option given to one party only (--lambdas, --prec_phase2 ...) is an error message instead of a wrong
  * result.  A check against misconfiguration, not an authentication of the peer. */
 int lgc_party_program_fingerprint(const lgc_party *p, uint8_t out[32]);
 /* cgd only, n = num_iterations: the launch that completes iteration t and the AND gates emitted up
@@ -258,28 +147,19 @@ int lgc_party_input_pairs(lgc_party *p, size_t share, uint8_t *m0, uint8_t *m1);
 /* garbler: labels of values it knows itself (feedOblivLLong for its own party, linear.oc:116-127) */
 int lgc_party_encode_inputs(lgc_party *p, size_t share, const uint64_t *values, uint8_t *labels_out);
 
-/* Device-resident table hand-off for a garbler and an evaluator PROCESS on the same node (same
- * MI355X, or two GPUs of one xGMI hive): instead of the osend/orecv byte stream that carries
- * the garbled tables in the reference (Obliv-C Yao runtime under execYaoProtocol, linreg.c:177)
- * the garbler allocates a ring of `nslots` table slots in its HBM, exports it as a 64-byte
- * hipIpc handle (sent over the existing socket), and the evaluator maps it.  Launch k lives in
- * slot k % nslots.  The host keeps the ordering: the garbler may call lgc_party_garble_ring(k)
- * only after the evaluator has finished launch k - nslots; the evaluator may call
- * lgc_party_evaluate_ring(k) only after lgc_party_garble_ring(k) has returned.  Both calls block
- * until their kernel has completed.
- * What the ring ever holds is what the socket would carry: garbled tables (and zeros).  The garbler's
- * intermediate state of critical-path launches -- zero-labels, from which R follows -- stays in a buffer
- * private to its process (src/input.c:94-108: label pairs never leave the CSP); a failed call leaves the
- * slot with its previous contents. */
-int lgc_party_ring_create(lgc_party *p, int nslots, uint8_t handle_out[64], size_t *slot_bytes);
-int lgc_party_ring_open(lgc_party *p, const uint8_t handle[64], int nslots, size_t slot_bytes);
-/* The same hand-off through a BYTE ring (bin/linreg --table_ring; the default since round 4): `ring_bytes` of HBM (0 = the
- * library's choice: the largest launch plus half as much again, the extra between 64 MiB and 4 GiB) in which launch k owns a
- * contiguous range, laid out identically in both processes (lgc_program_ring_plan: same program, same size, same offsets).
- * Before lgc_party_garble_ring(k) the garbler's host waits until the evaluator has finished launch
- * lgc_party_ring_wait_for(p, k) (-1: nothing to wait for) -- the newest earlier launch whose range launch k overwrites.
- * A slot ring of 4 x the largest launch was 10.5 GB at d = 100 (config 3) and 33 GB for config 4; fresh device memory costs
- * tens of ms per GB to allocate, map in the peer and release, which made it the largest start-up item of those runs. */
+/* Device-resident table hand-off for a garbler and an evaluator PROCESS on the same node (same MI355X, or two GPUs of one
+ * xGMI hive; bin/linreg --table_ring): instead of the osend/orecv byte stream that carries the garbled tables in the
+ * reference (Obliv-C Yao runtime under execYaoProtocol, linreg.c:177) the garbler allocates a BYTE ring in its HBM --
+ * `ring_bytes` (0 = the library's choice: the largest launch plus half as much again, the extra between 64 MiB and 4 GiB) in
+ * which launch k owns a contiguous range, laid out identically in both processes (same program, same size, same offsets) --,
+ * exports it as a 64-byte hipIpc handle (sent over the existing socket), and the evaluator maps it.  The host keeps the
+ * ordering: before lgc_party_garble_ring(k) the garbler's host waits until the evaluator has finished launch
+ * lgc_party_ring_wait_for(p, k) (-1: nothing to wait for) -- the newest earlier launch whose range launch k overwrites; the
+ * evaluator may call lgc_party_evaluate_ring(k) only after lgc_party_garble_ring(k) has returned (or _wait(k), below).  Both
+ * calls block until their kernel has completed.
+ * What the ring ever holds is what the socket would carry: garbled tables (and zeros).  The garbler's intermediate state of
+ * critical-path launches -- zero-labels, from which R follows -- stays in a buffer private to its process (src/input.c:94-108:
+ * label pairs never leave the CSP); a failed call leaves the range with its previous contents. */
 int lgc_party_ring_create_bytes(lgc_party *p, size_t ring_bytes, uint8_t handle_out[64], size_t *ring_bytes_out);
 int lgc_party_ring_open_bytes(lgc_party *p, const uint8_t handle[64], size_t ring_bytes);
 int64_t lgc_party_ring_wait_for(const lgc_party *p, size_t launch);
@@ -295,11 +175,6 @@ int lgc_party_evaluate_ring(lgc_party *p, size_t launch);
  * second thread while the first goes on enqueueing (host/tables.c does).  What the ring ever holds is unchanged. */
 int lgc_party_garble_ring_begin(lgc_party *p, size_t launch);
 int lgc_party_garble_ring_wait(lgc_party *p, size_t launch);
-/* streams = 1: table passes stay on the record kernels' stream (no second queue to create, no second stash): all that is
- * left of the asynchronous path is that the garbler's stream does not wait for the host between launches -- the form for
- * short programs, where creating a queue costs more than overlapping the passes gains.  2 (default): as above.  Before the
- * first _begin. */
-int lgc_party_garble_ring_streams(lgc_party *p, int streams);
 /* evaluator: the labels a data provider forwarded (dcsSendIntArray -> orecv, input.c:46, 84-92) */
 int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint8_t *labels);
 /* The same two hand-overs with the labels left in HBM (bin/linreg --input_ring: all parties on one node).  The garbler exports a
@@ -408,66 +283,6 @@ int lgc_ot_labels_recv_finish(lgc_ot_receiver *r, const uint8_t *e_in, uint8_t *
  * Returns NULL (and sets lgc_last_error) on failure. */
 void *lgc_host_alloc(size_t bytes);
 void lgc_host_free(void *p);
-/* A destroyed lgc_solver leaves its table ring (its one large device allocation) parked for the next
- * solver on that device: allocating tens of GB right after freeing as much costs more than a solve.
- * This call frees what is parked (all devices). */
-void lgc_release_cached_memory(void);
-
-/* Kernel choice for latency-bound launches (at most one record per CU), per role: non-zero (the
- * default) runs them column-split on 16 waves per record, zero on 4 waves per record.  Both produce
- * and consume the same garbled tables, so garbler and evaluator may differ; process-wide, takes
- * effect at the next launch.  Exists for A/B timing and for the interchangeability test. */
-void lgc_set_split_kernels(int garbler, int evaluator);
-
-/* The matrix-vector products of CGD at width 64 (src/cgd.oc:119-125, 96 % of the gates of a d = 500 solve) use a
- * Karatsuba multiplier -- three 32 x 32 arrays per product, 110 gate steps against 129 -- by default; 0 selects the
- * plain 64 x 64 array everywhere.  Same integers either way.  Process-wide, takes effect for programs built
- * afterwards; the two roles of one solve must agree (as on every other parameter of the program). */
-void lgc_set_karatsuba(int on);
-/* Co-located solvers created from now on: room in the table ring beyond the largest launch (what the garbler may run ahead of
- * the evaluator by), default 8 GiB, at most the largest launch again; 0 restores the default.  A block of a sharded sweep
- * needs little (its launches are few and large): eight ranks rehearsing an 8-GPU sweep on one MI355X set 512 MiB. */
-void lgc_set_table_ring_slack(size_t bytes);
-
-/* The gate hash of the half-gates scheme, H(x, t) = pi(sigma(x) ^ t) ^ sigma(x) ^ t (this library's counterpart of the
- * gate hash inside Obliv-C's Yao runtime, reached from execYaoProtocol, src/cmd/linreg.c:177):
- *   0  pi = AES-128 under a fixed public key -- the reference's choice, and the default.  CDNA4 has no AES instruction:
- *      160 LDS table lookups per block, which is what bounds every kernel of this engine on MI355X.
- *   1  pi = the 12-round permutation of Chaskey (Mouha et al., SAC 2014; Chaskey-12 = ISO/IEC 29192-6): 4 x 32-bit
- *      add / rotate / xor, no tables -- about 1.8x the garbling rate on MI355X.  An EXPERIMENT, frozen since round 4 (no
- *      new kernels, no bench leg by default), and a WEAKER assumption than the reference's: the half-gates proof models pi
- *      as a fixed PUBLIC random permutation, whereas Chaskey's own proof is Even-Mansour -- pi sits between two XORs of a
- *      SECRET key and is never evaluated at inputs the adversary knows.  Used bare, pi has properties an ideal permutation
- *      does not: no round constants, so pi(0) = 0 and rotational relations between inputs and outputs survive, and its
- *      designers do not claim it to be indistinguishable from random.  H = pi(u) ^ u with u = sigma(x) ^ t and a public
- *      tweak does not hide these.  Nobody has turned them into an attack on garbling, but modelling this pi as random is a
- *      heuristic of its own, not the reference's and not Chaskey's.  A deployment has to ask for it on both roles; nothing
- *      selects it silently.  The circuits, gate numbering, table layout and every revealed integer are the same.
- * Process-wide, takes effect for programs / solvers / parties created afterwards; garbler and evaluator of one solve
- * must agree (a mismatch decodes to garbage, like any other disagreement about the program).  Returns LGC_EINVAL for an
- * unknown kind.  lgc_gate_hash_eval computes H on n labels (16 bytes each, tweaks[i]) on the device: tests pin both
- * kinds to the CPU checker with it. */
-int lgc_set_gate_hash(int kind);
-int lgc_gate_hash(void);
-const char *lgc_gate_hash_name(int kind);              /* "aes128", "chaskey12", NULL */
-int lgc_gate_hash_eval(int device, int kind, const uint8_t *labels, const uint64_t *tweaks, uint8_t *out, size_t n);
-
-/* Test hooks (tests/test_gpu_roles.py; not part of the drop-in surface).  lgc_test_party_garble_ring_stage
- * issues launch k as lgc_party_garble_ring does, in halves: stage 1 = the record kernel (stops before the table
- * pass of a critical-path launch; *is_critical_path tells whether the launch has one), stage 2 = the table pass.
- * lgc_test_party_ring_read copies `bytes` of the ring slot of launch k to the host -- what the mapped peer could
- * read at that moment. */
-int lgc_test_party_garble_ring_stage(lgc_party *p, size_t launch, int stage, int *is_critical_path);
-int lgc_test_party_ring_read(lgc_party *p, size_t launch, uint8_t *out, size_t bytes);
-
-/* ------------------------------------------------------- micro-benchmarks */
-/* Stand-alone LDS T-table AES throughput (the "AES roofline" of the north
- * star): blocks_per_lane AES-128 encryptions in every lane of `waves` waves.
- * Returns blocks/second in *rate; *check gets an XOR checksum. */
-int lgc_aes_bench(int device, int waves, int blocks_per_lane, double *rate, uint32_t *check);
-/* AES-128 of `n` 16-byte blocks with the fixed key on the device (known-answer tests). */
-int lgc_aes_encrypt(int device, const uint8_t *in, uint8_t *out, size_t n);
-
 #ifdef __cplusplus
 }
 #endif

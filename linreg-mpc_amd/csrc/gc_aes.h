@@ -146,36 +146,6 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4], con
     for (int b = 0; b < N; b++) {
         s[b][0] ^= rk[0]; s[b][1] ^= rk[1]; s[b][2] ^= rk[2]; s[b][3] ^= rk[3];
     }
-#if defined(GC_AES_COLWISE) && GC_AES_COLWISE
-    // column-wise rounds: only 4 lookups per block live at a time (fewer VGPRs, less ILP per block)
-#pragma unroll
-    for (int rnd = 1; rnd < 10; rnd++) {
-        uint32_t ns[N][4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t v0[N], v1[N], v2[N], v3[N];
-#pragma unroll
-            for (int b = 0; b < N; b++) {
-                v0[b] = tab.lk(s[b][j], 0);
-                v1[b] = tab.lk(s[b][(j + 1) & 3], 1);
-                v2[b] = T::kTwoTables ? tab.lk2(s[b][(j + 2) & 3], 2) : tab.lk(s[b][(j + 2) & 3], 2);
-                v3[b] = T::kTwoTables ? tab.lk2(s[b][(j + 3) & 3], 3) : tab.lk(s[b][(j + 3) & 3], 3);
-            }
-#pragma unroll
-            for (int b = 0; b < N; b++) {
-                if (T::kTwoTables) {
-                    uint32_t x = xor3(v1[b], v3[b], rk24[4 * rnd + j]);
-                    ns[b][j] = xor3(v0[b], v2[b], rotl32(x, 8));
-                } else {
-                    uint32_t t = xor3(v0[b], rotl32(v2[b], 16), rk[4 * rnd + j]);
-                    ns[b][j] = xor3(t, rotl32(v1[b], 8), rotl32(v3[b], 24));
-                }
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < N; b++) { s[b][0] = ns[b][0]; s[b][1] = ns[b][1]; s[b][2] = ns[b][2]; s[b][3] = ns[b][3]; }
-    }
-#else
 #pragma unroll
     for (int rnd = 1; rnd < 10; rnd++) {
         uint32_t v[N][16];
@@ -215,7 +185,6 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4], con
             }
         }
     }
-#endif
     {
         uint32_t v[N][16];
 #pragma unroll
@@ -237,47 +206,6 @@ GC_HD void aes_encrypt_n(const T &tab, const uint32_t *rk, uint32_t s[N][4], con
     }
 }
 
-// ---- gate-hash option 1: the permutation of Chaskey-12 in the place of the fixed-key AES.  An EXPERIMENT of round 3, frozen
-// since round 4 (include/linreg_gc.h, lgc_set_gate_hash): off by default, no new kernels, no bench leg.
-// CDNA4 has no AES instruction, so the fixed-key AES above is 160 LDS lookups per block and the LDS sets the pace of
-// every kernel of this engine; twelve rounds of four additions, four XORs and six rotations on 4 x 32-bit words are 168
-// integer instructions per block, no table, no LDS (Mouha, Mennink, Van Herrewege, Watanabe, Preneel, Verbauwhede, SAC 2014;
-// Chaskey-12 = ISO/IEC 29192-6).  What it is NOT: the half-gates hash models pi as a fixed PUBLIC random permutation (ZRE15;
-// Guo-Katz-Wang-Yu 2020 for H(x, t) = pi(sigma(x) ^ t) ^ sigma(x) ^ t), whereas the Chaskey MAC's proof is Even-Mansour -- pi
-// sits between two XORs of a SECRET key and is never evaluated at inputs the adversary knows.  Used bare, this pi has
-// properties an ideal permutation lacks: no round constants, so pi(0) = 0 (chaskey12_permute_n maps the zero state to
-// itself) and rotational relations survive all twelve rounds; its designers do not claim otherwise.  No attack on garbling
-// is known from that, but "model pi as random" is here a heuristic of its own -- weaker than the reference's assumption
-// about fixed-key AES, and not the assumption of Chaskey's proof.  Same circuits, same integers; both roles of a solve
-// must ask for it.  State word i = block word i (little-endian, as in the Chaskey reference code).
-GC_HD void chaskey_round(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3) {
-    v0 += v1; v1 = rotl32(v1, 5); v1 ^= v0; v0 = rotl32(v0, 16);
-    v2 += v3; v3 = rotl32(v3, 8); v3 ^= v2;
-    v0 += v3; v3 = rotl32(v3, 13); v3 ^= v0;
-    v2 += v1; v1 = rotl32(v1, 7); v1 ^= v2; v2 = rotl32(v2, 16);
-}
-template <int N>
-GC_HD void chaskey12_permute_n(uint32_t s[N][4]) {
-#pragma unroll
-    for (int r = 0; r < 12; r++) {
-#pragma unroll
-        for (int b = 0; b < N; b++) chaskey_round(s[b][0], s[b][1], s[b][2], s[b][3]);
-    }
-}
-// the inverse round: tests only (the permutation is checked to be one, by a second piece of code)
-inline void chaskey_round_inverse(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3) {
-    auto rotr = [](uint32_t v, int k) { return (v >> k) | (v << (32 - k)); };
-    v2 = rotr(v2, 16); v1 ^= v2; v1 = rotr(v1, 7); v2 -= v1;
-    v3 ^= v0; v3 = rotr(v3, 13); v0 -= v3;
-    v3 ^= v2; v3 = rotr(v3, 8); v2 -= v3;
-    v0 = rotr(v0, 16); v1 ^= v0; v1 = rotr(v1, 5); v0 -= v1;
-}
-
-// The permutation is a property of the table accessor type T of hash_n (T::kHashKind): 0 = fixed-key AES-128 through
-// T's lookups (the reference's hash), 1 = Chaskey-12 (T carries no table).  Kernels are templates over T, so the two
-// hashes are different instantiations with different symbols.
-enum { GATE_HASH_AES = 0, GATE_HASH_CHASKEY12 = 1, GATE_HASH_KINDS = 2 };
-
 // K = sigma(x) ^ tweak, as 4 words
 GC_HD void hash_prep(Lbl x, uint64_t tweak, uint32_t k[4]) {
     k[0] = x.z ^ (uint32_t)tweak;
@@ -295,10 +223,7 @@ GC_HD void hash_n(const T &tab, const uint32_t *rk, const Lbl *x, const uint64_t
         hash_prep(x[b], tw[b], k[b]);
         s[b][0] = k[b][0]; s[b][1] = k[b][1]; s[b][2] = k[b][2]; s[b][3] = k[b][3];
     }
-#ifndef GC_X_NOHASH          /* timing experiments only (scripts/exp): results are wrong with it */
-    if constexpr (T::kHashKind == GATE_HASH_CHASKEY12) chaskey12_permute_n<N>(s);
-    else aes_encrypt_n<N, T>(tab, rk, s, rk24);
-#endif
+    aes_encrypt_n<N, T>(tab, rk, s, rk24);
 #pragma unroll
     for (int b = 0; b < N; b++) {
         out[b].x = s[b][0] ^ k[b][0]; out[b].y = s[b][1] ^ k[b][1];
@@ -310,21 +235,10 @@ GC_HD void hash_n(const T &tab, const uint32_t *rk, const Lbl *x, const uint64_t
 struct HostTab {
     static const bool kTwoTables = false;
     static const bool kFourTables = false;
-    static const int kHashKind = 0;
     const uint32_t *te0;
     inline uint32_t lkt(int, uint32_t word, int k) const { return lk(word, k); }
     inline uint32_t lk(uint32_t word, int k) const { return te0[(word >> (8 * k)) & 0xffu]; }
     inline uint32_t lk2(uint32_t word, int k) const { return rotl32(lk(word, k), 16); }
-};
-
-// host accessor of the table-free hash (CPU checker)
-struct HostNoTab {
-    static const bool kTwoTables = false;
-    static const bool kFourTables = false;
-    static const int kHashKind = 1;
-    inline uint32_t lkt(int, uint32_t, int) const { return 0; }
-    inline uint32_t lk(uint32_t, int) const { return 0; }
-    inline uint32_t lk2(uint32_t, int) const { return 0; }
 };
 
 // ---- half-gates, one AND gate (lane-local).  gid: unique gate id.
@@ -335,18 +249,9 @@ GC_HD Lbl garble_and(const T &tab, const uint32_t *rk, Lbl R, Lbl a0, Lbl b0, ui
     Lbl in[4] = {a0, lxor(a0, R), b0, lxor(b0, R)};
     uint64_t tw[4] = {2 * gid, 2 * gid, 2 * gid + 1, 2 * gid + 1};
     Lbl h[4];
-#ifndef GC_GARBLE_SPLIT22
-#define GC_GARBLE_SPLIT22 1   /* two pairs of interleaved blocks: fewer live registers, 4 waves/SIMD */
-#endif
-#ifndef GC_GARBLE_H1_SPLIT22
-#define GC_GARBLE_H1_SPLIT22 1
-#endif
-    if (T::kHashKind == GATE_HASH_CHASKEY12 ? (GC_GARBLE_H1_SPLIT22 != 0) : (GC_GARBLE_SPLIT22 != 0)) {
-        hash_n<2, T>(tab, rk, in, tw, h, rk24);
-        hash_n<2, T>(tab, rk, in + 2, tw + 2, h + 2, rk24);
-    } else {
-        hash_n<4, T>(tab, rk, in, tw, h, rk24);
-    }
+    // two pairs of interleaved blocks (four at once need more live registers than four waves per SIMD leave)
+    hash_n<2, T>(tab, rk, in, tw, h, rk24);
+    hash_n<2, T>(tab, rk, in + 2, tw + 2, h + 2, rk24);
     uint32_t pa = a0.x & 1u, pb = b0.x & 1u;
     TG = lxor(lxor(h[0], h[1]), lmask(R, pb));
     Lbl WG = lxor(h[0], lmask(TG, pa));
@@ -365,18 +270,6 @@ GC_HD Lbl eval_and(const T &tab, const uint32_t *rk, Lbl a, Lbl b, uint64_t gid,
     Lbl WG = lxor(h[0], lmask(TG, sa));
     Lbl WE = lxor(h[1], lmask(lxor(TE, a), sb));
     return lxor(WG, WE);
-}
-
-// two independent gate steps of the evaluator at once: four hashes interleaved in one wave instead of two and two
-template <class T>
-GC_HD void eval_and2(const T &tab, const uint32_t *rk, Lbl a1, Lbl b1, uint64_t gid1, Lbl TG1, Lbl TE1, Lbl a2, Lbl b2, uint64_t gid2,
-                     Lbl TG2, Lbl TE2, Lbl &c1, Lbl &c2, const uint32_t *rk24 = 0) {
-    Lbl in[4] = {a1, b1, a2, b2};
-    uint64_t tw[4] = {2 * gid1, 2 * gid1 + 1, 2 * gid2, 2 * gid2 + 1};
-    Lbl h[4];
-    hash_n<4, T>(tab, rk, in, tw, h, rk24);
-    c1 = lxor(lxor(h[0], lmask(TG1, a1.x & 1u)), lxor(h[1], lmask(lxor(TE1, a1), b1.x & 1u)));
-    c2 = lxor(lxor(h[2], lmask(TG2, a2.x & 1u)), lxor(h[3], lmask(lxor(TE2, a2), b2.x & 1u)));
 }
 
 }  // namespace gc

@@ -34,12 +34,6 @@
 #endif
 #endif
 
-// OP_IDIVC (division by the public normalizer): 1 = multiplication by a precomputed constant (Circ::divc), 0 = the
-// divider with a constant divisor word (Circ::divc_long, rounds 1-4)
-#ifndef GC_IDIVC_MAGIC
-#define GC_IDIVC_MAGIC 1
-#endif
-
 namespace gc {
 
 GC_HD uint64_t lanes(int n) { return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1)); }
@@ -563,15 +557,8 @@ struct Circ {
         W Q = div_mag(be, ua, ub, w, p, true, bounded);
         return condneg(be, Q, be.XOR(sa, sb), w);
     }
-    // tdiv(a, c) for a public constant c > 0 (the normalizer of linear.oc:52-65), the long way: the divider above with a
-    // constant divisor word (rounds 1-4; kept for A/B runs, GC_IDIVC_MAGIC=0)
-    static GC_HD W divc_long(B &be, W a, uint64_t c, int w) {
-        W sa = be.bcast(a, w - 1);
-        W ua = condneg(be, a, sa, w);
-        W Q = div_mag(be, ua, be.sel(lanes(w), be.konst(c), be.zero()), w, 0, false);
-        return condneg(be, Q, sa, w);
-    }
-    // The same quotient by a multiplication with a public constant (Granlund & Montgomery, "Division by invariant
+    // tdiv(a, c) for a public constant c > 0 (the normalizer of linear.oc:52-65; rounds 1-4 ran the divider above with a
+    // constant divisor word: 882 gate steps against 61) by a multiplication with a public constant (Granlund & Montgomery, "Division by invariant
     // integers using multiplication", PLDI 1994, theorem 4.2 at precision w-1): with l = ceil(log2 c) and
     //     m = floor(2^(w-1+l) / c) + 1        (2^(w-1) < m < 2^w; idivc_magic in gc_program.h, on the host)
     // floor(n / c) = floor(m n / 2^(w-1+l)) for every 0 <= n <= 2^(w-1) and c >= 2: m c = 2^(w-1+l) + e with 1 <= e <= c,

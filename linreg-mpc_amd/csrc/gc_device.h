@@ -25,19 +25,11 @@ namespace gc {
 // provider that runs four phase-1 kernels paid for the garbler's and the evaluator's MAC kernels.
 static __constant__ DevAesConst c_aes = aes_make_dev_const();
 
-#ifndef GC_SOLO_INLINE
-#define GC_SOLO_INLINE 1   /* wide generic kernel: gate bodies inlined at every AND site (0: one out-of-line body; the call ABI
-                              spills around every gate step, as it did in the 4-wave kernels) */
-#endif
-#ifndef GC_AES_TAB4
-#define GC_AES_TAB4 1   /* MAC kernels and the AES micro-benchmark: four rotated tables, 32 replicas each */
-#endif
 static constexpr int kLdsTabWords = 256 * 64;   // 64 KiB: entry x occupies the 256-byte row x
 
 struct LdsTab {
     static const bool kTwoTables = false;
     static const bool kFourTables = false;
-    static const int kHashKind = 0;
     const char *base;    // LDS byte address of the table
     uint32_t lane4;      // (lane << 2): fits one byte, merged into the address by v_perm_b32
     // Te0[byte k of word]: address = (byte << 8) | (lane << 2)
@@ -49,25 +41,6 @@ struct LdsTab {
     __device__ __forceinline__ uint32_t lkt(int, uint32_t word, int k) const { return lk(word, k); }
 };
 
-// MAC kernels: Te0 and Te2 = rotl16(Te0) side by side (128 KiB): one rotate per column instead of three
-struct LdsTab2 {
-    static const bool kTwoTables = true;
-    static const bool kFourTables = false;
-    static const int kHashKind = 0;
-    const char *base;
-    uint32_t lane4;
-    __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const {
-        uint32_t off = __builtin_amdgcn_perm(word, lane4, 0x0c0c0400u + ((uint32_t)k << 8));
-        return *reinterpret_cast<const uint32_t *>(base + off);
-    }
-    // second table at +64 KiB: bit 16 of the address comes from byte 2 of lane4 (= 0x01), so the
-    // address is still ONE v_perm_b32 (a +65536 immediate does not fit the 16-bit DS offset field)
-    __device__ __forceinline__ uint32_t lk2(uint32_t word, int k) const {
-        uint32_t off = __builtin_amdgcn_perm(word, lane4, 0x0c020400u + ((uint32_t)k << 8));
-        return *reinterpret_cast<const uint32_t *>(base + off);
-    }
-    __device__ __forceinline__ uint32_t lkt(int, uint32_t word, int k) const { return lk(word, k); }
-};
 // ---- staging the AES table image.  Row x of an image is 64 dwords that depend on Te0[x] and the position in the row only, so
 // wave w of a workgroup writes rows w, w + W, w + 2W, ...: Te0[x] is wave-uniform -- a SCALAR load, four in flight --, a row is
 // one ds_write_b32 of the whole wave, and nothing waits for vector memory.  (Rounds 1-4 had thread i write dwords i,
@@ -90,40 +63,18 @@ __device__ __forceinline__ void lds_tab_rows(F row) {
     }
     __syncthreads();
 }
-__device__ __forceinline__ void lds_tab2_fill(uint32_t *lds) {
-    lds_tab_rows([lds](uint32_t x, uint32_t lane, uint32_t v) {
-        lds[x * 64 + lane] = v;
-        lds[kLdsTabWords + x * 64 + lane] = (v << 16) | (v >> 16);
-    });
-}
-__device__ __forceinline__ LdsTab2 lds_tab2_make(const uint32_t *lds) {
-    LdsTab2 t;
-    t.base = reinterpret_cast<const char *>(lds);
-    t.lane4 = ((threadIdx.x & 63u) << 2) | 0x10000u;
-    return t;
-}
-
 // Four tables Te_t = rotl(Te0, 8t) in the same 128 KiB: a ds_read_b32 is serviced in two groups of
 // 32 lanes on 32 banks, so 32 replicas per entry are already conflict-free (lanes l and l + 32 share
 // a replica but never a cycle).  Row x (256 B) of the first half holds Te0[x] x 32 | Te1[x] x 32,
 // of the second half Te2[x] x 32 | Te3[x] x 32.  No rotates in the rounds.
-#ifndef GC_ADDR_BITOP3
-#define GC_ADDR_BITOP3 0
-#endif
 struct LdsTab4 {
     static const bool kTwoTables = false;
     static const bool kFourTables = true;
-    static const int kHashKind = 0;
     const char *base;
     uint32_t c[4];       // per table: ((lane & 31) << 2) | (t & 1) << 7 | (t >> 1) << 16
     __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const { return lkt(0, word, k); }
     __device__ __forceinline__ uint32_t lk2(uint32_t word, int k) const { return lkt(2, word, k); }
     __device__ __forceinline__ uint32_t lkt(int t, uint32_t word, int k) const {
-#if GC_ADDR_BITOP3
-        // byte 1 of the state word already sits where the address wants it: (word & 0xff00) | c[t] is one v_bitop3_b32, a
-        // full-rate instruction, where v_perm_b32 issues at half rate (profiles/r4_valu_issue.txt): 40 of a block's 160 addresses
-        if (k == 1) return *reinterpret_cast<const uint32_t *>(base + __builtin_amdgcn_bitop3_b32(word, 0xff00u, c[t], 0xEA));
-#endif
         uint32_t off = __builtin_amdgcn_perm(word, c[t], (t >= 2 ? 0x0c020400u : 0x0c0c0400u) + ((uint32_t)k << 8));
         return *reinterpret_cast<const uint32_t *>(base + off);
     }
@@ -158,7 +109,6 @@ __device__ __forceinline__ LdsTab lds_tab_make(const uint32_t *lds) {
 struct LdsTab2h {
     static const bool kTwoTables = true;
     static const bool kFourTables = false;
-    static const int kHashKind = 0;
     const char *base;
     uint32_t c0, c1;
     __device__ __forceinline__ uint32_t lk(uint32_t word, int k) const {
@@ -182,24 +132,8 @@ __device__ __forceinline__ LdsTab2h lds_tab2h_make(const uint32_t *lds) {
     return t;
 }
 
-// the accessor of the table-free gate hash (Chaskey-12 permutation, gc_aes.h): nothing to look up, no LDS
-struct NoTab {
-    static const bool kTwoTables = false;
-    static const bool kFourTables = false;
-    static const int kHashKind = 1;
-    __device__ __forceinline__ uint32_t lk(uint32_t, int) const { return 0u; }
-    __device__ __forceinline__ uint32_t lk2(uint32_t, int) const { return 0u; }
-    __device__ __forceinline__ uint32_t lkt(int, uint32_t, int) const { return 0u; }
-};
-
-// table variant by number: 2 = LdsTab2h (64 KiB), 4 = LdsTab4 (128 KiB), 0 = none (gate hash 1)
+// table variant by number: 2 = LdsTab2h (64 KiB), 4 = LdsTab4 (128 KiB)
 template <int TABV> struct TabSel;
-template <> struct TabSel<0> {
-    typedef NoTab T;
-    static constexpr int kWords = 1;
-    static __device__ __forceinline__ void fill(uint32_t *) {}
-    static __device__ __forceinline__ T make(const uint32_t *) { return NoTab(); }
-};
 template <> struct TabSel<2> {
     typedef LdsTab2h T;
     static constexpr int kWords = kLdsTabWords;
@@ -240,9 +174,8 @@ __device__ __forceinline__ void st_lbl_lds(Lbl *p, Lbl v) {
     *(__attribute__((address_space(3))) gc_u32x4 *)p = d;
 }
 
-// MODE_MAC : one wave does all AES of its gate step, gate body inlined (MAC kernel).
-// MODE_SOLO: the same with one out-of-line gate body: generic records in WIDE launches
-//            (thousands of records: throughput matters, not latency).
+// MODE_MAC : one wave does all AES of its gate step, gate body inlined (MAC kernels).
+// MODE_SOLO: the same for generic records in WIDE launches (thousands of records: throughput matters, not latency).
 // MODE_QUAD: the 4 waves of a workgroup run the same record redundantly and split the
 //            4 (garbler) / 2 (evaluator) hashes of every gate step between them, exchanging
 //            the results through LDS: the latency of a dependent chain of steps drops from
@@ -258,27 +191,11 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");   // no LDS access of the next phase may be scheduled above the barrier
 }
 
-// CRIT (garbler, MODE_QUAD only): "critical-path" garbling for launches of so few records that the
-// chain of dependent gate steps of ONE record sets the run time.  The garbler's output label needs only
-// two of its four hashes -- with pa, pb the colours of the zero-labels a0, b0 (half-gates, ZRE15):
-//     c0 = H(a0 ^ pa R, 2g) ^ H(b0 ^ pb R, 2g+1) ^ (pa & pb) R
-// (WG = pa ? h1 ^ pb R : h0 and WE = pb ? h3 : h2 in the notation of garble_and) -- the other two only
-// enter the ciphertexts.  The record kernel therefore computes c0 alone (two hash-waves per gate step,
-// what the evaluator needs too) and leaves (a0, b0) in the step's two table rows; gc_tabfill_kernel
-// then turns every row pair into (TG, TE) in place, all steps of all records in parallel on the whole
-// chip.  Inactive lanes leave zeros; an active gate with a0 = b0 = 0 (two public constants) never
-// reads its ciphertexts (both colours are 0), so "both rows zero" is the in-band "no table" mark.
-template <bool GARBLER, int MODE, class TAB = LdsTab, bool CRIT = false>
+template <bool GARBLER, int MODE, class TAB = LdsTab>
 struct GpuBackend {
     typedef Lbl W;
     // latency-bound kernels issue independent gate steps of the multiplier as dual steps (gc_circuits.h)
-    // ... and (GC_EVAL_PAIR) the evaluator's MAC kernels: a wave that evaluates has only two hashes per gate step to interleave,
-    // against the garbler's four; with the independent steps of the multiplier paired it has four as well
-#ifndef GC_EVAL_PAIR
-#define GC_EVAL_PAIR 0
-#endif
-    static const bool kEvalPair = (MODE == MODE_MAC && !GARBLER && GC_EVAL_PAIR != 0);
-    static const bool kPairSteps = (MODE == MODE_QUAD) || kEvalPair;
+    static const bool kPairSteps = (MODE == MODE_QUAD);
     int wave;            // MODE_QUAD: wave index inside the workgroup (wave-uniform)
     Lbl *xch;            // MODE_QUAD: LDS exchange area, 2 buffers x 512 labels (16 KiB)
     int xsel;            // MODE_QUAD: buffer used by the next step (adjacent steps alternate)
@@ -293,14 +210,7 @@ struct GpuBackend {
 
     __device__ __forceinline__ W zero() const { return lzero(); }
     // public lane masks are wave-uniform 64-bit scalars: used directly as the v_cndmask condition
-#ifndef GC_INVBALLOT
-#define GC_INVBALLOT 1
-#endif
-#if GC_INVBALLOT
     __device__ __forceinline__ bool bit(uint64_t m) const { return __builtin_amdgcn_inverse_ballot_w64(m); }
-#else
-    __device__ __forceinline__ bool bit(uint64_t m) const { return (m >> lane) & 1u; }
-#endif
     __device__ __forceinline__ W rmask(uint64_t m) const {
         bool t = bit(m);
         W r = {t ? R.x : 0u, t ? R.y : 0u, t ? R.z : 0u, t ? R.w : 0u};
@@ -324,9 +234,6 @@ struct GpuBackend {
         return sel(0xffffffffull, lo, hi);
     }
     __device__ __forceinline__ W pull(W a, int from, bool ok) const {
-#ifdef GC_X_NOSHL           /* timing experiments only */
-        return a;
-#endif
         int addr = (from & 63) << 2;
         W r = {(uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)a.x), (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)a.y),
                (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)a.z), (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)a.w)};
@@ -354,27 +261,11 @@ struct GpuBackend {
         const uint64_t gid = step * 64 + (uint64_t)lane;
         Lbl *slot = tab + (step - launch_step0) * 128 + lane;
         step++;
-        if (MODE == MODE_SOLO) return GC_SOLO_INLINE ? and_impl(lt, R, a, b, gid, slot, on) : and_outlined(lt, R, a, b, gid, slot, on);
-        if (MODE == MODE_MAC) return and_impl(lt, R, a, b, gid, slot, on);
+        if (MODE == MODE_SOLO || MODE == MODE_MAC) return and_impl(lt, R, a, b, gid, slot, on);
         xsel ^= 1;
         return and_quad(lt, R, a, b, gid, slot, on, wave, xch + xsel * 512, lane);
     }
     __device__ __forceinline__ void AND2(W a1, W b1, uint64_t act1, W a2, W b2, uint64_t act2, W &c1, W &c2) {
-        if (kEvalPair) {
-            const bool on1 = bit(act1), on2 = bit(act2);
-            const uint64_t gid = step * 64 + (uint64_t)lane;
-            Lbl *slot = tab + (step - launch_step0) * 128 + lane;
-            step += 2;
-            c1 = lzero(); c2 = lzero();
-            if (on1 || on2) {
-                Lbl TG1 = ld_lbl_global(slot), TE1 = ld_lbl_global(slot + 64), TG2 = ld_lbl_global(slot + 128), TE2 = ld_lbl_global(slot + 192);
-                Lbl r1, r2;
-                eval_and2(lt, c_aes.rk, a1, b1, gid, TG1, TE1, a2, b2, gid + 64, TG2, TE2, r1, r2, c_aes.rk24);
-                c1 = lmask(r1, on1 ? 1u : 0u);
-                c2 = lmask(r2, on2 ? 1u : 0u);
-            }
-            return;
-        }
         if (MODE != MODE_QUAD) {
             c1 = AND(a1, b1, act1);
             c2 = AND(a2, b2, act2);
@@ -402,9 +293,6 @@ struct GpuBackend {
         }
         return c;
     }
-    static __device__ __noinline__ W and_outlined(TAB lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on) {
-        return and_impl(lt, R, a, b, gid, slot, on);
-    }
     // cooperative gate step.  Every wave of the workgroup calls this with identical operands; exactly
     // one barrier per step, the exchange area is double-buffered by step parity.  Inlined: the call
     // ABI spilled around every gate step (DIV 3.5 -> 2.4 ms).
@@ -412,27 +300,6 @@ struct GpuBackend {
     // wide whatever the activity mask), so no EXEC-masked load forces a vmcnt(0) ahead of the hash.
     static __device__ __forceinline__ W and_quad(TAB lt, Lbl R, W a, W b, uint64_t gid, Lbl *slot, bool on,
                                                  int wave, Lbl *xbuf, int lane) {
-        if (GARBLER && CRIT) {
-            const uint32_t pa = a.x & 1u, pb = b.x & 1u;
-            if (wave < 2) {
-                Lbl h = lzero();
-                if (on) {
-                    Lbl x = (wave == 0) ? lxor(a, lmask(R, pa)) : lxor(b, lmask(R, pb));
-                    uint64_t tw = 2 * gid + (uint64_t)wave;
-                    hash_n<1, TAB>(lt, c_aes.rk, &x, &tw, &h, c_aes.rk24);
-                }
-                st_lbl_lds(xbuf + wave * 64 + lane, h);
-            } else {
-                Lbl v = (wave == 2) ? a : b;     // the zero-labels, for gc_tabfill_kernel
-#ifndef GC_X_NOSTASH
-                st_lbl_global(slot + (wave - 2) * 64, on ? v : lzero());
-#endif
-            }
-            lds_barrier();
-            W c = lzero();
-            if (on) c = lxor(lxor(xbuf[lane], xbuf[64 + lane]), lmask(R, pa & pb));
-            return c;
-        }
         const int nh = GARBLER ? 4 : 2;
         Lbl TGe = lzero(), TEe = lzero();
         if (!GARBLER) { TGe = ld_lbl(slot); TEe = ld_lbl(slot + 64); }   // in flight during the hash
@@ -471,33 +338,11 @@ struct GpuBackend {
         }
         return c;
     }
-    // two gate steps (gid, gid + 64) at once: 8 (garbler) / 4 (evaluator, critical-path garbler) hashes over 4 waves
+    // two gate steps (gid, gid + 64) at once: 8 (garbler) / 4 (evaluator) hashes over 4 waves
     static __device__ __forceinline__ void and2_quad(TAB lt, Lbl R, W a1, W b1, W a2, W b2, uint64_t gid, Lbl *slot,
                                                      bool on1, bool on2, int wave, Lbl *xbuf, int lane, W &c1, W &c2) {
         const uint64_t gid2 = gid + 64;
         Lbl *slot2 = slot + 128;
-        if (GARBLER && CRIT) {
-            // wave q: colour-0 label of input (q & 1) of gate (q >> 1); it also stashes that zero-label (row q)
-            const bool g2 = wave >= 2;
-            Lbl src = (wave & 1) ? (g2 ? b2 : b1) : (g2 ? a2 : a1);
-            const bool on = g2 ? on2 : on1;
-            Lbl h = lzero();
-            if (on) {
-                Lbl x = lxor(src, lmask(R, src.x & 1u));
-                uint64_t tw = 2 * (g2 ? gid2 : gid) + (uint64_t)(wave & 1);
-                hash_n<1, TAB>(lt, c_aes.rk, &x, &tw, &h, c_aes.rk24);
-            }
-            st_lbl_lds(xbuf + wave * 64 + lane, h);
-#ifndef GC_X_NOSTASH
-            st_lbl_global(slot + wave * 64, on ? src : lzero());
-#endif
-            lds_barrier();
-            c1 = lzero();
-            c2 = lzero();
-            if (on1) c1 = lxor(lxor(xbuf[lane], xbuf[64 + lane]), lmask(R, a1.x & b1.x & 1u));
-            if (on2) c2 = lxor(lxor(xbuf[128 + lane], xbuf[192 + lane]), lmask(R, a2.x & b2.x & 1u));
-            return;
-        }
         Lbl TG1 = lzero(), TE1 = lzero(), TG2 = lzero(), TE2 = lzero();
         if (!GARBLER) {
             TG1 = ld_lbl(slot); TE1 = ld_lbl(slot + 64);
@@ -579,28 +424,15 @@ struct GpuBackend {
     }
 };
 
-#ifndef GC_MAC_PERSIST
-#define GC_MAC_PERSIST 0
-#endif
 // MAC launches: one wavefront per record; the TPB/64 waves of a workgroup share the LDS table
-template <bool GARBLER, int TPB, int HK = 0>
+template <bool GARBLER, int TPB>
 __global__ void __launch_bounds__(TPB)
 gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
-    // HK = 0: Te0 | Te2 or the four rotated tables: 128 KiB, one workgroup per CU.  HK = 1 (table-free gate hash): no LDS
-    __shared__ uint32_t lds_te0[HK == 1 ? 1 : 2 * kLdsTabWords];
-    if constexpr (HK == 0) {
-#if GC_AES_TAB4
-        lds_tab4_fill(lds_te0);
-#else
-        lds_tab2_fill(lds_te0);
-#endif
-    }
+    // the four rotated tables: 128 KiB, one workgroup per CU
+    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    lds_tab4_fill(lds_te0);
     const int lane = threadIdx.x & 63;
-#if GC_AES_TAB4
-    typedef GpuBackend<GARBLER, MODE_MAC, typename std::conditional<HK == 1, NoTab, LdsTab4>::type> B;
-#else
-    typedef GpuBackend<GARBLER, MODE_MAC, typename std::conditional<HK == 1, NoTab, LdsTab2>::type> B;
-#endif
+    typedef GpuBackend<GARBLER, MODE_MAC, LdsTab4> B;
     B be;
     be.R = R;
     be.words = words;
@@ -611,24 +443,13 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
     be.lane = lane;
     be.wave = 0;
     be.xch = 0;
-    if constexpr (HK == 0) {
-#if GC_AES_TAB4
-        be.lt = lds_tab4_make(lds_te0);
-#else
-        be.lt = lds_tab2_make(lds_te0);
-#endif
-    }
+    be.lt = lds_tab4_make(lds_te0);
     typedef Circ<B> C;
-    // GC_MAC_PERSIST: a grid of one workgroup per CU whose waves walk the records round-robin with the WORKGROUP index
-    // running fastest, so that a partly filled last round is spread over all CUs.  Measured: the garbler's MAC launches
-    // of d=100 (2.44 rounds) 12-14 % faster, serialised or not -- but the co-located solve gets SLOWER (0.154 -> 0.160 s
-    // with the garbler alone persistent, d=500 +2..4 %): the evaluator's kernels no longer slip in between the garbler's
-    // workgroups and its chain, pushed into the gaps, ends later.  Off; worth another look for roles on separate GPUs.
-    const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-    const bool persist = GC_MAC_PERSIST && gridDim.x * waves < nrec;          // fewer slots than records: walk
-    const uint32_t first = persist ? wave * gridDim.x + blockIdx.x : blockIdx.x * waves + wave;
-    const uint32_t stride = persist ? waves * gridDim.x : (nrec ? nrec : 1u);
-    for (uint32_t wid = first; wid < nrec; wid += stride) {
+    // (A persistent form -- one workgroup per CU walking the records -- was measured in round 4: the garbler's launches of a
+    // few rounds 12-14 % faster alone, the co-located solve slower, because the evaluator's kernels no longer slip in between
+    // the garbler's workgroups.  Not kept.)
+    const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wid < nrec) {
         Rec r = recs[wid];
         r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);
         r.dst = __builtin_amdgcn_readfirstlane(r.dst);
@@ -646,7 +467,7 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
                         be.load2(r.b + (int32_t)k * r.sb, r.b + (int32_t)(r.cnt + k) * r.sb), p);
             be.store2(r.dst, r.dst + 2, S);
             be.store2(r.dst + 1, r.dst + 3, Cc);
-            continue;
+            return;
         }
         for (uint32_t k = 0; k < r.cnt; k++)
             C::mac(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
@@ -660,12 +481,12 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
 // each of the two recombination loops; the nine sub-product words of a pair wait in scratch memory meanwhile.
 // (Out-of-line gates for the recombination, or one kernel for OP_MAC and OP_MACK together, measured no faster / slower:
 // the combined kernel spilled 175 VGPRs.)
-template <bool GARBLER, int TPB, int HK = 0>
+template <bool GARBLER, int TPB>
 __global__ void __launch_bounds__(TPB)
 gc_mack_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
-    __shared__ uint32_t lds_te0[HK == 1 ? 1 : 2 * kLdsTabWords];
-    if constexpr (HK == 0) lds_tab4_fill(lds_te0);
-    typedef GpuBackend<GARBLER, MODE_MAC, typename std::conditional<HK == 1, NoTab, LdsTab4>::type> B;
+    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    lds_tab4_fill(lds_te0);
+    typedef GpuBackend<GARBLER, MODE_MAC, LdsTab4> B;
     B be;
     be.R = R;
     be.words = words;
@@ -676,7 +497,7 @@ gc_mack_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t la
     be.lane = threadIdx.x & 63;
     be.wave = 0;
     be.xch = 0;
-    if constexpr (HK == 0) be.lt = lds_tab4_make(lds_te0);
+    be.lt = lds_tab4_make(lds_te0);
     const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (wid >= nrec) return;
     Rec r = recs[wid];
@@ -700,7 +521,7 @@ gc_mack_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t la
 // launches; TPB = 256); QUAD = false: one wave per record, TPB / 64 records per workgroup (wide
 // launches).  TABV picks the AES tables: 4 = four rotated tables in 128 KiB (fewest instructions
 // per round; one workgroup per CU), 2 = two tables in 64 KiB (two 4-wave workgroups per CU).
-template <bool GARBLER, bool QUAD, int TABV, int TPB, bool CRIT = false>
+template <bool GARBLER, bool QUAD, int TABV, int TPB>
 __global__ void __launch_bounds__(TPB)
 gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *decode,
                uint64_t launch_step0, Lbl R, int w, int p) {
@@ -710,7 +531,7 @@ gc_exec_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t *d
     TS::fill(lds_te0);
     const uint32_t wid = QUAD ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // wide: blockDim <= TPB
     if (wid >= nrec) return;
-    typedef GpuBackend<GARBLER, QUAD ? MODE_QUAD : MODE_SOLO, typename TS::T, CRIT && GARBLER && QUAD> B;
+    typedef GpuBackend<GARBLER, QUAD ? MODE_QUAD : MODE_SOLO, typename TS::T> B;
     B be;
     be.R = R;
     be.words = words;

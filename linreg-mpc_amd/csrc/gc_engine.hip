@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "../../include/linreg_gc.h"
+#include "../../include/linreg_gc_sweep.h"
+#include "../../include/linreg_gc_debug.h"
 #include "hip_scope.h"
 #include "gc_device.h"
 #include "gc_program.h"
@@ -197,17 +199,10 @@ gc_input_kernel(Lbl *wordsG, Lbl *wordsE, const uint64_t *vals, uint32_t base, u
 __global__ void __launch_bounds__(1024)
 gc_aes_bench_kernel(uint32_t *out, int blocks_per_lane) {
     // the table variant of the MAC kernels (the roof they are priced against)
-#if GC_AES_TAB4
     __shared__ uint32_t lds_te0[2 * kLdsTabWords];
     lds_tab4_fill(lds_te0);
     LdsTab4 lt = lds_tab4_make(lds_te0);
     typedef LdsTab4 TabT;
-#else
-    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
-    lds_tab2_fill(lds_te0);
-    LdsTab2 lt = lds_tab2_make(lds_te0);
-    typedef LdsTab2 TabT;
-#endif
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s[4][4];
     for (int b = 0; b < 4; b++) { s[b][0] = gid; s[b][1] = b; s[b][2] = gid * 2654435761u; s[b][3] = 0x9e3779b9u ^ b; }
@@ -225,15 +220,9 @@ gc_aes_encrypt_kernel(const uint4 *in, uint4 *out, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint4 v = i < n ? in[i] : make_uint4(0, 0, 0, 0);
     uint32_t s[1][4] = {{v.x, v.y, v.z, v.w}}, s1[1][4] = {{v.x, v.y, v.z, v.w}};
-#if GC_AES_TAB4
     lds_tab4_fill(lds_te0);
     LdsTab4 l4 = lds_tab4_make(lds_te0);
     aes_encrypt_n<1, LdsTab4>(l4, c_aes.rk, s, c_aes.rk24);
-#else
-    lds_tab2_fill(lds_te0);
-    LdsTab2 l2 = lds_tab2_make(lds_te0);
-    aes_encrypt_n<1, LdsTab2>(l2, c_aes.rk, s, c_aes.rk24);
-#endif
     __syncthreads();
     lds_tab_fill(lds_te0);
     LdsTab lt = lds_tab_make(lds_te0);
@@ -242,23 +231,18 @@ gc_aes_encrypt_kernel(const uint4 *in, uint4 *out, uint32_t n) {
     out[i] = (i & 1) ? make_uint4(s1[0][0], s1[0][1], s1[0][2], s1[0][3]) : make_uint4(s[0][0], s[0][1], s[0][2], s[0][3]);
 }
 
-// the gate hash H(x, t) of kind `kind` (gc_aes.h) on n labels: what the record kernels compute per half gate; pins the
-// device code of both kinds to the host code (tests)
+// the gate hash H(x, t) (gc_aes.h) on n labels: what the record kernels compute per half gate; pins the device code to
+// the host code and to OpenSSL's AES (tests)
 __global__ void __launch_bounds__(256)
-gc_gate_hash_kernel(const uint4 *in, const uint64_t *tweak, uint4 *out, uint32_t n, int kind) {
+gc_gate_hash_kernel(const uint4 *in, const uint64_t *tweak, uint4 *out, uint32_t n) {
     __shared__ uint32_t lds_te0[2 * kLdsTabWords];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint4 v = i < n ? in[i] : make_uint4(0, 0, 0, 0);
     Lbl x = {v.x, v.y, v.z, v.w}, h = lzero();
     uint64_t tw = i < n ? tweak[i] : 0;
-    if (kind == GATE_HASH_CHASKEY12) {
-        NoTab nt;
-        hash_n<1, NoTab>(nt, c_aes.rk, &x, &tw, &h);
-    } else {
-        lds_tab4_fill(lds_te0);
-        LdsTab4 l4 = lds_tab4_make(lds_te0);
-        hash_n<1, LdsTab4>(l4, c_aes.rk, &x, &tw, &h, c_aes.rk24);
-    }
+    lds_tab4_fill(lds_te0);
+    LdsTab4 l4 = lds_tab4_make(lds_te0);
+    hash_n<1, LdsTab4>(l4, c_aes.rk, &x, &tw, &h, c_aes.rk24);
     if (i < n) out[i] = make_uint4(h.x, h.y, h.z, h.w);
 }
 
@@ -380,7 +364,6 @@ extern "C" int lgc_program_info_get(const lgc_program *p, lgc_program_info *info
     info->prefix_launches = P.prefix_launches;
     info->prefix_steps = P.prefix_steps;
     info->total_xors = P.total_xors;
-    info->gate_hash = P.gate_hash;
     return LGC_OK;
 }
 static_assert(sizeof(lgc_record) == sizeof(Rec), "record layout");
@@ -662,27 +645,25 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
         Lbl *tab = reinterpret_cast<Lbl *>(reinterpret_cast<char *>(s->tab) + s->tab_off[i]);
         bool timed = profile || L.mac_only;
         if (!profile && s->tab_wait[i] >= 0) HIPCHK(hipStreamWaitEvent(sG, s->evE[(size_t)s->tab_wait[i]], 0));
-#if GC_MAC_EXCLUSIVE
         // MAC launches are shaped to fill whole rounds of the chip (gc_program.h: kRoundRecs): a garbler
         // MAC launch sharing the CUs with the previous launch's evaluator would break both into ragged rounds
         if (!profile && L.mac_only && i > 0 && P.launches[i - 1].mac_only && L.nrec >= kExclusiveMac &&
             P.launches[i - 1].nrec >= kExclusiveMac)
             HIPCHK(hipStreamWaitEvent(sG, s->evE[i - 1], 0));
-#endif
         if (timed) HIPCHK(hipEventRecord(s->evs[3 * i], sG));
-        const LaunchMode modeG = gc_launch_mode(L, true, P.gate_hash);      // read once: record kernel and table pass agree
+        const LaunchMode modeG = gc_launch_mode(L, true);      // read once: record kernel and table pass agree
         if (pre && i < P.prefix_launches) {          // tables already in the ring
             if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
             if (!profile) HIPCHK(hipEventRecord(s->evG[i], sG));
         } else if (profile || !gc_mode_is_crit(modeG, L)) {
-            HIPCHK(gc_launch_records<true>(modeG, P.gate_hash, s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
+            HIPCHK(gc_launch_records<true>(modeG, s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
             if (gc_mode_is_crit(modeG, L)) HIPCHK(gc_launch_tabfill(L, tab, tab, s->R, sG));
             if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
             if (!profile) HIPCHK(hipEventRecord(s->evG[i], sG));
         } else {
             // critical path on the garbler chain, table pass on the side stream: only the evaluation waits for it.
             // The stash is the launch's own ring region (in place): this ring is private to the process
-            HIPCHK(gc_launch_records<true>(modeG, P.gate_hash, s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
+            HIPCHK(gc_launch_records<true>(modeG, s->recs, L, s->wordsG, s->decG, tab, s->R, s->P.w, s->P.p, sG));
             if (timed) HIPCHK(hipEventRecord(s->evs[3 * i + 1], sG));
             HIPCHK(hipEventRecord(s->evC[i], sG));
             HIPCHK(hipStreamWaitEvent(s->streamT, s->evC[i], 0));
@@ -692,11 +673,11 @@ extern "C" int lgc_solver_run(lgc_solver *s, int profile) {
         if (!profile) HIPCHK(hipStreamWaitEvent(sE, s->evG[i], 0));
         const bool done_e = pre && i < P.prefix_launches;                     // evaluated with the prefix
         if (profile) {
-            if (!done_e) HIPCHK(gc_launch<false>(s->recs, L, P.gate_hash, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
+            if (!done_e) HIPCHK(gc_launch<false>(s->recs, L, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
             HIPCHK(hipEventRecord(s->evs[3 * i + 2], sE));
         } else {
             if (L.mac_only) HIPCHK(hipEventRecord(s->evs[3 * i + 2], sE));   // start of the evaluate kernel
-            if (!done_e) HIPCHK(gc_launch<false>(s->recs, L, P.gate_hash, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
+            if (!done_e) HIPCHK(gc_launch<false>(s->recs, L, s->wordsE, s->decE, tab, s->R, s->P.w, s->P.p, sE));
             HIPCHK(hipEventRecord(s->evE[i], sE));
         }
         while (next_iter < P.iter_launch.size() && P.iter_launch[next_iter] == i)
@@ -773,8 +754,8 @@ extern "C" int lgc_solver_prefix_garble(lgc_solver *s) {
     HIPCHK(hipGetLastError());
     for (uint32_t i = 0; i < P.prefix_launches; i++) {
         Lbl *tab = reinterpret_cast<Lbl *>(reinterpret_cast<char *>(s->tab) + s->tab_off[i]);
-        HIPCHK(gc_launch<true>(s->recs, P.launches[i], P.gate_hash, s->wordsG, s->decG, tab, s->R, P.w, P.p, s->stream));
-        HIPCHK(gc_launch<false>(s->recs, P.launches[i], P.gate_hash, s->wordsE, s->decE, tab, s->R, P.w, P.p, s->stream));
+        HIPCHK(gc_launch<true>(s->recs, P.launches[i], s->wordsG, s->decG, tab, s->R, P.w, P.p, s->stream));
+        HIPCHK(gc_launch<false>(s->recs, P.launches[i], s->wordsE, s->decE, tab, s->R, P.w, P.p, s->stream));
     }
     HIPCHK(hipStreamSynchronize(s->stream));
     s->prefix_ready = true;
@@ -914,17 +895,8 @@ extern "C" void lgc_set_table_ring_slack(size_t bytes) {
     ring_slack_bytes() = bytes ? ((bytes + 4095) & ~(size_t)4095) : kRingSlackBytes;
     ring_cache().release(-1);                 // a parked ring was sized with the old slack
 }
-extern "C" int lgc_set_gate_hash(int kind) {
-    if (kind < 0 || kind >= GATE_HASH_KINDS) return lgc_fail(LGC_EINVAL, "gate hash %d: 0 (fixed-key AES-128) or 1 (Chaskey-12 permutation)", kind);
-    program_gate_hash() = kind;
-    return LGC_OK;
-}
-extern "C" int lgc_gate_hash(void) { return program_gate_hash(); }
-extern "C" const char *lgc_gate_hash_name(int kind) {
-    return kind == GATE_HASH_AES ? "aes128" : (kind == GATE_HASH_CHASKEY12 ? "chaskey12" : (const char *)0);
-}
-extern "C" int lgc_gate_hash_eval(int device, int kind, const uint8_t *labels, const uint64_t *tweaks, uint8_t *out, size_t n) {
-    if (kind < 0 || kind >= GATE_HASH_KINDS || !labels || !tweaks || !out) return lgc_fail(LGC_EINVAL, "gate hash kind / null argument");
+extern "C" int lgc_gate_hash_eval(int device, const uint8_t *labels, const uint64_t *tweaks, uint8_t *out, size_t n) {
+    if (!labels || !tweaks || !out) return lgc_fail(LGC_EINVAL, "null argument");
     DevFree dev_guard;
     int rc = lgc_need_device(device);
     if (rc) return rc;
@@ -935,7 +907,7 @@ extern "C" int lgc_gate_hash_eval(int device, int kind, const uint8_t *labels, c
     HIPCHK(hipMalloc(&dt, n * 8 + 8)); dev_guard.add(dt);
     HIPCHK(hipMemcpy(di, labels, n * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dt, tweaks, n * 8, hipMemcpyHostToDevice));
-    if (n) hipLaunchKernelGGL(gc_gate_hash_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, di, dt, dout, (uint32_t)n, kind);
+    if (n) hipLaunchKernelGGL(gc_gate_hash_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, di, dt, dout, (uint32_t)n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(out, dout, n * 16, hipMemcpyDeviceToHost));
     return LGC_OK;

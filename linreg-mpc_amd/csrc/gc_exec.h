@@ -183,8 +183,7 @@ GC_HD void exec_record(B &be, const Rec &r, int w, int p) {
         break;
     case OP_IDIVC:
         // c: the divisor; b | sb << 32: its multiplier m and sa: l = ceil(log2 c) (idivc_rec below)
-        if (GC_IDIVC_MAGIC) be.store(r.dst, C::divc(be, be.load(r.a), (uint64_t)r.b | ((uint64_t)(uint32_t)r.sb << 32), (int)r.sa, w));
-        else be.store(r.dst, C::divc_long(be, be.load(r.a), (uint64_t)r.c, w));
+        be.store(r.dst, C::divc(be, be.load(r.a), (uint64_t)r.b | ((uint64_t)(uint32_t)r.sb << 32), (int)r.sa, w));
         break;
     case OP_CONST:
         be.store(r.dst, be.sel(lanes(w), be.konst((uint64_t)r.a | ((uint64_t)r.b << 32)), be.zero()));

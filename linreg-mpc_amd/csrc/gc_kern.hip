@@ -1,17 +1,9 @@
-// gc_kern.hip -- one translation unit per (role, kernel family, gate hash): compiled with -DGC_KERN_G=0|1 (evaluator |
-// garbler), -DGC_KERN_PART=0|1|2|3 (MAC | generic, one wave per record | column-split | generic, 4 waves per record; the
-// garbler's part 2 also holds the table pass of critical-path garbling) and -DGC_KERN_HASH=0|1 (fixed-key AES | Chaskey-12
-// permutation; parts 0, 1, 3).  Fourteen units build in parallel instead of one that takes minutes.
+// gc_kern.hip -- one translation unit per (role, kernel family): compiled with -DGC_KERN_G=0|1 (evaluator | garbler) and
+// -DGC_KERN_PART=0|1|2|3 (MAC | generic, one wave per record | column-split | generic, 4 waves per record; the garbler's
+// part 2 also holds the table pass of critical-path garbling).  Eight units build in parallel instead of one that takes minutes.
 #include "gc_kernels.h"
 
-#ifndef GC_KERN_HASH
-#define GC_KERN_HASH 0
-#endif
-#if GC_KERN_HASH
-#define GC_CAT3_(a, b, c) a##b##_##c##h
-#else
 #define GC_CAT3_(a, b, c) a##b##_##c
-#endif
 #define GC_CAT3(a, b, c) GC_CAT3_(a, b, c)
 #if GC_KERN_G
 #define GC_ROLE_TAG g
@@ -22,7 +14,7 @@
 namespace gc {
 hipError_t GC_CAT3(gc_launch_records_, GC_ROLE_TAG, GC_KERN_PART)(LaunchMode m, const Rec *recs, const Launch &L, Lbl *words, uint64_t *dec,
                                                                    Lbl *tab, Lbl R, int w, int p, hipStream_t st) {
-    return gc_launch_records_impl<GC_KERN_G != 0, GC_KERN_PART, GC_KERN_HASH>(m, recs, L, words, dec, tab, R, w, p, st);
+    return gc_launch_records_impl<GC_KERN_G != 0, GC_KERN_PART>(m, recs, L, words, dec, tab, R, w, p, st);
 }
 // loads this translation unit's code object (first launch of any of its kernels does: ~5-10 ms) ahead of the first real launch
 __global__ void GC_CAT3(gc_kern_touch_kernel_, GC_ROLE_TAG, GC_KERN_PART)() {}
@@ -30,14 +22,14 @@ hipError_t GC_CAT3(gc_kern_touch_, GC_ROLE_TAG, GC_KERN_PART)(hipStream_t st) {
     hipLaunchKernelGGL(GC_CAT3(gc_kern_touch_kernel_, GC_ROLE_TAG, GC_KERN_PART), dim3(1), dim3(64), 0, st);
     return hipGetLastError();
 }
-#if GC_KERN_G && GC_KERN_PART == 2 && !GC_KERN_HASH
+#if GC_KERN_G && GC_KERN_PART == 2
 hipError_t gc_launch_tabfill(const Launch &L, const Lbl *stash, Lbl *tab, Lbl R, hipStream_t st) {
     return gc_launch_tabfill_impl(L, stash, tab, R, st);
 }
 #endif
 }  // namespace gc
-#if GC_SPLIT_TRACE && GC_KERN_PART == 2 && !GC_KERN_HASH
-// timing experiments only: the stamps of gc_split.h (GC_SPLIT_TRACE builds), and a reset
+#if GC_SPLIT_TRACE && GC_KERN_PART == 2
+// profiling builds only (-DGC_SPLIT_TRACE=1): the stamps of gc_split.h, and a reset
 #if GC_KERN_G
 extern "C" int lgc_dbg_split_trace_g(uint64_t *out, uint32_t *n, int reset) {
 #else

@@ -85,9 +85,6 @@ struct Program {
     // for every lambda (lambda enters after them, linear.oc:52-57): garbled once, shared by all circuits
     uint32_t shared_end, prefix_launches;
     uint64_t prefix_steps;
-    // the gate hash both roles run this program with (gc_aes.h: 0 = fixed-key AES, 1 = Chaskey-12 permutation): fixed when
-    // the program is built (program_gate_hash), like everything else the two roles must agree on
-    int gate_hash = 0;
 
     // ---- builder state
     size_t merge_hint = 1;       // this program will be replicated this many times (replicate_program): the dot products of
@@ -297,9 +294,6 @@ struct Program {
             const size_t by_slot = (size_t)(cap_steps / ((uint64_t)kMinRecsPerLaunch * s1));
             if (chi > by_slot) chi = by_slot > c0 ? by_slot : c0;
         }
-#ifdef GC_X_MV_WAVES_ENV     /* timing experiments only (scripts/exp/mvw_ab3.sh): one chunk size, no shaping */
-        if (const char *e = getenv("LGC_X_MV_CHUNK")) if (atol(e) > 0 && (size_t)atol(e) >= clo) { chi = (size_t)atol(e); clo = chi; }
-#endif
         const size_t rep = merge_hint ? merge_hint : 1;
         std::vector<Rec> recs_best, recs_try;
         std::vector<std::pair<uint32_t, uint32_t>> parts, parts_try;
@@ -537,12 +531,7 @@ static const size_t kTargetWaves = 8192;
 static const size_t kMvRecords64 = 131072;       // matrix-vector products of CGD, 64-bit (chunk floor: one Karatsuba pair)
 static const size_t kMvRecords32 = 65536;        // ... 32-bit (two-chunk OP_MAC2 records; 131 072 costs 5 % more steps)
 static const size_t kFactRecords = 65536;        // a column step of Cholesky / LDL^T (d = 500: 12.6 -> 12.0 s)
-static inline size_t x_fact_waves() {     // records per column step of the factorisations
-#ifdef GC_X_MV_WAVES_ENV     /* timing experiments only (scripts/exp/shape_ab.sh) */
-    if (const char *e = getenv("LGC_X_CHOL_WAVES")) if (atol(e) > 0) return (size_t)atol(e);
-#endif
-    return kFactRecords;
-}
+static inline size_t x_fact_waves() { return kFactRecords; }     // records per column step of the factorisations
 
 // Build the whole phase-2 program.
 //   normalize = 1: data-provider path (linear.oc:52-65): diag += lambda, off-diag and b divided by d
@@ -551,18 +540,12 @@ static inline size_t x_fact_waves() {     // records per column step of the fact
 // Karatsuba products in the matrix-vector launches of CGD (64-bit; Circ::mack2).  Process-wide switch for A/B runs
 // (lgc_set_karatsuba); garbler and evaluator must agree, as on everything else that shapes the program.
 inline int &program_karatsuba() { static int on = 1; return on; }
-// OP_DIVB for CGD's g / max|g| at w = 64 (LGC_BOUNDED_DIV=0 in the environment: the full divider, for A/B runs)
-inline int &program_bounded_div() {
-    static int on = [] { const char *e = getenv("LGC_BOUNDED_DIV"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }();
-    return on;
-}
-// Gate hash of the programs built from now on (lgc_set_gate_hash): process-wide, the two roles of a solve must agree.
-inline int &program_gate_hash() { static int kind = 0; return kind; }
+// OP_DIVB (p + 1 quotient bits) for CGD's g / max|g| at w = 64
+inline int program_bounded_div() { return 1; }
 
 inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters, size_t nshares,
                           int normalize, uint64_t lambda_fixed, int reveal_ab, int trace) {
     P.w = w; P.p = p; P.d = d; P.nshares = nshares;
-    P.gate_hash = program_gate_hash();
     const size_t T = d * (d + 1) / 2;
     P.T = T;
     const uint32_t D = (uint32_t)d;
@@ -646,15 +629,9 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
         const uint32_t sc_ip = P.alloc(2 * Program::inner_scratch(d));
         // records per matrix-vector product: enough to fill the chip -- together with the other circuits of a merged sweep
         size_t mv_target = w == 64 ? kMvRecords64 : kMvRecords32;
-#ifdef GC_X_MV_WAVES_ENV     /* timing experiments only: records per matrix-vector launch from the environment */
-        if (const char *e = getenv("LGC_X_MV_WAVES")) if (atol(e) > 0) mv_target = (size_t)atol(e);
-#endif
         size_t mv_waves = mv_target / (P.merge_hint ? P.merge_hint : 1);
         if (mv_waves < 2 * d) mv_waves = 2 * d < mv_target ? 2 * d : mv_target;     // at least two records per row
         size_t kara_target = kTargetWaves;
-#ifdef GC_X_MV_WAVES_ENV     /* timing experiments only */
-        if (const char *e = getenv("LGC_X_KARA_MIN")) if (atol(e) > 0) kara_target = (size_t)atol(e);
-#endif
         size_t kara_min = kara_target / (P.merge_hint ? P.merge_hint : 1);          // Karatsuba products where d * d exceeds this
         if (kara_min < 2 * d) kara_min = 2 * d < kara_target ? 2 * d : kara_target;
         const uint32_t sc_dot = P.alloc_dots(d * d, d, mv_waves);
@@ -851,7 +828,6 @@ inline void build_program(Program &P, int alg, size_t d, int w, int p, int iters
 static const uint64_t kSweepCircuitStride = 1ull << 36;
 inline bool replicate_program(Program &P, const Program &P0, size_t count, const uint64_t *lambda_fixed, size_t first_copy = 0) {
     P.w = P0.w; P.p = P0.p; P.d = P0.d; P.T = P0.T; P.nshares = P0.nshares;
-    P.gate_hash = P0.gate_hash;
     P.cap_steps = P0.cap_steps;
     P.shared_end = P0.shared_end;
     P.word_stride = P0.n_words - P0.shared_end;

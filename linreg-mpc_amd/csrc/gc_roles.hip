@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "../../include/linreg_gc.h"
+#include "../../include/linreg_gc_sweep.h"
+#include "../../include/linreg_gc_debug.h"
 #include "hip_scope.h"
 #include "gc_device.h"
 #include "gc_program.h"
@@ -149,7 +151,7 @@ extern "C" int lgc_party_share_prefix(lgc_party *dst, const lgc_party *src) {
     if (!dst || !src) return lgc_fail(LGC_EINVAL, "null party");
     const Program &D = dst->P, &S = src->P;
     if (dst->role != src->role || D.shared_end != S.shared_end || D.prefix_launches != S.prefix_launches || !S.prefix_launches ||
-        D.w != S.w || D.p != S.p || D.d != S.d || D.T != S.T || D.nshares != S.nshares || D.gate_hash != S.gate_hash ||
+        D.w != S.w || D.p != S.p || D.d != S.d || D.T != S.T || D.nshares != S.nshares ||
         D.prefix_steps != S.prefix_steps || D.in_base != S.in_base)
         return lgc_fail(LGC_EINVAL, "the parties are not blocks of the same sweep");
     // the prefix itself: the same records in the same launches (what the source garbled is what the destination's circuits read)
@@ -238,8 +240,8 @@ static int party_create(lgc_party **out, int device, const lgc_system *sys, int 
     }
     p->hdec.resize(P.n_reveal + 1);
     // the code objects of this role's record kernels now (creation runs beside phase 1), not inside the first launches
-    if (role == LGC_ROLE_GARBLER) RCHK(gc_preload<true>(P.launches, P.gate_hash, 0));
-    else RCHK(gc_preload<false>(P.launches, P.gate_hash, 0));
+    if (role == LGC_ROLE_GARBLER) RCHK(gc_preload<true>(P.launches, 0));
+    else RCHK(gc_preload<false>(P.launches, 0));
     RCHK(hipDeviceSynchronize());
     *out = p;
     lgc_trace_mark(role == LGC_ROLE_GARBLER ? "lib: word file, records, input zero-labels on the device" : "lib: word file and records on the device");
@@ -264,7 +266,7 @@ extern "C" int lgc_party_program_fingerprint(const lgc_party *p, uint8_t out[32]
     auto mix = [&](uint64_t v) {
         for (int k = 0; k < 4; k++) { h[k] = (h[k] ^ v) * mul[k]; h[k] ^= h[k] >> 29; }
     };
-    const uint64_t head[] = {(uint64_t)P.w, (uint64_t)P.p, (uint64_t)P.d, (uint64_t)P.nshares, (uint64_t)P.gate_hash, P.n_words, P.n_reveal,
+    const uint64_t head[] = {(uint64_t)P.w, (uint64_t)P.p, (uint64_t)P.d, (uint64_t)P.nshares, (uint64_t)P.n_words, P.n_reveal,
                              P.in_base, P.rv_beta, P.replicas, P.shared_end, P.prefix_launches, P.total_steps, P.total_gates,
                              (uint64_t)P.recs.size(), (uint64_t)P.launches.size()};
     for (uint64_t v : head) mix(v);
@@ -374,7 +376,7 @@ extern "C" int lgc_party_set_input_labels(lgc_party *p, size_t share, const uint
 // private buffer for the largest launch of all -- 2.6 GB at d = 100, allocated inside the first garbling call.
 static size_t party_stash_bytes(const lgc_party *p) {
     uint64_t steps = 0;
-    const uint32_t lim = kSplitMaxRecs > kQuadOnePerCu ? kSplitMaxRecs : kQuadOnePerCu;
+    const uint32_t lim = kSplitMaxRecs;
     for (const Launch &L : p->P.launches)
         if (L.nrec <= lim && L.steps > steps) steps = L.steps;
     return (size_t)steps * 2048 + 16;
@@ -391,7 +393,7 @@ template <bool G>
 static hipError_t party_launch(lgc_party *p, const Launch &L, Lbl *tab = 0, int stages = 3, bool *was_crit = 0) {
     if (!tab) { hipError_t e = party_need_tab(p); if (e != hipSuccess) return e; }
     else if (G) { hipError_t e = party_need_tab(p, party_stash_bytes(p)); if (e != hipSuccess) return e; }
-    return gc_launch<G>(p->recs, L, p->P.gate_hash, p->words, p->dec, tab ? tab : p->tab, p->R, p->P.w, p->P.p, 0, (G && tab) ? p->tab : (Lbl *)0,
+    return gc_launch<G>(p->recs, L, p->words, p->dec, tab ? tab : p->tab, p->R, p->P.w, p->P.p, 0, (G && tab) ? p->tab : (Lbl *)0,
                         stages, was_crit);
 }
 
@@ -515,7 +517,6 @@ static size_t default_ring_bytes(const Program &P) {
     size_t slack = largest / 2;
     if (slack < ((size_t)64 << 20)) slack = (size_t)64 << 20;
     if (slack > ((size_t)4 << 30)) slack = (size_t)4 << 30;
-    if (const char *e = getenv("LGC_PARTY_RING_SLACK_MB")) if (atol(e) > 0) slack = (size_t)atol(e) << 20;   // experiments (scripts/exp/two_proc_shape_ab.sh)
     return largest + slack + 4096;
 }
 extern "C" int lgc_party_ring_create_bytes(lgc_party *p, size_t ring_bytes, uint8_t handle_out[64], size_t *ring_bytes_out) {
@@ -613,15 +614,15 @@ extern "C" int lgc_party_garble_ring_begin(lgc_party *p, size_t launch) {
     const int k = (int)(p->n_crit & 1);
     Lbl *stash = (k && p->stash2) ? p->stash2 : p->tab;
     // the launch's mode is decided ONCE (it reads a run-time switch): record kernel and table pass cannot disagree
-    const LaunchMode m = gc_launch_mode(L, true, p->P.gate_hash);
+    const LaunchMode m = gc_launch_mode(L, true);
     const bool crit = gc_mode_is_crit(m, L);
     if (!crit) {
-        RCHK(gc_launch_records<true>(m, p->P.gate_hash, p->recs, L, p->words, p->dec, tab, p->R, p->P.w, p->P.p, 0));
+        RCHK(gc_launch_records<true>(m, p->recs, L, p->words, p->dec, tab, p->R, p->P.w, p->P.p, 0));
         RCHK(hipEventRecord(p->ev_done[slot], 0));
     } else {
         // this stash was last read by the table pass of an earlier launch: the record kernel must not overwrite it before
         if (p->stash_user[k] >= 0) RCHK(hipStreamWaitEvent(0, p->ev_done[p->stash_user[k] % kPartyEvents], 0));
-        RCHK(gc_launch_records<true>(m, p->P.gate_hash, p->recs, L, p->words, p->dec, stash, p->R, p->P.w, p->P.p, 0));
+        RCHK(gc_launch_records<true>(m, p->recs, L, p->words, p->dec, stash, p->R, p->P.w, p->P.p, 0));
         RCHK(hipEventRecord(p->ev_rec[slot], 0));
         RCHK(hipStreamWaitEvent(p->s_pass, p->ev_rec[slot], 0));
         RCHK(gc_launch_tabfill(L, stash, tab, p->R, p->s_pass));

@@ -38,9 +38,6 @@ __device__ __forceinline__ uint32_t hash_split(const LdsTab4 &lt, const uint32_t
     const uint32_t t = quad_perm<0x4E>(x);                 // lanes 0,1 <- columns 2,3 ; lanes 2,3 <- columns 0,1
     const uint32_t k = (c < 2) ? (t ^ twc) : (x ^ t);
     uint32_t s = k ^ rkl[0];
-#ifdef GC_X_NOHASH          /* timing experiments only (scripts/exp): results are wrong with it */
-    return s;
-#endif
 #pragma unroll
     for (int rnd = 1; rnd < 10; rnd++) {
         // (looking up with the own column and routing the results as DPP operands of the XORs saves the three moves but

@@ -23,6 +23,8 @@
 #include <vector>
 
 #include "../../include/linreg_gc.h"
+#include "../../include/linreg_gc_sweep.h"
+#include "../../include/linreg_gc_debug.h"
 #include "hip_scope.h"
 #include "gc_device.h"
 

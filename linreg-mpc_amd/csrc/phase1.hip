@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "../../include/linreg_gc.h"
+#include "../../include/linreg_gc_sweep.h"
+#include "../../include/linreg_gc_debug.h"
 #include "hip_scope.h"
 #include "gc_device.h"
 
@@ -376,14 +378,10 @@ static thread_local P1Scratch t_scratch;
 // provider processes share one GPU in the single-box runs.  A stream (= a hardware queue) per worker thread
 // oversubscribes the queues, which the scheduler then time-slices at millisecond granularity: config 4 takes
 // 65.7 s that way against 21.5 s with all calls of a process taking turns on ONE stream -- measured again in
-// round 2 with one call per batch of 16 pairs (LGC_P1_THREAD_STREAMS=1 selects the per-thread streams).
+// round 2 with one call per batch of 16 pairs (per-thread streams: not kept).
 #include <mutex>
 static std::mutex g_p1_mutex;
-static bool p1_shared_stream() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("LGC_P1_THREAD_STREAMS"); v = (e && *e == '1') ? 0 : 1; }
-    return v == 1;
-}
+static bool p1_shared_stream() { return true; }
 struct P1Serial {
     bool locked;
     P1Serial() : locked(p1_shared_stream()) { if (locked) g_p1_mutex.lock(); }

@@ -237,9 +237,7 @@ int main(int argc, char **argv) {
           "         --lambdas=l1,l2,...: regularisation sweep -- one circuit per value on the same shares (the data\n"
           "                  providers share their inputs once); [Lambda] is then ignored\n"
           "         --devices=g0,g1,...: (parties 1 and 2, with --lambdas and --table_ring) contiguous blocks of the sweep on\n"
-          "                  these GPUs, one block per entry (an index may repeat); without it LINREG_DEVICE (default 0)\n"
-          "         --gate_hash=<aes128|chaskey12>: (parties 1 and 2, the same on both) the fixed permutation of the garbling\n"
-          "                  hash: fixed-key AES-128 as in the reference (default), or the table-free Chaskey-12 permutation", argv[0]);
+          "                  these GPUs, one block per entry (an index may repeat); without it LINREG_DEVICE (default 0)", argv[0]);
     char *end;
     errno = 0;
     int precision = (int)strtol(argv[2], &end, 10);
@@ -288,11 +286,6 @@ int main(int argc, char **argv) {
                 q = *e2 ? e2 + 1 : e2;
             }
             check(n_devices > 0, "--devices wants at least one index");
-        }
-        else if (!strncmp(argv[i], "--gate_hash=", 12)) {
-            int kind = -1;
-            for (int k = 0; lgc_gate_hash_name(k); k++) if (!strcmp(argv[i] + 12, lgc_gate_hash_name(k))) kind = k;
-            check(kind >= 0 && lgc_set_gate_hash(kind) == LGC_OK, "--gate_hash wants aes128 or chaskey12");
         }
         else if (!strcmp(argv[i], "--table_ring")) ring_slots = TABLE_RING_BYTES;
         else if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) {}
@@ -655,11 +648,6 @@ int main(int argc, char **argv) {
 done:
     g_protocol_over = 1;
     TRACE("protocol done");
-    {   /* experiment (scripts/exp/provider_linger.sh): a data provider's exit -- its HIP runtime going away -- falls into the
-         * table phase of parties 1 and 2; LINREG_PROVIDER_LINGER_MS makes the providers wait that long before they leave */
-        const char *lg = getenv("LINREG_PROVIDER_LINGER_MS");
-        if (lg && party > 2 && atoi(lg) > 0) usleep((useconds_t)atoi(lg) * 1000u);
-    }
     for (int k = 1; k < n_devices; k++) if (blocks[k]) lgc_party_destroy(blocks[k]);
     if (party_obj) lgc_party_destroy(party_obj);           /* (wipes label material before its memory is released) */
     node_destroy(&self);

@@ -15,6 +15,8 @@
 #include <time.h>
 #include <unistd.h>
 #include "../../include/linreg_gc.h"
+#include "../../include/linreg_gc_sweep.h"
+#include "../../include/linreg_gc_debug.h"
 #include "baseot.h"
 #include "config.h"
 #include "net.h"
@@ -286,7 +288,7 @@ static void *ti_worker_main(void *arg) {
          * run the pipelined form of that role */
         size_t cnt = 0, as_b = 0;
         for (size_t k = 0; k < w->npairs; k++) if (w->pairs[k].peer == w->peer) { cnt++; as_b += !w->pairs[k].is_a; }
-        if (cnt && (as_b == cnt || as_b == 0) && !getenv("LINREG_TI_LOCKSTEP")) {
+        if (cnt && (as_b == cnt || as_b == 0)) {
             const ti_pair **mine = malloc(cnt * sizeof *mine);
             size_t m = 0;
             for (size_t k = 0; k < w->npairs; k++) if (w->pairs[k].peer == w->peer) mine[m++] = &w->pairs[k];
@@ -641,8 +643,7 @@ int run_party(node *self, config *c, int precision, int precision_p2, int w1, in
                  * (1.6e9 OTs between two provider processes on one GPU, scripts/exp/ot_batch_ab.sh): phase 1 through at 0.46 s with
                  * 2^24, 0.58 s with 2^25 (rounds 2-3), 0.8 / 1.2 / 2.2 s with 2^26..28 -- the session's buffers grow with the batch
                  * and a fresh device or page-locked allocation costs more than the per-batch tokens do */
-                int ot_log = 24;
-                { const char *e_ = getenv("LINREG_OT_BATCH_LOG2"); if (e_ && atoi(e_) >= 20 && atoi(e_) <= 30) ot_log = atoi(e_); }   /* experiments */
+                const int ot_log = 24;
                 size_t per = ((size_t)1 << ot_log) / (n * (size_t)w1);
                 if (per < 1) per = 1;
                 if (per > npairs) per = npairs;

@@ -14,6 +14,8 @@
 #include <time.h>
 #include <unistd.h>
 #include "../../include/linreg_gc.h"
+#include "../../include/linreg_gc_sweep.h"
+#include "../../include/linreg_gc_debug.h"
 #include "baseot.h"
 #include "config.h"
 #include "net.h"
@@ -130,11 +132,9 @@ static size_t enumerate_cross(config *c, xpair **out) {
 enum { kTiRingSlots = 3 };
 /* pairs per batch: a batch costs every party a fixed ~0.5 ms of tokens and device synchronisations whatever its size, and
  * config 4 has 1e5 pairs of 5e4 words -- with 64 MiB slots (167 pairs, 602 batches; rounds 2-3) its phase 1 was 0.55 s of
- * which two thirds were those fixed costs.  LINREG_TI_SLOT_MB overrides the slot size (experiments). */
+ * which two thirds were those fixed costs. */
 static size_t ti_ring_batch(size_t n) {
-    size_t slot_mb = 256;
-    const char *e = getenv("LINREG_TI_SLOT_MB");
-    if (e && atoi(e) > 0) slot_mb = (size_t)atoi(e);
+    const size_t slot_mb = 256;
     size_t b = (slot_mb << 20) / (n * 8);
     if (b < 1) b = 1;
     if (b > 1024) b = 1024;

@@ -18,6 +18,8 @@
 #include <unistd.h>
 
 #include "../../include/linreg_gc.h"
+#include "../../include/linreg_gc_sweep.h"
+#include "../../include/linreg_gc_debug.h"
 #include "baseot.h"
 #include "config.h"
 #include "net.h"

@@ -6,6 +6,8 @@
 #include "config.h"
 #include "net.h"
 #include "../../include/linreg_gc.h"
+#include "../../include/linreg_gc_sweep.h"
+#include "../../include/linreg_gc_debug.h"
 
 #define check(cond, ...)                              \
     do {                                              \

@@ -15,6 +15,8 @@
 #include <time.h>
 #include <unistd.h>
 #include "../../include/linreg_gc.h"
+#include "../../include/linreg_gc_sweep.h"
+#include "../../include/linreg_gc_debug.h"
 #include "baseot.h"
 #include "config.h"
 #include "net.h"
@@ -352,8 +354,11 @@ int table_link_send_range(table_link *l, size_t lo, size_t hi) {
          * itself, evaluator's marks, six runs each on one box (scripts/exp/ring_modes_ab.sh): d = 20 Cholesky (147 launches)
          * 0.0436 s against 0.0448 s with the synchronous loop, d = 100 CGD-15 (355) 0.140 against 0.147, d = 200 Cholesky
          * (1 400) 1.30 against 1.35: 3-5 % of a phase that is a tenth of a small run -- taken from a thousand launches on.
-         * LINREG_RING_ASYNC=1 / 0 forces it on / off. */
-        const char *force = getenv("LINREG_RING_ASYNC");
+         * LINREG_RING_ASYNC=1 / 0 forces it on / off in bin/linreg_testhooks (the tests run every form on the README example). */
+        const char *force = 0;
+#ifdef LINREG_TEST_HOOKS
+        force = getenv("LINREG_RING_ASYNC");
+#endif
         const int use_async = force ? atoi(force) : (l->end - l->start >= 1000 ? 1 : kRingAsyncShort);
         /* 2: the same with the table passes left on the record kernels' stream (lgc_party_garble_ring_streams(po, 1)): no
          * queue to create, and still no host round trip between the garbler's launches */
@@ -451,7 +456,7 @@ int programs_agree(node *self, int peer, lgc_party *po, int sending) {
     }
     if (!ok)
         fprintf(stderr, "the CSP and the Evaluator built different programs: algorithm, iterations, precision, widths, --lambdas, "
-                        "--gate_hash and --devices must be the same on parties 1 and 2\n");
+                        "--prec_phase2 and --devices must be the same on parties 1 and 2\n");
     return ok ? 0 : 1;
 }
 

@@ -46,12 +46,6 @@ int main(int argc, char **argv) {
         if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) continue;
         if (sscanf(argv[i], "--table_chunk_mb=%ld", &chunk_mb) == 1 && chunk_mb > 0) continue;
         { int lanes = 0; if (sscanf(argv[i], "--table_lanes=%i", &lanes) == 1) { protocol_set_table_lanes(lanes); continue; } }
-        if (!strncmp(argv[i], "--gate_hash=", 12)) {       /* aes128 (default, the reference's) | chaskey12; the same on both parties */
-            int kind = -1;
-            for (int k = 0; lgc_gate_hash_name(k); k++) if (!strcmp(argv[i] + 12, lgc_gate_hash_name(k))) kind = k;
-            check(kind >= 0 && lgc_set_gate_hash(kind) == LGC_OK, "--gate_hash wants aes128 or chaskey12");
-            continue;
-        }
         if (!strncmp(argv[i], "--host=", 7)) host = argv[i] + 7;
     }
     int num_iterations = !strcmp(algorithm, "cgd") ? atoi(argv[5]) : 0;

@@ -55,7 +55,7 @@ class ProgramInfo(C.Structure):
                 ("total_gates", C.c_uint64), ("max_launch_steps", C.c_uint64),
                 ("replicas", C.c_uint32), ("word_stride", C.c_uint32), ("reveal_stride", C.c_uint32),
                 ("shared_end", C.c_uint32), ("prefix_launches", C.c_uint32), ("prefix_steps", C.c_uint64),
-                ("total_xors", C.c_uint64), ("gate_hash", C.c_int)]
+                ("total_xors", C.c_uint64)]
 
 
 _lib = None
@@ -623,30 +623,15 @@ def set_table_ring_slack(nbytes):
 GATE_HASH = {"aes128": 0, "chaskey12": 1}
 
 
-def set_gate_hash(kind="aes128"):
-    """gate hash of the solvers / parties / programs created from now on: "aes128" (fixed-key AES, the reference's and the
-    default) or "chaskey12" (table-free ARX permutation: include/linreg_gc.h, lgc_set_gate_hash).  Both roles must agree."""
-    k = GATE_HASH[kind] if isinstance(kind, str) else int(kind)
-    lib().lgc_set_gate_hash.argtypes = [C.c_int]; lib().lgc_set_gate_hash.restype = C.c_int
-    _chk(lib().lgc_set_gate_hash(k))
-
-
-def gate_hash():
-    lib().lgc_gate_hash.restype = C.c_int
-    k = lib().lgc_gate_hash()
-    return [n for n, v in GATE_HASH.items() if v == k][0]
-
-
-def gate_hash_eval(kind, labels, tweaks, device=0):
-    """H(x, t) of the given kind on the device: labels (n, 16) uint8, tweaks (n,) uint64 -> (n, 16) uint8"""
-    k = GATE_HASH[kind] if isinstance(kind, str) else int(kind)
+def gate_hash_eval(labels, tweaks, device=0):
+    """the gate hash H(x, t) on the device: labels (n, 16) uint8, tweaks (n,) uint64 -> (n, 16) uint8"""
     x = np.ascontiguousarray(labels, dtype=np.uint8).reshape(-1, 16)
     t = np.ascontiguousarray(tweaks, dtype=np.uint64).reshape(-1)
     assert len(t) == len(x)
     out = np.zeros_like(x)
     L = lib()
-    L.lgc_gate_hash_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]; L.lgc_gate_hash_eval.restype = C.c_int
-    _chk(L.lgc_gate_hash_eval(device, k, x.ctypes.data, t.ctypes.data, out.ctypes.data, len(x)))
+    L.lgc_gate_hash_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]; L.lgc_gate_hash_eval.restype = C.c_int
+    _chk(L.lgc_gate_hash_eval(device, x.ctypes.data, t.ctypes.data, out.ctypes.data, len(x)))
     return out
 
 

@@ -48,19 +48,9 @@ static inline void aesni_n(__m128i s[N]) {
         for (int b = 0; b < N; b++) s[b] = _mm_aesenc_si128(s[b], g_rk[r]);
     for (int b = 0; b < N; b++) s[b] = _mm_aesenclast_si128(s[b], g_rk[10]);
 }
-// the permutation of the gate hash (gc_aes.h): kind 0 = fixed-key AES (AES-NI), 1 = Chaskey-12 (the checker of
-// lgc_set_gate_hash(1); word i of the block = state word i)
-static int g_gate_hash = 0;
+// the permutation of the gate hash (gc_aes.h): fixed-key AES, here through AES-NI
 template <int N>
-static inline void gate_perm_n(__m128i s[N]) {
-    if (g_gate_hash == 0) { aesni_n<N>(s); return; }
-    for (int b = 0; b < N; b++) {
-        uint32_t v[1][4];
-        _mm_storeu_si128((__m128i *)v[0], s[b]);
-        chaskey12_permute_n<1>(v);
-        s[b] = _mm_loadu_si128((const __m128i *)v[0]);
-    }
-}
+static inline void gate_perm_n(__m128i s[N]) { aesni_n<N>(s); }
 // sigma(x) ^ tweak  (gc_aes.h: hash_prep)
 static inline __m128i hprep(__m128i x, uint64_t tw) {
     __m128i sw = _mm_shuffle_epi32(x, 0x4E);                          // (x2,x3,x0,x1)
@@ -398,41 +388,16 @@ void gcc_aes_encrypt_ttable(const uint8_t *in, uint8_t *out, size_t n) {
         memcpy(out + 16 * i, s[0], 16);
     }
 }
-// which permutation gcc_garble_run / gcc_eval_run hash with (0: fixed-key AES, 1: Chaskey-12); returns the previous kind
-int gcc_set_gate_hash(int kind) {
-    int old = g_gate_hash;
-    if (kind == 0 || kind == 1) g_gate_hash = kind;
-    return old;
-}
-// H(x, t) of the given kind through the shared scalar code of gc_aes.h (hash_n)
-void gcc_gate_hash(int kind, const uint8_t *x, const uint64_t *tweak, uint8_t *out, size_t n) {
+// H(x, t) through the shared scalar code of gc_aes.h (hash_n)
+void gcc_gate_hash(const uint8_t *x, const uint64_t *tweak, uint8_t *out, size_t n) {
     init();
     for (size_t i = 0; i < n; i++) {
         Lbl l, o;
         memcpy(&l, x + 16 * i, 16);
-        if (kind == 1) {
-            HostNoTab nt;
-            hash_n<1, HostNoTab>(nt, g_t.rk, &l, &tweak[i], &o);
-        } else {
-            HostTab ht = {g_t.te0};
-            hash_n<1, HostTab>(ht, g_t.rk, &l, &tweak[i], &o);
-        }
+        HostTab ht = {g_t.te0};
+        hash_n<1, HostTab>(ht, g_t.rk, &l, &tweak[i], &o);
         memcpy(out + 16 * i, &o, 16);
     }
-}
-// `rounds` applications of the Chaskey round (gc_aes.h: chaskey_round; 12 = the permutation of gate hash 1) and of its
-// inverse (a second piece of code): tests pin the round to the published Chaskey test vectors (8 rounds) through these
-void gcc_chaskey(const uint8_t in[16], uint8_t out[16], int rounds) {
-    uint32_t v[4];
-    memcpy(v, in, 16);
-    for (int r = 0; r < rounds; r++) chaskey_round(v[0], v[1], v[2], v[3]);
-    memcpy(out, v, 16);
-}
-void gcc_chaskey_inverse(const uint8_t in[16], uint8_t out[16], int rounds) {
-    uint32_t v[4];
-    memcpy(v, in, 16);
-    for (int r = 0; r < rounds; r++) chaskey_round_inverse(v[0], v[1], v[2], v[3]);
-    memcpy(out, v, 16);
 }
 void gcc_hash(const uint8_t x[16], uint64_t tweak, uint8_t out[16]) {
     init();

@@ -33,9 +33,7 @@ class GcCpu:
         L.gcc_aes_encrypt.argtypes = [vp, vp, sz]
         L.gcc_aes_encrypt_ttable.argtypes = [vp, vp, sz]
         L.gcc_hash.argtypes = [vp, u64, vp]
-        L.gcc_set_gate_hash.argtypes = [ci]; L.gcc_set_gate_hash.restype = ci
-        L.gcc_gate_hash.argtypes = [ci, vp, vp, vp, sz]
-        L.gcc_chaskey.argtypes = [vp, vp, ci]; L.gcc_chaskey_inverse.argtypes = [vp, vp, ci]
+        L.gcc_gate_hash.argtypes = [vp, vp, vp, sz]
         L.gcc_aes_ctr.argtypes = [C.c_char_p, u64, u64, vp]
         L.gcc_iknp_extend.argtypes = [vp, vp, C.c_char_p, vp, u64, u64, vp, vp, vp]
         L.gcc_iknp_gilboa.argtypes = [vp, vp, C.c_char_p, vp, vp, u64, u64, ci, u64, vp, vp, vp]
@@ -66,22 +64,11 @@ class GcCpu:
         self.lib.gcc_rec_cost(op, cnt, w, p, C.byref(s), C.byref(g))
         return s.value, g.value
 
-    def set_gate_hash(self, kind):
-        """permutation of the gate hash in garble_eval (0: fixed-key AES, 1: Chaskey-12); returns the previous kind"""
-        return self.lib.gcc_set_gate_hash(int(kind))
-
-    def gate_hash(self, kind, labels, tweaks):
+    def gate_hash(self, labels, tweaks):
         x = np.ascontiguousarray(labels, dtype=np.uint8).reshape(-1, 16)
         t = np.ascontiguousarray(tweaks, dtype=np.uint64).reshape(-1)
         out = np.zeros_like(x)
-        self.lib.gcc_gate_hash(int(kind), _p(x), _p(t), _p(out), len(x))
-        return out
-
-    def chaskey(self, block, rounds=12, inverse=False):
-        """`rounds` Chaskey rounds (or inverse rounds) on a 16-byte block (state word i = little-endian word i)"""
-        x = np.ascontiguousarray(block, dtype=np.uint8).reshape(16)
-        out = np.zeros(16, dtype=np.uint8)
-        (self.lib.gcc_chaskey_inverse if inverse else self.lib.gcc_chaskey)(_p(x), _p(out), int(rounds))
+        self.lib.gcc_gate_hash(_p(x), _p(t), _p(out), len(x))
         return out
 
     def derive_R(self, seed):

@@ -142,12 +142,12 @@ def test_gate_hash_on_device_matches_openssl(lgc):
     x = rng.integers(0, 256, size=(2048 + 3, 16), dtype=np.uint8)
     t = rng.integers(0, 2 ** 63, size=len(x), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=len(x), dtype=np.uint64)
     x[0] = 0; t[0] = 0
-    assert np.array_equal(lgc.gate_hash_eval(0, x, t), openssl_gate_hash(x, t))
+    assert np.array_equal(lgc.gate_hash_eval(x, t), openssl_gate_hash(x, t))
     # half-gates by hand, hashes from the DEVICE: garbler side
     R = rng.integers(0, 256, size=16, dtype=np.uint8); R[0] |= 1
     a0 = rng.integers(0, 256, size=16, dtype=np.uint8); b0 = rng.integers(0, 256, size=16, dtype=np.uint8)
     gid = 123456789
-    H = lambda lab, tw: lgc.gate_hash_eval(0, lab[None, :], np.array([tw], dtype=np.uint64))[0]
+    H = lambda lab, tw: lgc.gate_hash_eval(lab[None, :], np.array([tw], dtype=np.uint64))[0]
     pa, pb = int(a0[0] & 1), int(b0[0] & 1)
     h0, h1, h2, h3 = H(a0, 2 * gid), H(a0 ^ R, 2 * gid), H(b0, 2 * gid + 1), H(b0 ^ R, 2 * gid + 1)
     TG = h0 ^ h1 ^ (R if pb else 0 * R)

@@ -113,9 +113,8 @@ README_RESULT = ["0.984331027786964", "0.792399824970372", "0.754117840176144", 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--use_ot"], ["--table_ring"], ["--ot_ring", "--table_ring"], ["--ti_ring", "--table_ring"],
-                                   ["--table_lanes=4"], ["--gate_hash=chaskey12"], ["--gate_hash=chaskey12", "--table_ring"],
-                                   ["--input_ring"], ["--ti_ring", "--input_ring", "--table_ring"]],
-                         ids=["ti", "ot", "table-ring", "ot-ring", "ti-ring", "table-lanes", "chaskey", "chaskey-ring", "input-ring", "all-rings"])
+                                   ["--table_lanes=4"], ["--input_ring"], ["--ti_ring", "--input_ring", "--table_ring"]],
+                         ids=["ti", "ot", "table-ring", "ot-ring", "ti-ring", "table-lanes", "input-ring", "all-rings"])
 def test_five_process_readme_example(tmp_path, golden_dir, extra):
     """bin/linreg examples/readme_example.in 56 $party cgd 10 0.001 (README.md:81) -> README.md:87"""
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
@@ -133,7 +132,7 @@ def test_five_process_readme_example(tmp_path, golden_dir, extra):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("odd", [["--gate_hash=chaskey12"], ["--prec_phase2=50"]], ids=["gate-hash", "precision"])
+@pytest.mark.parametrize("odd", [["--prec_phase2=50"]], ids=["precision"])
 def test_an_option_given_to_one_party_only_is_an_error_not_a_wrong_result(tmp_path, golden_dir, odd):
     """the CSP and the Evaluator compare the fingerprints of their programs before the first table moves
     (host/tables.c: programs_agree): party 1 alone gets the extra option"""
@@ -161,7 +160,8 @@ def test_five_process_ring_with_the_asynchronous_garbler(tmp_path, golden_dir, o
     subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
     infile = str(tmp_path / "readme.in")
     P = _rewrite_ports(os.path.join(golden_dir, "readme_example.in"), infile)
-    outs = _run_all(infile, P, ["56", alg, iters, "0.001", "--table_ring", "--input_ring"], env=dict(os.environ, LINREG_RING_ASYNC=async_ring))
+    outs = _run_all(infile, P, ["56", alg, iters, "0.001", "--table_ring", "--input_ring"], env=dict(os.environ, LINREG_RING_ASYNC=async_ring),
+                    exe_name="linreg_testhooks")      # the production binary picks the form by the program's length alone
     got = re.findall("-?[0-9]+\\.[0-9]+", outs[1].strip().splitlines()[-1])
     beta = oracle.linreg_file(os.path.join(golden_dir, "readme_example.in"), 56, -1, 64, 64, {"cholesky": 0, "cgd": 2}[alg], int(iters), 0.001)
     assert got == ["%.15f" % (int(b) / 2.0 ** 56) for b in beta]
