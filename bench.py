@@ -57,7 +57,7 @@ def compact_line(out, limit=COMPACT_LIMIT):
     8 000-character stdout tail, so the round's headline went unmeasured).  Everything else -- timelines, the sweep model,
     notes, definitions -- stays in the detail dict, which main() writes to bench_detail.json."""
     line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                       "vs_baseline", "dtype", "data", "exact_vs_oracle", "barrier_backend", "rccl_ranks", "devices", "gate_hash",
+                       "vs_baseline", "dtype", "data", "exact_vs_oracle", "barrier_backend", "rccl_ranks", "devices", "preflight",
                        "and_gates_per_solve", "ref_equiv_gates_per_s"))
     cfg = out.get("config") or {}
     line["config"] = {"workload": "d=%s CGD-%s %s-bit p=%s, two-party masked input, garbler+evaluator co-located; one system per GPU"
@@ -78,6 +78,8 @@ def compact_line(out, limit=COMPACT_LIMIT):
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "model", "total_cores"))
         line["cpu_baseline"]["spread"] = _r((cb.get("repeats") or {}).get("spread"))
         line["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:160]
+        if cb.get("whole_solve"):
+            line["cpu_baseline"]["whole_solve"] = _pick(cb["whole_solve"], ("value", "cores", "seconds", "circuit", "exact"))
         if cb.get("checker_error"):
             line["cpu_baseline"]["checker_error"] = str(cb["checker_error"])[:120]
     e2e = out.get("phase12")
@@ -86,6 +88,12 @@ def compact_line(out, limit=COMPACT_LIMIT):
         for res in e2e:
             p12[res.get("config", "?")] = _r(res.get("phase12_wall_s"), 4) if "error" not in res else "error: " + str(res["error"])[-80:]
         p12["all_exact"] = all(res.get("exact_vs_oracle") is True for res in e2e)
+        # a configuration that was run a second time (a party failed, or the first dispatch stalled behind the driver's memory
+        # wipe) says so here, with the wall clock of the attempt that was set aside (no silent best-of-two)
+        retried = {res.get("config", "?"): _r((res.get("first_attempt") or {}).get("phase12_wall_s"), 4) if res.get("first_attempt")
+                   else "failed: " + str(res.get("first_error"))[-60:] for res in e2e if res.get("attempts", 1) > 1}
+        if retried:
+            p12["retried_first_attempt"] = retried
         line["phase12"] = p12
     ring = out.get("two_process_ring")
     if ring:
@@ -100,12 +108,13 @@ def compact_line(out, limit=COMPACT_LIMIT):
         if model:                       # N = 1: what this GPU predicts for the sharded runs, one number each
             c["predicted_seconds_by_n_gpus"] = {k: _r(v["predicted_seconds"], 4) for k, v in model.items()}
         line["sweep64"] = c
-    if out.get("alt_gate_hash"):
-        line["alt_gate_hash"] = _pick(out["alt_gate_hash"], ("gate_hash", "seconds_per_solve", "and_gates_per_s", "same_integers_as_headline"))
+    ot = out.get("ot")
+    if ot:
+        line["ot"] = _pick(ot, ("ot_per_s", "gb_per_s", "frac_hbm", "batch", "exact")) if "error" not in ot else {"error": str(ot["error"])[-120:]}
     line["detail"] = out.get("detail_file", "bench_detail.json")
     txt = json.dumps(line, separators=(",", ":"))
     # belt and braces: drop the least important keys rather than ever print a line the driver cannot keep whole
-    for victim in ("alt_gate_hash", "devices", "two_process_ring", "phase12", "sweep64", "cpu_baseline"):
+    for victim in ("devices", "two_process_ring", "ot", "phase12", "sweep64", "cpu_baseline"):
         if len(txt) <= limit:
             break
         if victim == "devices":
@@ -115,6 +124,60 @@ def compact_line(out, limit=COMPACT_LIMIT):
             line.setdefault("dropped", []).append(victim)
         txt = json.dumps(line, separators=(",", ":"))
     return txt
+
+
+def ot_accounting(np, torch, lgc, npairs=64, n=10000, w=64, reps=4):
+    """IKNP extension + Gilboa correlation of `npairs` inner products of length n (config 3: n = 10^4, 64-bit, 6.4e5 OTs per
+    product; bin/linreg sends them in batches of 2^24 OTs): receiver start -> sender -> receiver finish, operands, u and y in
+    HBM (lgc_ot_*_set_device_io), HIP-synchronised wall clock of the three calls, best of `reps`.  Bytes: SURVEY.md 8(d)'s
+    48 B per extended OT on EACH side (16 B of PRG column material + 16 B transposed row + 8 B payload + the hash), both
+    sides on this GPU."""
+    import time
+    rng = np.random.default_rng(11)
+    seeds0 = rng.integers(0, 256, size=(128, 16), dtype=np.uint8); seeds1 = rng.integers(0, 256, size=(128, 16), dtype=np.uint8)
+    delta = rng.integers(0, 256, size=16, dtype=np.uint8)
+    dbits = np.unpackbits(delta, bitorder="little")
+    m = npairs * n * w
+    a = rng.integers(0, 2 ** 63, size=(npairs, n), dtype=np.uint64); b = rng.integers(0, 2 ** 63, size=(npairs, n), dtype=np.uint64)
+    S = lgc.OtSender(delta.tobytes(), np.where(dbits[:, None] == 1, seeds1, seeds0)); R = lgc.OtReceiver(seeds0, seeds1)
+    try:
+        S.set_device_io(True); R.set_device_io(True)
+        ub = lgc.lib().lgc_ot_u_bytes(m)
+        da = torch.from_numpy(a.view(np.int64)).cuda(); db = torch.from_numpy(b.view(np.int64)).cuda()
+        du = torch.empty(ub, dtype=torch.uint8, device="cuda"); dy = torch.empty(m, dtype=torch.int64, device="cuda")
+        dss = torch.zeros(npairs, dtype=torch.int64, device="cuda"); dsr = torch.zeros(npairs, dtype=torch.int64, device="cuda")
+        best = None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            R.gilboa_start_ptr(da.data_ptr(), npairs, n, w, du.data_ptr())
+            S.gilboa_ptr(db.data_ptr(), npairs, n, w, du.data_ptr(), dy.data_ptr(), dss.data_ptr())
+            R.gilboa_finish_ptr(dy.data_ptr(), dsr.data_ptr())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        ss, sr = dss.cpu().numpy().view(np.uint64), dsr.cpu().numpy().view(np.uint64)
+        M = (1 << 64) - 1
+        exact = all(((int(ss[q]) + int(sr[q])) & M) == (sum(int(x) * int(y) for x, y in zip(a[q], b[q])) & M) for q in (0, npairs - 1))
+    finally:
+        S.close(); R.close()
+    rate = m / best
+    gbs = 2 * 48.0 * rate / 1e9
+    return {"ot_per_s": rate, "gb_per_s": gbs, "frac_hbm": gbs / HBM_PEAK_GBS, "batch": m, "exact": bool(exact), "seconds": best,
+            "shape": "%d inner products x n = %d x %d bit (config 3's Gilboa batches), device-resident I/O" % (npairs, n, w),
+            "bytes_per_ot": "2 x 48 B algorithmic (SURVEY.md 8(d): both sides of the extension run on this GPU)"}
+
+
+def devices_preflight(torch, world, ndev, can_access=None):
+    """the device side of `--gpus N`: one distinct GPU per rank, and every pair can reach the other (xGMI peer access; RCCL
+    falls back to host memory without it, so a missing path is reported, not fatal).  can_access: injectable for the CPU tests."""
+    if world > ndev:
+        return {"error": "%d ranks but %d visible GPU(s): an RCCL group needs one GPU per rank (LGC_BENCH_BACKEND=gloo dry-runs "
+                         "N ranks on fewer GPUs)" % (world, ndev)}
+    can = can_access or torch.cuda.can_device_access_peer
+    missing = [(i, j) for i in range(world) for j in range(world) if i != j and not can(i, j)]
+    return {"distinct_devices": True, "peer_access": not missing,
+            "no_peer_path": ["%d->%d" % ij for ij in missing[:8]] or None}
 
 
 def cpu_info():
@@ -547,11 +610,6 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the 64-lambda sweep (BASELINE config 5)")
     ap.add_argument("--no-sweep-model", action="store_true", help="skip the modelled 2/4/8-GPU figures of the sweep (three more block runs)")
     ap.add_argument("--no-c4", action="store_true", help="skip the end-to-end run of config 4 (n = 50 000, d = 500: ~10 s to write its input, ~1 min to check it)")
-    ap.add_argument("--alt-hash", action="store_true", help="also time the headline solve and the sweep over gate hash 1 (Chaskey-12 "
-                    "permutation; an option of the library, never the headline): off by default")
-    ap.add_argument("--gate-hash", default="aes128", choices=["aes128", "chaskey12"],
-                    help="the gate hash of EVERY run of this invocation (lgc_set_gate_hash; default: fixed-key AES, the reference's). "
-                         "With chaskey12 the line reports that option's figures as value / roofline and says so in `gate_hash`")
     ap.add_argument("--sweep-d", type=int, default=100)
     ap.add_argument("--sweep-iters", type=int, default=15)
     ap.add_argument("--sweep-lambdas", type=int, default=64)
@@ -573,7 +631,7 @@ def main():
     traffic, traffic_detail = None, {"source": "not measured (--no-traffic, N > 1, or a non-default workload)"}
     if rank == 0 and world == 1 and not args.child and not args.no_traffic:
         traffic, traffic_detail = measure_hbm_traffic(["--d", str(args.d), "--iters", str(args.iters), "--width", str(args.width),
-                                                       "--precision", str(args.precision), "--gate-hash", args.gate_hash])
+                                                       "--precision", str(args.precision)])
 
     import numpy as np
     import torch                       # first: one HIP runtime per process (shared SONAME)
@@ -590,6 +648,13 @@ def main():
     if world > ndev and os.environ.get("LGC_BENCH_BACKEND", "nccl") == "nccl":
         raise SystemExit("bench.py: %d ranks but %d visible GPU(s): an RCCL group needs one GPU per rank "
                          "(LGC_BENCH_BACKEND=gloo dry-runs N ranks on fewer GPUs)" % (world, ndev))
+    # --gpus N preflight (rank 0 speaks for the node): N distinct devices exist and can reach each other -- the first run on a
+    # real multi-GPU node should fail HERE, with the pair named, not inside an RCCL broadcast
+    preflight = None
+    if world > 1 and os.environ.get("LGC_BENCH_BACKEND", "nccl") == "nccl":
+        preflight = devices_preflight(torch, world, ndev)
+        if preflight.get("error"):
+            raise SystemExit("bench.py --gpus %d: %s" % (world, preflight["error"]))
     torch.cuda.set_device(device_index)
     dist = None
     backend = os.environ.get("LGC_BENCH_BACKEND", "nccl")   # "gloo" only to dry-run N > 1 on one GPU
@@ -616,6 +681,8 @@ def main():
         ids = [None] * dist.get_world_size()
         dist.all_gather_object(ids, "%s/%d" % (os.uname().nodename, device_index))
         devices = sorted(set(ids))
+        if backend == "nccl" and len(devices) != dist.get_world_size():
+            raise SystemExit("bench.py: %d RCCL ranks on %d distinct GPU(s) (%s): one rank per GPU is required" % (dist.get_world_size(), len(devices), devices))
 
     d, iters, w, p = args.d, args.iters, args.width, args.precision
     T = d * (d + 1) // 2
@@ -639,8 +706,6 @@ def main():
     if w == 32:
         shares &= np.uint64(0xffffffff)
 
-    lgc.set_gate_hash(args.gate_hash)
-    hash_opt = ["--gate_hash=%s" % args.gate_hash] if args.gate_hash != "aes128" else []
     sysm = lgc.make_system(d, w, p, "cgd", iters, 0.0, 2, 0, 0, 0)
     solver = lgc.Solver(sysm, seed=bytes((rank + i) & 0xff for i in range(16)), device=device_index)
     solver.set_shares(shares)
@@ -683,44 +748,6 @@ def main():
     total_gates = gates * args.steps * world
     value = total_gates / elapsed
 
-    # ---- the same solve over gate hash 1 (lgc_set_gate_hash: the table-free Chaskey-12 permutation in the place of the
-    # fixed-key AES; include/linreg_gc.h).  Reported beside the headline, never as `value`: the headline runs the
-    # reference's primitive.  Same program, same integers (compared below); the parked table ring is taken over.
-    alt_hash = None
-    if args.alt_hash and world == 1 and args.gate_hash == "aes128":
-        lgc.set_gate_hash("chaskey12")
-        try:
-            s2 = lgc.Solver(sysm, seed=bytes((rank + i) & 0xff for i in range(16)), device=device_index)
-            s2.set_shares(shares)
-            s2.run()
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for _ in range(args.steps):
-                s2.run()
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t2) / args.steps
-            st2 = s2.stats()
-            beta2 = s2.beta()
-            s2.run(profile=True)
-            stx2 = s2.stats()
-            s2.close()
-            # 168 integer instructions per block (12 rounds x (4 add + 4 xor + 6 rotate)), one wave64 instruction per
-            # clock and CU (4 SIMDs x 16 lanes): the issue roof of the hash alone
-            valu_roof = 256 * 64 * 2.4e9 / 168
-            alt_hash = {"gate_hash": "chaskey12", "seconds_per_solve": dt2, "and_gates_per_s": st2["and_gates"] / dt2,
-                        "speedup_vs_headline": (elapsed / args.steps) / dt2,
-                        "same_integers_as_headline": [int(v) for v in beta2] == [int(v) for v in beta_fixed],
-                        "seconds_exclusive_per_solve": {"mac_garble": stx2["seconds_mac_garble"], "mac_eval": stx2["seconds_mac_eval"],
-                                                        "all_garble": stx2["seconds_garble"], "all_eval": stx2["seconds_eval"]},
-                        "hash_roofline": {"bound": "valu", "unit": "permutations/s", "peak": valu_roof,
-                                          "achieved_garbler_mac": 4.0 * stx2["mac_gates"] / stx2["seconds_mac_garble"] if stx2["seconds_mac_garble"] > 0 else None,
-                                          "achieved_evaluator_mac": 2.0 * stx2["mac_gates"] / stx2["seconds_mac_eval"] if stx2["seconds_mac_eval"] > 0 else None,
-                                          "peak_source": "256 CUs x 64 lanes/clk x 2.4 GHz / 168 integer instructions per permutation"},
-                        "note": "option (lgc_set_gate_hash(1) / bin/linreg --gate_hash=chaskey12), not the default: a different "
-                                "instantiation of the random permutation than the reference's fixed-key AES"}
-        finally:
-            lgc.set_gate_hash("aes128")
-
     # ---- BASELINE config 5: the 64-lambda sweep of the d=100 CGD-15 circuit, sharded over the ranks.  The
     # lambda-independent prefix (input labels + garbled share summation) is garbled on rank 0 and broadcast
     # (RCCL over xGMI at N > 1), every rank runs its contiguous block as one merged program, all_gather
@@ -762,18 +789,6 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             sdt = float(tmax[0].item())
             phases = [float(v) for v in tmax[1:].tolist()]
-        if alt_hash is not None:                                   # the same sweep over gate hash 1 (world == 1 here)
-            lgc.set_gate_hash("chaskey12")
-            try:
-                sweep.shared_prefix_sweep(sshares, lams[:2], sd, make, dist=None, tensor_device="cuda")
-                torch.cuda.synchronize()
-                ts2 = time.perf_counter()
-                sres2 = sweep.shared_prefix_sweep(sshares, lams, sd, make, dist=None, tensor_device="cuda")
-                torch.cuda.synchronize()
-                alt_hash["sweep64_seconds"] = time.perf_counter() - ts2
-                alt_hash["sweep64_same_integers"] = bool((np.asarray(sres2) == np.asarray(sres)).all())
-            finally:
-                lgc.set_gate_hash("aes128")
         dump = os.environ.get("LGC_BENCH_DUMP")
         if dump:                                                   # tests: what every rank holds after the gather
             json.dump({"rank": rank, "lambdas": lams, "beta": sres.tolist(), "shares": sshares.tolist(), "d": sd, "iters": sit,
@@ -862,46 +877,47 @@ def main():
                               "alternate with their evaluator launches; small launches of the two chains overlap); "
                               "*_exclusive: the same kernels in a fully serialised pass",
                     "note": "integer/bitwise kernel bound by LDS T-table AES issue, not HBM: see aes_roofline"}
-        if args.gate_hash == "chaskey12":        # the run was asked to use the table-free hash throughout: its own roof
-            valu_roof = 256 * 64 * 2.4e9 / 168
-            roofline["binding"] = "valu_chaskey12"
-            roofline["note"] = "integer kernel bound by vector-instruction issue of the Chaskey-12 permutation (168 per block), not HBM: see hash_roofline"
-            roofline["hash_roofline"] = {"bound": "valu", "unit": "permutations/s", "peak": valu_roof, "achieved": aes_achieved,
-                                         "achieved_eval_kernel": aes_achieved_eval, "frac": aes_achieved / valu_roof,
-                                         "peak_source": "256 CUs x 64 lanes/clk x 2.4 GHz / 168 integer instructions per permutation"}
         aes_roofline = {"achieved": aes_achieved, "achieved_eval_kernel": aes_achieved_eval,
                         "peak": lds_roof, "unit": "AES-128 blocks/s", "frac": aes_achieved / lds_roof,
                         "frac_eval_kernel": aes_achieved_eval / lds_roof,
                         "peak_source": "LDS lookup roof: 256 CUs x 64 lanes x 2.4 GHz / (160 ds_read_b32 x 2 LDS cycles)",
                         "micro_kernel": aes_rate,
                         "micro_kernel_source": "lgc_aes_bench (stand-alone four-table AES kernel), best of 3 in this run"}
+        # ---- OT-extension accounting (replaces honestCorrelatedOTExt{Send,Recv}1Of2, src/phase1.c:58-65, 84-89):
+        # the Gilboa batches of config 3's --use_ot phase 1 through the C ABI with every operand resident in HBM
+        ot_res = None
+        if world == 1 and not args.no_e2e:
+            try:
+                ot_res = ot_accounting(np, torch, lgc)
+            except Exception as e:
+                ot_res = {"error": str(e)}
         # the second half of the metric string and the deployment-shaped rate, measured in this run
         e2e, ring = None, None
         if world == 1 and not args.no_e2e:
             import shutil as _sh
-            warm = phase12_wall(np, "warm-up", 200, 4, [0, 2], "cholesky", 0, ["--table_ring"] + hash_opt, device_index)   # untimed: pages the binaries in
+            warm = phase12_wall(np, "warm-up", 200, 4, [0, 2], "cholesky", 0, ["--table_ring"], device_index)   # untimed: pages the binaries in
             if warm.get("_check"):
                 _sh.rmtree(warm["_check"]["tmp"], ignore_errors=True)
             # every party runs on this box, so every bulk message may stay in HBM: --table_ring (garbled tables), --ti_ring / --ot_ring
             # (phase 1), --input_ring (the label OT of phase 2)
-            e2e = [phase12_wall(np, "c2", 1000, 20, [0, 10], "cholesky", 0, ["--table_ring", "--input_ring"] + hash_opt, device_index),
-                   phase12_wall(np, "c3-ti", 10000, 100, [0, 50], "cgd", 15, ["--ti_ring", "--input_ring", "--table_ring"] + hash_opt, device_index),
+            e2e = [phase12_wall(np, "c2", 1000, 20, [0, 10], "cholesky", 0, ["--table_ring", "--input_ring"], device_index),
+                   phase12_wall(np, "c3-ti", 10000, 100, [0, 50], "cgd", 15, ["--ti_ring", "--input_ring", "--table_ring"], device_index),
                    # BASELINE config 3 proper: --use_ot phase 1 (1.6e9 extended OTs); all parties are on this node,
                    # so the bulk messages of both phases stay in HBM (--ot_ring = --use_ot through device rings)
-                   phase12_wall(np, "c3-ot", 10000, 100, [0, 50], "cgd", 15, ["--ot_ring", "--input_ring", "--table_ring"] + hash_opt, device_index),
+                   phase12_wall(np, "c3-ot", 10000, 100, [0, 50], "cgd", 15, ["--ot_ring", "--input_ring", "--table_ring"], device_index),
                    # config 1: the reference's own example (README.md:81), five processes
-                   phase12_wall(np, "c1", 10, 5, [0, 1, 2], "cgd", 10, ["--ti_ring", "--input_ring", "--table_ring"] + hash_opt, device_index,
+                   phase12_wall(np, "c1", 10, 5, [0, 1, 2], "cgd", 10, ["--ti_ring", "--input_ring", "--table_ring"], device_index,
                                 source=os.path.join(ROOT, "tests", "golden", "readme_example.in"))]
             if not args.no_c4:
                 # config 4: five providers, phase 1 in 64 bits, phase 2 in 32 (every share shifted on its own, phase1.c:609-638).
                 # bin/linreg_testhooks = bin/linreg plus ONE getenv that pins the TI's seed, so that the checker can replay the
                 # TI stream and compare the Result line exactly (what a share-level check needs; tests/test_gpu_configs.py)
                 e2e.append(phase12_wall(np, "c4", 50000, 500, [0, 100, 200, 300, 400], "cgd", 20,
-                                        ["--width_phase2=32", "--prec_phase2=30", "--ti_ring", "--input_ring", "--table_ring"] + hash_opt, device_index,
+                                        ["--width_phase2=32", "--prec_phase2=30", "--ti_ring", "--input_ring", "--table_ring"], device_index,
                                         exe_name="linreg_testhooks", env_extra={"LINREG_TI_SEED": bytes(range(0x60, 0x70)).hex()},
                                         prec2=30, w2=32))
             if (w, p) == (64, 56):
-                ring = two_process_ring(np, d, iters, p, Af, bf, gates, device_index, hash_opt)
+                ring = two_process_ring(np, d, iters, p, Af, bf, gates, device_index)
         # ---- cpu_baseline leg: the only part of this script that imports, links or runs anything under oracle/.
         # (1) the baseline itself: the CPU mirror of the garbling protocol, timed on a bounded sample;
         # (2) the oracle as CHECKER of what the runs above produced (never of anything that is timed).
@@ -928,6 +944,38 @@ def main():
                 import orc
                 from helpers import oracle_solve
                 orc_ = orc.load()
+                # a WHOLE solve beside the MAC records: d = 100 CGD-1 (input labels, share sums, dividers, inner products,
+                # the matrix-vector product, reveals) through the CPU garbler and evaluator, launch by launch on ONE thread
+                # (garble launch k, evaluate launch k), decoded result checked against the oracle
+                wd, wit = 100, 1
+                wrng = np.random.default_rng(77)
+                wX = wrng.standard_normal((4 * wd, wd)); wX /= np.abs(wX).max(axis=0)
+                wy = wX @ wrng.random(wd) + 0.1 * wrng.standard_normal(4 * wd)
+                wA = wX.T @ wX / (4 * wd * wd) + np.eye(wd) * 1e-3; wb = wX.T @ wy / (4 * wd * wd)
+                wtot = np.concatenate([[int(wA[i, j] * scale) for i in range(wd) for j in range(i + 1)],
+                                       [int(v * scale) for v in wb]]).astype(np.int64).astype(np.uint64)
+                wmask = wrng.integers(0, 2 ** 63, size=wtot.size, dtype=np.uint64)
+                if w == 32:
+                    wtot &= np.uint64(0xffffffff); wmask &= np.uint64(0xffffffff)
+                with np.errstate(over="ignore"):
+                    wsh = np.stack([wtot - wmask, wmask])
+                if w == 32:
+                    wsh &= np.uint64(0xffffffff)
+                wprog = lgc.Program(lgc.make_system(wd, w, p, "cgd", wit, 0.0, 2, 0, 0, 0))
+                tw0 = time.perf_counter()
+                wdec, wgates, _ = g.garble_eval(wprog, wsh, seed=bytes(range(16)))
+                wsec = time.perf_counter() - tw0
+                wT = wd * (wd + 1) // 2
+                wexp, _, _ = oracle_solve(orc_, wtot[:wT], wtot[wT:], wd, w, p, "cgd", wit, 0.0, 0)
+                wgot = wdec[wprog.info.rv_beta:wprog.info.rv_beta + wd]
+                if w == 32:
+                    wgot = wgot & np.uint64(0xffffffff)
+                wmaskw = (1 << w) - 1
+                cpu["whole_solve"] = {"value": wgates / wsec, "unit": "AND-gates/s", "cores": 1, "seconds": wsec, "and_gates": int(wgates),
+                                      "circuit": "d=%d CGD-%d %d-bit" % (wd, wit, w),
+                                      "exact": [int(v) & wmaskw for v in wgot] == [int(v) & wmaskw for v in wexp],
+                                      "sample": "one whole solve, every launch garbled then evaluated on one thread (AES-NI); the "
+                                                "two-thread pipeline of `value` is the reference's structure, this is the whole circuit"}
                 for res in (e2e or []):
                     ck = res.get("_check")
                     if ck and ck["w2"] == 64:
@@ -979,14 +1027,16 @@ def main():
             "value": value, "unit": "AND-gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "barrier_backend": (backend if dist is not None else None),
-            "rccl_ranks": rccl_ranks, "devices": devices,
+            "rccl_ranks": rccl_ranks, "devices": devices, "preflight": preflight,
             # BASELINE.md's published rate (4.63e6 gates/s) counts the REFERENCE's circuit, 2.8x this build's gate count for the same
             # integers: the comparable ratio divides reference-equivalent gates by it; the own-count ratio is printed beside it
             "vs_baseline": (refg * args.steps * world / elapsed / REF_RATE) if (refg and d == 500 and iters == 15 and w == 64) else None,
             "vs_baseline_definition": "ref_equiv_gates_per_s / 4.63e6 (reference gates of this circuit per second of this build "
                                       "over the reference's published rate)",
             "vs_baseline_own_gate_count": value / REF_RATE if (d == 500 and iters == 15 and w == 64) else None,
-            "dtype": "u32", "data": "synthetic", "gate_hash": args.gate_hash,
+            # the arithmetic type of the path: two's-complement fixed point of `width` bits (config.width / config.precision);
+            # the garbled circuit computes it gate by gate on 128-bit wire labels (4 x u32 per lane)
+            "dtype": "int%d" % w, "data": "synthetic",
             "config": {"workload": "phase-2 CGD solve, d=%d, %d iterations, %d-bit fixed point, precision %d, "
                                    "two-party masked input (test_linear_system path), garbler+evaluator co-located; "
                                    "one independent system per GPU" % (d, iters, w, p),
@@ -999,8 +1049,7 @@ def main():
             "seconds_mac_garble_per_solve": mac_g / args.steps,
             "seconds_exclusive_per_solve": {"mac_garble": xg, "mac_eval": xe, "all_garble": stx["seconds_garble"],
                                             "all_eval": stx["seconds_eval"]},
-            "roofline": roofline, "aes_roofline": aes_roofline if args.gate_hash == "aes128" else None, "cpu_baseline": cpu,
-            "alt_gate_hash": alt_hash,
+            "roofline": roofline, "aes_roofline": aes_roofline, "cpu_baseline": cpu, "ot": ot_res,
             "phase12": e2e, "two_process_ring": ring, "sweep64": sweep_res,
             "beta0": float(int(beta_fixed[0]) / scale),
         }

@@ -68,6 +68,12 @@ size_t lgc_party_prefix_launches(const lgc_party *p);
 uint64_t lgc_party_prefix_and_gates(const lgc_party *p);
 int lgc_party_share_prefix(lgc_party *dst, const lgc_party *src);
 
+/* Preflight of a device list (bin/linreg --devices, bench.py --gpus N) before anything is allocated: every index exists, and
+ * every pair of DISTINCT devices can reach each other (hipDeviceCanAccessPeer, both ways) -- the shared prefix travels by peer
+ * copy (lgc_party_share_prefix) and an Evaluator on another GPU maps the CSP's table ring over hipIpc.  An index may repeat
+ * (several blocks on one GPU: the one-GPU rehearsal).  LGC_EINVAL with a message that names the index or the pair. */
+int lgc_devices_preflight(const int *devices, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

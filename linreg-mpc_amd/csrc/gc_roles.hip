@@ -137,6 +137,25 @@ extern "C" int lgc_party_create_sweep(lgc_party **out, int device, const lgc_sys
                                       size_t max_launch_table_bytes, size_t count, const double *lambdas) {
     return lgc_party_create_sweep_at(out, device, sys, role, seed, max_launch_table_bytes, count, lambdas, 0);
 }
+extern "C" int lgc_devices_preflight(const int *devices, size_t n) {
+    if (!devices || !n) return lgc_fail(LGC_EINVAL, "empty device list");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return lgc_fail(LGC_ENODEVICE, "no HIP device visible");
+    for (size_t i = 0; i < n; i++)
+        if (devices[i] < 0 || devices[i] >= count)
+            return lgc_fail(LGC_EINVAL, "device index %d does not exist (%d device%s visible)", devices[i], count, count == 1 ? "" : "s");
+    for (size_t i = 0; i < n; i++)
+        for (size_t j = 0; j < n; j++) {
+            if (devices[i] == devices[j]) continue;
+            int can = 0;
+            hipError_t e = hipDeviceCanAccessPeer(&can, devices[i], devices[j]);
+            if (e != hipSuccess) return lgc_fail(LGC_EHIP, "hipDeviceCanAccessPeer(%d, %d): %s", devices[i], devices[j], hipGetErrorString(e));
+            if (!can)
+                return lgc_fail(LGC_EINVAL, "device %d cannot access device %d (no peer path: not in one xGMI hive, or peer access is "
+                                            "switched off): the blocks of a sweep share their prefix by peer copy", devices[i], devices[j]);
+        }
+    return LGC_OK;
+}
 extern "C" size_t lgc_party_num_circuits(const lgc_party *p) { return p ? p->P.replicas : 0; }
 extern "C" size_t lgc_party_prefix_launches(const lgc_party *p) { return p ? p->P.prefix_launches : 0; }
 extern "C" uint64_t lgc_party_prefix_and_gates(const lgc_party *p) {

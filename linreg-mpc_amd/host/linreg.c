@@ -42,11 +42,7 @@ static void *block_main(void *arg) {
     return NULL;
 }
 /* contiguous block [lo, hi) of block k out of K; sizes differ by at most one (python/sweep.py: partition) */
-static void block_range(size_t n, size_t K, size_t k, size_t *lo, size_t *hi) {
-    size_t base = n / K, extra = n % K;
-    *lo = k * base + (k < extra ? k : extra);
-    *hi = *lo + base + (k < extra ? 1 : 0);
-}
+#define block_range sweep_block_range      /* host/sweep_plan.c */
 
 /* The phase-2 object(s) of party 1 / 2: one, or with --devices one block of the sweep per entry (same seed: one set of
  * input labels, one label OT per data provider; block k starts at circuit lo_k, which keeps its gate ids disjoint), and for
@@ -276,16 +272,8 @@ int main(int argc, char **argv) {
             check(n_lambdas > 0, "--lambdas wants at least one value");
         }
         else if (!strncmp(argv[i], "--devices=", 10)) {
-            const char *q = argv[i] + 10;
-            while (*q) {
-                char *e2;
-                long v = strtol(q, &e2, 10);
-                check(e2 != q && (*e2 == ',' || !*e2) && v >= 0, "--devices wants a comma-separated list of device indices");
-                check(n_devices < kMaxDevices, "--devices: at most %d entries", kMaxDevices);
-                devices[n_devices++] = (int)v;
-                q = *e2 ? e2 + 1 : e2;
-            }
-            check(n_devices > 0, "--devices wants at least one index");
+            n_devices = sweep_parse_devices(argv[i] + 10, devices, kMaxDevices);
+            check(n_devices > 0, "--devices wants a comma-separated list of at most %d device indices", kMaxDevices);
         }
         else if (!strcmp(argv[i], "--table_ring")) ring_slots = TABLE_RING_BYTES;
         else if (sscanf(argv[i], "--table_ring=%i", &ring_slots) == 1) {}
@@ -305,7 +293,12 @@ int main(int argc, char **argv) {
     if (n_devices) {
         check(n_lambdas > 0 && ring_slots > 0, "--devices shards a --lambdas sweep and needs --table_ring (CSP and Evaluator on this node)");
         if ((size_t)n_devices > n_lambdas) n_devices = (int)n_lambdas;       /* no empty blocks */
-        if (party <= 2) device = devices[0];
+        if (party <= 2) {
+            /* before anything is allocated: every index exists, and distinct devices can reach each other (the shared prefix
+             * travels by peer copy, lgc_party_share_prefix; the Evaluator maps the CSP's table rings over hipIpc) */
+            check(lgc_devices_preflight(devices, (size_t)n_devices) == LGC_OK, "--devices: %s", lgc_last_error());
+            device = devices[0];
+        }
     }
 
     /* HIP runtime + device context (60-150 ms with four or five processes starting at once): on a thread, beside the

@@ -45,6 +45,11 @@ int tables_recv(node *self, int peer, lgc_party *po, int ring_slots, size_t chun
 /* ring mode in pieces, for several blocks of a sweep side by side (bin/linreg --devices): see protocol.c */
 /* ring_slots: 0 = no ring (tables through the socket), 1..64 = a ring of that many slots of the largest launch,
  * TABLE_RING_BYTES = the byte ring (largest launch + slack: lgc_party_ring_create_bytes), what plain --table_ring selects */
+/* sweep_plan.c: the blocks of a --lambdas sweep over the entries of --devices (pure host logic) */
+typedef struct { int device; size_t lo, hi; } sweep_block;
+void sweep_block_range(size_t n, size_t K, size_t k, size_t *lo, size_t *hi);
+int sweep_parse_devices(const char *text, int *devices, int max);
+int sweep_plan(size_t n_lambdas, const int *devices, int n_devices, sweep_block *plan);
 void host_trace_mark(const char *what);       /* lgc_trace_mark, and the LINREG_DIE_AT hook of bin/linreg_testhooks */
 enum { TABLE_RING_BYTES = 65 };
 typedef struct { node *self; int peer, fd; lgc_party *po; size_t start, end, nslots, acked; int64_t last_ack; int last_ack_known; } table_link;   /* nslots 0: byte ring */

@@ -620,7 +620,6 @@ def set_table_ring_slack(nbytes):
     lib().lgc_set_table_ring_slack(int(nbytes))
 
 
-GATE_HASH = {"aes128": 0, "chaskey12": 1}
 
 
 def gate_hash_eval(labels, tweaks, device=0):

@@ -680,3 +680,50 @@ def test_input_file_numbers_parsed_by_several_threads_are_the_ones_one_thread_re
         for threads in (1, 3, 8):
             rc, _, _ = _parse_with(hostlib, pth, n, d, 3, 7, 1, 56, 1.0, 64, threads)
             assert rc != 0, (pth, threads)
+
+
+def test_sweep_plan_of_devices_0_1_is_the_plan_of_devices_0_0(lgc, hostlib):
+    """host/sweep_plan.c: which circuits go to which --devices entry depends on the NUMBER of entries only -- the blocks (and
+    with them every block's lowered program: records, launch list, gate-step numbers) of --devices=0,1 are those of
+    --devices=0,0, which is what a one-GPU box can run.  Blocks are contiguous, cover the sweep, and never empty."""
+    H = hostlib
+    class Blk(C.Structure):
+        _fields_ = [("device", C.c_int), ("lo", C.c_size_t), ("hi", C.c_size_t)]
+    H.sweep_parse_devices.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int]; H.sweep_parse_devices.restype = C.c_int
+    H.sweep_plan.argtypes = [C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(Blk)]; H.sweep_plan.restype = C.c_int
+
+    def plan(text, n_lambdas):
+        dev = (C.c_int * 16)()
+        n = H.sweep_parse_devices(text.encode(), dev, 16)
+        assert n > 0, text
+        out = (Blk * 16)()
+        k = H.sweep_plan(n_lambdas, dev, n, out)
+        return [(out[i].device, out[i].lo, out[i].hi) for i in range(k)]
+
+    for bad in ("", "0,", "a", "0,-1", "1,,2", ",".join(["0"] * 17)):
+        assert H.sweep_parse_devices(bad.encode(), (C.c_int * 16)(), 16) == -1, bad
+    for nl in (1, 2, 7, 8, 64):
+        for text_a, text_b in (("0,1", "0,0"), ("0,1,2,3,4,5,6,7", "0,0,0,0,0,0,0,0"), ("3,1,2", "0,0,0")):
+            pa, pb = plan(text_a, nl), plan(text_b, nl)
+            assert [(lo, hi) for _, lo, hi in pa] == [(lo, hi) for _, lo, hi in pb]
+            assert [dv for dv, _, _ in pa] == [int(t) for t in text_a.split(",")][:len(pa)]
+            assert pa[0][1] == 0 and pa[-1][2] == nl and all(a[2] == b[1] for a, b in zip(pa, pa[1:])) and all(hi > lo for _, lo, hi in pa)
+            assert max(hi - lo for _, lo, hi in pa) - min(hi - lo for _, lo, hi in pa) <= 1
+    # ... and the program of a block is a function of (system, lambdas of the block, first circuit) only: same records and launches
+    lams = [10 ** (-6 + 6 * k / 7) for k in range(8)]
+    sysm = lgc.make_system(6, 64, 56, "cgd", 2, 0.0, 2, 1, 0, 0)
+    for (_, lo, hi), (_, lo2, hi2) in zip(plan("0,1", 8), plan("0,0", 8)):
+        pa = lgc.Program(sysm, lambdas=lams[lo:hi], first=lo)
+        pb = lgc.Program(sysm, lambdas=lams[lo2:hi2], first=lo2)
+        assert pa.records().tobytes() == pb.records().tobytes() and pa.launches() == pb.launches()
+
+
+def test_bench_gpus_preflight_names_what_is_wrong():
+    """bench.py --gpus N checks its devices before it builds the RCCL group (one GPU per rank, every pair reachable)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    assert "2 ranks but 1 visible GPU" in bench.devices_preflight(None, 2, 1)["error"]
+    ok = bench.devices_preflight(None, 4, 8, can_access=lambda i, j: True)
+    assert ok == {"distinct_devices": True, "peer_access": True, "no_peer_path": None}
+    part = bench.devices_preflight(None, 3, 4, can_access=lambda i, j: (i, j) != (0, 2))
+    assert part["peer_access"] is False and part["no_peer_path"] == ["0->2"]
