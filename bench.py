@@ -947,7 +947,7 @@ def main():
                 # a WHOLE solve beside the MAC records: d = 100 CGD-1 (input labels, share sums, dividers, inner products,
                 # the matrix-vector product, reveals) through the CPU garbler and evaluator, launch by launch on ONE thread
                 # (garble launch k, evaluate launch k), decoded result checked against the oracle
-                wd, wit = 100, 1
+                wd, wit = 100, 5
                 wrng = np.random.default_rng(77)
                 wX = wrng.standard_normal((4 * wd, wd)); wX /= np.abs(wX).max(axis=0)
                 wy = wX @ wrng.random(wd) + 0.1 * wrng.standard_normal(4 * wd)

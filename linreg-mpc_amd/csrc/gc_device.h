@@ -425,11 +425,44 @@ struct GpuBackend {
 };
 
 // MAC launches: one wavefront per record; the TPB/64 waves of a workgroup share the LDS table
+// Which record a wave of a MAC workgroup takes next.  A SIMD issues from its OLDEST wave first: of sixteen waves with one
+// record each, the four that arrived first on their SIMDs are through after 45 % of the workgroup's time, the last four
+// need all of it, and the CU hashes with twelve, eight, four waves meanwhile (profiles/r6_wave_order.txt: the same AES work
+// per wave, 19.5 / 28.1 / 35.8 / 43.0 ms by arrival).  So a workgroup owns `per_wg` CONSECUTIVE records (chunk = waves x a
+// few) and its waves PULL them from a counter in LDS: all waves stay busy until the chunk is empty, whatever their speed.
+// per_wg = waves: the old static assignment (one record per wave), for launches of a few rounds.
+#ifndef GC_MAC_WAVE_TRACE
+#define GC_MAC_WAVE_TRACE 0     /* profiling builds only: time in the kernel by wave index (scripts/gpu_wave_order.py) */
+#endif
+#if GC_MAC_WAVE_TRACE
+__device__ unsigned long long g_mac_wave_ticks[2 * 16];      // [role][wave index]: summed over workgroups; and counts
+__device__ unsigned long long g_mac_wave_count[2 * 16];
+#endif
+struct MacQueue {
+    uint32_t *next;        // LDS
+    uint32_t base, end;    // this workgroup's records [base, end)
+    __device__ __forceinline__ void init(uint32_t *lds_next, uint32_t per_wg, uint32_t nrec) {
+        next = lds_next;
+        base = blockIdx.x * per_wg;
+        end = base + per_wg < nrec ? base + per_wg : nrec;
+        if (threadIdx.x == 0) *lds_next = 0;      // (made visible by the barrier that ends the table fill)
+    }
+    __device__ __forceinline__ bool pull(uint32_t &wid) {
+        uint32_t k = 0;
+        if ((threadIdx.x & 63u) == 0) k = atomicAdd(next, 1u);
+        wid = base + (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        return wid < end;
+    }
+};
+
 template <bool GARBLER, int TPB>
 __global__ void __launch_bounds__(TPB)
-gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
+gc_mac_kernel(const Rec *recs, uint32_t nrec, uint32_t per_wg, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
     // the four rotated tables: 128 KiB, one workgroup per CU
     __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    __shared__ uint32_t lds_next;
+    MacQueue q;
+    q.init(&lds_next, per_wg, nrec);
     lds_tab4_fill(lds_te0);
     const int lane = threadIdx.x & 63;
     typedef GpuBackend<GARBLER, MODE_MAC, LdsTab4> B;
@@ -445,11 +478,11 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
     be.xch = 0;
     be.lt = lds_tab4_make(lds_te0);
     typedef Circ<B> C;
-    // (A persistent form -- one workgroup per CU walking the records -- was measured in round 4: the garbler's launches of a
+    // (A persistent form -- ONE workgroup per CU walking all records -- was measured in round 4: the garbler's launches of a
     // few rounds 12-14 % faster alone, the co-located solve slower, because the evaluator's kernels no longer slip in between
-    // the garbler's workgroups.  Not kept.)
-    const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wid < nrec) {
+    // the garbler's workgroups.  A chunk of a few records per wave keeps the turnover.)
+    uint32_t wid;
+    while (q.pull(wid)) {
         Rec r = recs[wid];
         r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);
         r.dst = __builtin_amdgcn_readfirstlane(r.dst);
@@ -467,7 +500,7 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
                         be.load2(r.b + (int32_t)k * r.sb, r.b + (int32_t)(r.cnt + k) * r.sb), p);
             be.store2(r.dst, r.dst + 2, S);
             be.store2(r.dst + 1, r.dst + 3, Cc);
-            return;
+            continue;
         }
         for (uint32_t k = 0; k < r.cnt; k++)
             C::mac(be, S, Cc, be.load(r.a + (int32_t)k * r.sa), be.load(r.b + (int32_t)k * r.sb), w, p);
@@ -483,8 +516,14 @@ gc_mac_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t lau
 // the combined kernel spilled 175 VGPRs.)
 template <bool GARBLER, int TPB>
 __global__ void __launch_bounds__(TPB)
-gc_mack_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
+gc_mack_kernel(const Rec *recs, uint32_t nrec, uint32_t per_wg, Lbl *words, Lbl *tab, uint64_t launch_step0, Lbl R, int w, int p) {
+#if GC_MAC_WAVE_TRACE
+    const unsigned long long t_in = wall_clock64();
+#endif
     __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    __shared__ uint32_t lds_next;
+    MacQueue q;
+    q.init(&lds_next, per_wg, nrec);
     lds_tab4_fill(lds_te0);
     typedef GpuBackend<GARBLER, MODE_MAC, LdsTab4> B;
     B be;
@@ -498,23 +537,30 @@ gc_mack_kernel(const Rec *recs, uint32_t nrec, Lbl *words, Lbl *tab, uint64_t la
     be.wave = 0;
     be.xch = 0;
     be.lt = lds_tab4_make(lds_te0);
-    const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wid >= nrec) return;
-    Rec r = recs[wid];
-    r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);
-    r.dst = __builtin_amdgcn_readfirstlane(r.dst);
-    r.a = __builtin_amdgcn_readfirstlane(r.a);
-    r.b = __builtin_amdgcn_readfirstlane(r.b);
-    r.c = __builtin_amdgcn_readfirstlane(r.c);
-    r.sa = __builtin_amdgcn_readfirstlane(r.sa);
-    r.sb = __builtin_amdgcn_readfirstlane(r.sb);
-    uint32_t s_lo = __builtin_amdgcn_readfirstlane((uint32_t)r.step0);
-    uint32_t s_hi = __builtin_amdgcn_readfirstlane((uint32_t)(r.step0 >> 32));
-    be.step = ((uint64_t)s_hi << 32) | s_lo;
-    Lbl S = lzero(), Cc = lzero();
-    Circ<B>::mack_rec(be, S, Cc, r.a, r.b, r.sa, r.sb, r.cnt, r.c, p);
-    be.store(r.dst, S);
-    be.store(r.dst + 1, Cc);
+    uint32_t wid;
+    while (q.pull(wid)) {
+        Rec r = recs[wid];
+        r.cnt = __builtin_amdgcn_readfirstlane(r.cnt);
+        r.dst = __builtin_amdgcn_readfirstlane(r.dst);
+        r.a = __builtin_amdgcn_readfirstlane(r.a);
+        r.b = __builtin_amdgcn_readfirstlane(r.b);
+        r.c = __builtin_amdgcn_readfirstlane(r.c);
+        r.sa = __builtin_amdgcn_readfirstlane(r.sa);
+        r.sb = __builtin_amdgcn_readfirstlane(r.sb);
+        uint32_t s_lo = __builtin_amdgcn_readfirstlane((uint32_t)r.step0);
+        uint32_t s_hi = __builtin_amdgcn_readfirstlane((uint32_t)(r.step0 >> 32));
+        be.step = ((uint64_t)s_hi << 32) | s_lo;
+        Lbl S = lzero(), Cc = lzero();
+        Circ<B>::mack_rec(be, S, Cc, r.a, r.b, r.sa, r.sb, r.cnt, r.c, p);
+        be.store(r.dst, S);
+        be.store(r.dst + 1, Cc);
+    }
+#if GC_MAC_WAVE_TRACE
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_mac_wave_ticks[(GARBLER ? 0 : 16) + (threadIdx.x >> 6)], wall_clock64() - t_in);
+        atomicAdd(&g_mac_wave_count[(GARBLER ? 0 : 16) + (threadIdx.x >> 6)], 1ull);
+    }
+#endif
 }
 
 // every other record type.  QUAD = true: one 4-wave workgroup per record (narrow, latency-bound

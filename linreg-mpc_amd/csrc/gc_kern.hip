@@ -41,3 +41,21 @@ extern "C" int lgc_dbg_split_trace_e(uint64_t *out, uint32_t *n, int reset) {
     return (int)e;
 }
 #endif
+#if GC_MAC_WAVE_TRACE && GC_KERN_PART == 0
+// profiling builds only (-DGC_MAC_WAVE_TRACE=1): mean time a wave of a Karatsuba MAC workgroup spends in the kernel, by wave index
+#if GC_KERN_G
+extern "C" int lgc_dbg_mac_wave_ticks_g(uint64_t *ticks, uint64_t *count, int reset) {
+#else
+extern "C" int lgc_dbg_mac_wave_ticks_e(uint64_t *ticks, uint64_t *count, int reset) {
+#endif
+    if (reset) {
+        unsigned long long z[32] = {0};
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(gc::g_mac_wave_ticks), z, sizeof z);
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(gc::g_mac_wave_count), z, sizeof z);
+        return (int)e;
+    }
+    hipError_t e = hipMemcpyFromSymbol(ticks, HIP_SYMBOL(gc::g_mac_wave_ticks), 32 * 8);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(count, HIP_SYMBOL(gc::g_mac_wave_count), 32 * 8);
+    return (int)e;
+}
+#endif

@@ -31,8 +31,9 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
     case LM_MAC: if constexpr (PART == 0) {
         constexpr int TPB = G ? kTpbMacG : kTpbMacE;       // upper bound (register budget of the kernel)
         const unsigned per = gc_mac_waves(L.nrec, kMacAdaptLo, TPB / 64);
-        hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(per * 64), 0, st, recs + L.first_rec, L.nrec, words, tab,
-                           L.step0, R, w, p);
+        const unsigned per_wg = gc_mac_per_wg(L.nrec, per);
+        hipLaunchKernelGGL((gc_mac_kernel<G, TPB>), dim3((L.nrec + per_wg - 1) / per_wg), dim3(per * 64), 0, st, recs + L.first_rec, L.nrec, per_wg,
+                           words, tab, L.step0, R, w, p);
     } break;
     case LM_MACK: if constexpr (PART == 0) {
         constexpr int TPB = G ? kTpbMackG : kTpbMackE;
@@ -41,8 +42,9 @@ static inline hipError_t gc_launch_records_impl(LaunchMode m, const Rec *recs, c
         // number of rounds costs less (5 000 pairs: 2 rounds of 12 waves instead of 16 + 3.5).  Only for launches of at most
         // kMackAdaptMaxRounds rounds (gc_launch.h has the measurements).
         const unsigned per = gc_mack_waves(L.nrec, kMacAdaptLo, TPB / 64);
-        hipLaunchKernelGGL((gc_mack_kernel<G, TPB>), dim3((L.nrec + per - 1) / per), dim3(per * 64), 0, st,
-                           recs + L.first_rec, L.nrec, words, tab, L.step0, R, w, p);
+        const unsigned per_wg = gc_mac_per_wg(L.nrec, per);
+        hipLaunchKernelGGL((gc_mack_kernel<G, TPB>), dim3((L.nrec + per_wg - 1) / per_wg), dim3(per * 64), 0, st,
+                           recs + L.first_rec, L.nrec, per_wg, words, tab, L.step0, R, w, p);
     } break;
     case LM_WIDE: if constexpr (PART == 1) {
         // records (waves) per workgroup: as few as keep the launch within one workgroup per CU, at most TPB / 64 --

@@ -93,6 +93,28 @@ static inline unsigned gc_adapt_waves(uint32_t nrec, unsigned lo, unsigned hi, u
     }
     return best;
 }
+// Records per WORKGROUP of a MAC launch (MacQueue, gc_device.h).  A SIMD
+// issues from its OLDEST wave first: of sixteen waves with one record each, the four that arrived first on their SIMDs are
+// through after 45 % of the workgroup's time and the CU hashes with twelve, eight, four waves until the last four are done
+// (profiles/r6_wave_order.txt).  So the waves of a workgroup PULL records from a chunk the workgroup owns, and every wave
+// stays busy to the end whatever its speed.  How large a chunk: a launch of equal workgroups runs in rounds (one workgroup
+// per CU) and ends with a partly filled one -- the longer the workgroups the more that costs -- while the OTHER role's small
+// launches get CUs only when workgroups retire.  Measured on d = 500 CGD-15 (scripts/gpu_headline.py, one box, s per solve):
+// 1 record per wave 1.769; 4: 1.731; 8: 1.694; 12: 1.664; 16 (garbler 2 rounds, evaluator 3): 1.659; 24-200 (ONE round: the
+// launch is persistent) 1.645-1.653 -- an iteration is then garble + evaluate + the two chains together on an idle chip
+// (65.2 + 37.0 + 7.5 ms) instead of 74.3 + 39.1 + 4.5; another box: 1.791 -> 1.741 (2 / 3 rounds) -> 1.726 (one round);
+// d = 300: 0.691 -> 0.653-0.667; 32-bit d = 500 CGD-20: 0.762 -> 0.740.  So: about kMacChunk records per wave, the number of
+// workgroups a whole number of rounds, at least one; launches of fewer than kMacChunkMinRounds rounds of one record per
+// wave keep the static assignment (the products of small systems, which their own chain waits for).
+static constexpr unsigned kMacChunk = 32, kMacChunkMinRounds = 4;
+static inline unsigned gc_mac_per_wg(uint32_t nrec, unsigned waves) {
+    const uint64_t cus = gc_num_cus();
+    if ((uint64_t)nrec < (uint64_t)kMacChunkMinRounds * cus * waves) return waves;
+    uint64_t rounds = ((uint64_t)nrec + cus * waves * kMacChunk / 2) / (cus * waves * kMacChunk);      // nearest whole number of rounds
+    if (rounds < 1) rounds = 1;
+    const uint64_t wgs = rounds * cus;
+    return (unsigned)(((uint64_t)nrec + wgs - 1) / wgs);
+}
 static inline unsigned gc_mac_waves(uint32_t nrec, unsigned lo, unsigned hi) { return gc_adapt_waves(nrec, lo, hi, kMacAdaptMaxRounds); }
 static inline unsigned gc_mack_waves(uint32_t nrec, unsigned lo, unsigned hi) { return gc_adapt_waves(nrec, lo, hi, kMackAdaptMaxRounds); }
 

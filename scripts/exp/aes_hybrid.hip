@@ -40,7 +40,7 @@ __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(
 
 // ------------------------------------------------------------------ T-table waves
 template <int TPB, int NB, bool STATIC_LDS>
-__device__ __forceinline__ void t_body(WaveRep *rep, uint64_t dur) {
+__device__ __forceinline__ void t_body(WaveRep *rep, uint64_t dur, uint64_t max_blocks = ~0ull) {
     // dynamic LDS: with a static 128 KiB array the compiler knows that only one workgroup fits a CU and pads the kernel's VGPR
     // allocation up to 512 / (waves per SIMD) + 1 -- the T kernel would then own the whole register file
     extern __shared__ uint32_t lds_dyn[];
@@ -59,7 +59,7 @@ __device__ __forceinline__ void t_body(WaveRep *rep, uint64_t dur) {
         for (int i = 0; i < 4; i++) aes_encrypt_n<NB, LdsTab4>(lt, c_aes.rk, s, c_aes.rk24);
         n += 4 * NB;
         t1 = wall_clock64();
-    } while (t1 - t0 < dur);
+    } while (t1 - t0 < dur && n < max_blocks);
     uint32_t acc = 0;
 #pragma unroll
     for (int b = 0; b < NB; b++) acc ^= s[b][0] ^ s[b][1] ^ s[b][2] ^ s[b][3];
@@ -120,6 +120,8 @@ __device__ __forceinline__ void b_body(WaveRep *rep, uint64_t dur) {
 #define TS_KERNEL(TPB, NB) \
     __global__ void __launch_bounds__(TPB) ts_kernel_##TPB##_##NB(WaveRep *rep, uint64_t dur) { t_body<TPB, NB, true>(rep, dur); } \
     static void launch_ts_##TPB##_##NB(WaveRep *rep, uint64_t dur, int grid, hipStream_t st) { hipLaunchKernelGGL(ts_kernel_##TPB##_##NB, dim3(grid), dim3(TPB), 0, st, rep, dur); }
+// the static-LDS window kernel ended by a block count: timed by events, for the comparison with fixed_work_kernel
+__global__ void __launch_bounds__(1024) ts_count_kernel(WaveRep *rep, uint64_t max_blocks) { t_body<1024, 4, true>(rep, ~0ull >> 2, max_blocks); }
 #define B_KERNEL(TPB) \
     __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(TPB / 256, 8))) b_kernel_##TPB(WaveRep *rep, uint64_t dur) { b_body<TPB, 0, 0>(rep, dur); } \
     static void launch_b_##TPB(WaveRep *rep, uint64_t dur, int grid, hipStream_t st) { hipLaunchKernelGGL(b_kernel_##TPB, dim3(grid), dim3(TPB), 0, st, rep, dur); }
@@ -137,6 +139,76 @@ TS_KERNEL(768, 2)
 TS_KERNEL(1024, 1)
 B_KERNEL(256)
 B_KERNEL(512)
+
+// the product's micro-kernel (gc_engine.hip gc_aes_bench_kernel) as it is there: a fixed amount of work per lane, timed by
+// HIP events around the launch -- to see what the fixed-work / many-workgroups form costs against the fixed-window form above
+// MODE 0: as the product's.  1: every wave starts late by (wave index) x `arg` s_sleep units (64 clk each).  2: reads the
+// wall clock every four batches (what the fixed-window kernels above do).  3: sleeps (wave & 3) units every `arg` batches.
+template <int MODE, int NB>
+__global__ void __launch_bounds__(1024)
+fixed_work_kernel(uint32_t *out, int blocks_per_lane, int arg, unsigned long long *stamps) {
+    const uint64_t t_in = wall_clock64();
+    __shared__ uint32_t lds_te0[2 * kLdsTabWords];
+    lds_tab4_fill(lds_te0);
+    LdsTab4 lt = lds_tab4_make(lds_te0);
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t s[NB][4];
+    for (int b = 0; b < NB; b++) { s[b][0] = gid; s[b][1] = b; s[b][2] = gid * 2654435761u; s[b][3] = 0x9e3779b9u ^ b; }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (MODE == 1) for (int k = 0; k < wave * arg; k++) __builtin_amdgcn_s_sleep(1);
+    uint64_t sink = 0;
+    __shared__ uint32_t wg_next;
+    if (MODE == 6) { if (threadIdx.x == 0) wg_next = 0; __syncthreads(); }
+    if (MODE == 5) {            // rotating user priorities: the SIMD's issue arbiter otherwise favours its oldest wave
+        for (int i = 0, k = 0; i < blocks_per_lane; i += NB, k++) {
+            if ((k % arg) == 0) {
+                switch (((wave >> 2) + k / arg) & 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+                }
+            }
+            aes_encrypt_n<NB, LdsTab4>(lt, c_aes.rk, s, c_aes.rk24);
+        }
+    } else if (MODE == 6) {     // the workgroup's work (16 waves x blocks_per_lane) in units of `arg` batches, pulled from a counter
+        const uint32_t units = (uint32_t)((blockDim.x >> 6) * (blocks_per_lane / (NB * arg)));
+        for (;;) {
+            uint32_t u = 0;
+            if ((threadIdx.x & 63) == 0) u = atomicAdd(&wg_next, 1u);
+            u = __builtin_amdgcn_readfirstlane(u);
+            if (u >= units) break;
+            for (int k = 0; k < arg; k++) aes_encrypt_n<NB, LdsTab4>(lt, c_aes.rk, s, c_aes.rk24);
+        }
+    } else if (MODE == 4) {            // the loop of the fixed-window kernels, ended by a count instead of the clock
+        int done = 0;
+        const uint64_t t0 = wall_clock64();
+        uint64_t t1 = t0;
+        do {
+#pragma unroll 1
+            for (int i = 0; i < 4; i++) aes_encrypt_n<NB, LdsTab4>(lt, c_aes.rk, s, c_aes.rk24);
+            done += 4 * NB;
+            t1 = wall_clock64();
+        } while (done < blocks_per_lane && t1 - t0 < (uint64_t)1 << 40);
+        sink = t1;
+    } else
+    for (int i = 0, k = 0; i < blocks_per_lane; i += NB, k++) {
+        aes_encrypt_n<NB, LdsTab4>(lt, c_aes.rk, s, c_aes.rk24);
+        if (MODE == 2 && (k & 3) == 3) sink += wall_clock64();
+        if (MODE == 3 && (k % arg) == arg - 1) { if (wave & 1) __builtin_amdgcn_s_sleep(1); if (wave & 2) __builtin_amdgcn_s_sleep(2); }
+    }
+    s[0][0] ^= (uint32_t)(sink >> 40);
+    uint32_t acc = 0;
+    for (int b = 0; b < NB; b++) acc ^= s[b][0] ^ s[b][1] ^ s[b][2] ^ s[b][3];
+    out[gid] = acc;
+    if (stamps && (threadIdx.x & 63) == 0) {
+        const unsigned long long t_out = wall_clock64();
+        atomicMin(&stamps[0], (unsigned long long)t_in);
+        atomicMax(&stamps[1], t_out);
+        // how long each wave of a workgroup took (summed over the workgroups): slot 2 + wave
+        atomicAdd(&stamps[2 + wave], t_out - t_in);
+    }
+}
 
 // known-answer path of the bitsliced cipher on the device: 32 blocks per lane through load / encrypt / store
 __global__ void __launch_bounds__(64)
@@ -220,15 +292,19 @@ int main(int argc, char **argv) {
         if (bad) return 1;
     }
 
-    const uint64_t dur = (uint64_t)(dur_ms * 1e5);   // 100 MHz
+    int wall_khz = 0;
+    CHK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0));
+    printf("wall_clock64 rate: %d kHz\n", wall_khz);
+    const double kTicksPerMs = (double)wall_khz;
+    const uint64_t dur = (uint64_t)(dur_ms * kTicksPerMs);
     const double dur_s = dur_ms * 1e-3;
-    hipStream_t st_t, st_b;
-    CHK(hipStreamCreateWithFlags(&st_t, hipStreamNonBlocking));
-    CHK(hipStreamCreateWithFlags(&st_b, hipStreamNonBlocking));
     WaveRep *rep_t, *rep_b;
     const int kMaxWaves = 4096 * 4;
     CHK(hipMalloc(&rep_t, sizeof(WaveRep) * kMaxWaves));
     CHK(hipMalloc(&rep_b, sizeof(WaveRep) * kMaxWaves));
+    hipStream_t st_t, st_b;
+    CHK(hipStreamCreateWithFlags(&st_t, hipStreamNonBlocking));
+    CHK(hipStreamCreateWithFlags(&st_b, hipStreamNonBlocking));
 
     const Side T[] = {
         {"T 16w nb4", launch_t_1024_4, 1024},
@@ -271,7 +347,7 @@ int main(int argc, char **argv) {
         size_t shared = 0;
         for (auto c : ct) shared += cb.count(c);
         const uint64_t first = rt.first < rb.first ? rt.first : rb.first, last = rt.last > rb.last ? rt.last : rb.last;
-        const double win_s = (double)(last - first) / 1e8;
+        const double win_s = (double)(last - first) / (kTicksPerMs * 1e3);
         printf("%-9s | %-4s x%d | T %.3e  B %.3e  sum %.3e blocks/s over the joint window of %6.2f ms | CUs T %3zu B %3zu both %3zu\n",
                ti >= 0 ? T[ti].name : "-", bi >= 0 ? B[bi].name : "-", bgrid_mul, rt.blocks / win_s, rb.blocks / win_s, (rt.blocks + rb.blocks) / win_s,
                win_s * 1e3, rt.cus, rb.cus, shared);
@@ -279,6 +355,80 @@ int main(int argc, char **argv) {
         return (rt.blocks + rb.blocks) / win_s;
     };
 
+    {   // fixed work, event-timed (the form of lgc_aes_bench): workgroups x blocks per lane
+        uint32_t *fout;
+        CHK(hipMalloc(&fout, (size_t)16384 * 1024 * 4));
+        hipEvent_t ea, eb;
+        CHK(hipEventCreate(&ea)); CHK(hipEventCreate(&eb));
+        printf("\n-- the product's micro-kernel, fixed work timed by events (lgc_aes_bench runs 4096 workgroups x 256 blocks per lane)\n");
+        unsigned long long *stamps;
+        CHK(hipMalloc(&stamps, 18 * 8));
+        bool show_waves = false;
+        auto timed = [&](const char *name, void (*k)(uint32_t *, int, int, unsigned long long *), int wgs, int bpl, int arg) {
+            unsigned long long init[18] = {~0ull, 0ull}, got[18];
+            CHK(hipMemcpy(stamps, init, 18 * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k, dim3(wgs), dim3(1024), 0, 0, fout, 8, arg, (unsigned long long *)0);
+            CHK(hipEventRecord(ea, 0));
+            hipLaunchKernelGGL(k, dim3(wgs), dim3(1024), 0, 0, fout, bpl, arg, stamps);
+            CHK(hipEventRecord(eb, 0));
+            CHK(hipEventSynchronize(eb));
+            float ms = 0;
+            CHK(hipEventElapsedTime(&ms, ea, eb));
+            CHK(hipMemcpy(got, stamps, 18 * 8, hipMemcpyDeviceToHost));
+            const double win_ms = (double)(got[1] - got[0]) / 1e5;
+            printf("%-44s %6d workgroups x %6d blocks per lane: events %8.3f ms  %.3e blocks/s | first wave in .. last wave out %8.3f ms  %.3e\n", name, wgs, bpl, ms,
+                   (double)wgs * 1024.0 * bpl / (ms * 1e-3), win_ms, (double)wgs * 1024.0 * bpl / (win_ms * 1e-3));
+            if (show_waves) {
+                printf("      mean time in the kernel by wave index (ms):");
+                for (int w = 0; w < 16; w++) printf(" %.2f", (double)got[2 + w] / 1e5 / wgs);
+                printf("\n");
+            }
+        };
+        show_waves = true;
+        timed("as the product's (nb4)", fixed_work_kernel<0, 4>, 256, 16384, 0);
+        timed("as the product's (nb4)", fixed_work_kernel<0, 4>, 4096, 1024, 0);
+        for (int a : {1, 4, 16, 64}) {
+            char nm[64]; snprintf(nm, sizeof nm, "nb4, user priority rotates every %d batches", a);
+            timed(nm, fixed_work_kernel<5, 4>, 4096, 1024, a);
+        }
+        for (int a : {1, 4, 16}) {
+            char nm[64]; snprintf(nm, sizeof nm, "nb4, units of %d batches pulled by the waves", a);
+            timed(nm, fixed_work_kernel<6, 4>, 4096, 1024, a);
+        }
+        timed("nb4, units of 4 batches pulled by the waves", fixed_work_kernel<6, 4>, 256, 16384, 4);
+        show_waves = false;
+        timed("as the product's (nb4)", fixed_work_kernel<0, 4>, 256, 4096, 0);
+        timed("as the product's (nb4)", fixed_work_kernel<0, 4>, 256, 16384, 0);
+        timed("as the product's (nb4)", fixed_work_kernel<0, 4>, 4096, 1024, 0);
+        timed("nb2", fixed_work_kernel<0, 2>, 256, 16384, 0);
+        timed("nb2", fixed_work_kernel<0, 2>, 4096, 1024, 0);
+        timed("nb1", fixed_work_kernel<0, 1>, 4096, 1024, 0);
+        for (int a : {1, 2, 4, 8}) {
+            char nm[64]; snprintf(nm, sizeof nm, "nb4, wave w starts w x %d sleep units late", a);
+            timed(nm, fixed_work_kernel<1, 4>, 4096, 1024, a);
+        }
+        timed("nb4, wall clock read every 4 batches", fixed_work_kernel<2, 4>, 4096, 1024, 0);
+        timed("nb4, wall clock read every 4 batches", fixed_work_kernel<2, 4>, 256, 16384, 0);
+        for (int a : {1, 4, 16}) {
+            char nm[64]; snprintf(nm, sizeof nm, "nb4, (wave & 3) sleep units every %d batches", a);
+            timed(nm, fixed_work_kernel<3, 4>, 4096, 1024, a);
+        }
+        timed("nb2, wall clock read every 4 batches", fixed_work_kernel<2, 2>, 4096, 1024, 0);
+        {
+            CHK(hipEventRecord(ea, 0));
+            hipLaunchKernelGGL(ts_count_kernel, dim3(256), dim3(1024), 0, 0, rep_t, (uint64_t)16384);
+            CHK(hipEventRecord(eb, 0));
+            CHK(hipEventSynchronize(eb));
+            float ms = 0;
+            CHK(hipEventElapsedTime(&ms, ea, eb));
+            printf("the static-LDS WINDOW kernel (Ts16w nb4) ended by a count of 16384 blocks per lane, 256 workgroups: events %8.3f ms  %.3e blocks/s\n", ms, 256.0 * 1024 * 16384 / (ms * 1e-3));
+        }
+        timed("nb4, the window kernels' loop, count-ended", fixed_work_kernel<4, 4>, 256, 16384, 0);
+        timed("nb4, the window kernels' loop, count-ended", fixed_work_kernel<4, 4>, 4096, 1024, 0);
+        timed("nb1, the window kernels' loop, count-ended", fixed_work_kernel<4, 1>, 4096, 1024, 0);
+        CHK(hipFree(fout));
+    }
+    if (argc > 2) return 0;     // only the fixed-work table
     run(0, -1, 1);   // warm-up (code objects, clocks)
     printf("\n-- T-table alone (one workgroup per CU)\n");
     double base = 0;

@@ -5,7 +5,7 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 n=$1; shift
 D=/tmp/lgc_var/a/$n
 mkdir -p $R/scripts/exp/libs $D /tmp/lgc_var/include
-cp $R/include/linreg_gc.h /tmp/lgc_var/include/
+cp $R/include/*.h /tmp/lgc_var/include/
 cp $R/linreg-mpc_amd/csrc/*.h $R/linreg-mpc_amd/csrc/*.hip $R/linreg-mpc_amd/csrc/Makefile $D/
 (cd $D && make -s JOBS=${JOBS:-8} EXTRA="$*" 2>&1 | grep -E "error|Error" )
 cp $D/liblinreg_gc.so $R/scripts/exp/libs/lib_$n.so && echo "built lib_$n.so"

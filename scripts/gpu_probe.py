@@ -7,10 +7,7 @@ import linreg_gc as lgc
 
 if os.environ.get("LGC_KARATSUBA") == "0":      # A/B: plain 64 x 64 array in the matrix-vector products
     lgc.set_karatsuba(False)
-for a in sys.argv[1:]:                          # hash=chaskey12: the probes over gate hash 1 (lgc_set_gate_hash)
-    if a.startswith("hash="):
-        lgc.set_gate_hash(a[5:])
-print("devices", lgc.device_count(), "gate hash", lgc.gate_hash(), flush=True)
+print("devices", lgc.device_count(), flush=True)
 for waves, bpl in ((4096, 64), (16384, 256), (65536, 256)):
     r, c = lgc.aes_bench(waves, bpl)
     print("aes_bench waves=%d bpl=%d: %.3e blocks/s chk=%08x" % (waves, bpl, r, c), flush=True)
@@ -34,7 +31,7 @@ def run(d, alg, iters, w=64, p=56, profile=False):
         print("   profiled: garble %.3fs eval %.3fs" % (st["seconds_garble"], st["seconds_eval"]), flush=True)
     s.close()
 
-args = [a for a in sys.argv[1:] if not a.startswith("hash=")] or ["small"]
+args = sys.argv[1:] or ["small"]
 if "small" in args:
     run(20, "cgd", 2)
     run(100, "cgd", 2)
@@ -43,6 +40,10 @@ if "small" in args:
 if "big" in args:
     run(500, "cgd", 1)
     run(500, "cgd", 1, profile=True)
+if "big3" in args:     # the headline's shape, shorter: overlapped and serialised
+    run(500, "cgd", 3)
+    run(500, "cgd", 3)
+    run(500, "cgd", 3, profile=True)
 if "w32" in args:
     run(100, "cgd", 2, w=32, p=30)
 if "mid" in args:      # overlap of the garbler and evaluator chains on latency-bound circuits
