@@ -10,8 +10,6 @@ alg = sys.argv[2] if len(sys.argv) > 2 else "cgd"
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 w = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 p = 56 if w == 64 else 30
-if sys.argv[-1] in lgc.GATE_HASH:      # last argument: the gate hash (lgc_set_gate_hash)
-    lgc.set_gate_hash(sys.argv[-1])
 rng = np.random.default_rng(0)
 T = d * (d + 1) // 2
 shares = rng.integers(0, 2**62, size=(2, T + d), dtype=np.uint64)
