@@ -104,9 +104,10 @@ static inline unsigned gc_adapt_waves(uint32_t nrec, unsigned lo, unsigned hi, u
 // launch is persistent) 1.645-1.653 -- an iteration is then garble + evaluate + the two chains together on an idle chip
 // (65.2 + 37.0 + 7.5 ms) instead of 74.3 + 39.1 + 4.5; another box: 1.791 -> 1.741 (2 / 3 rounds) -> 1.726 (one round);
 // d = 300: 0.691 -> 0.653-0.667; 32-bit d = 500 CGD-20: 0.762 -> 0.740.  So: about kMacChunk records per wave, the number of
-// workgroups a whole number of rounds, at least one; launches of fewer than kMacChunkMinRounds rounds of one record per
-// wave keep the static assignment (the products of small systems, which their own chain waits for).
-static constexpr unsigned kMacChunk = 32, kMacChunkMinRounds = 4;
+// workgroups a whole number of rounds, at least one; launches of less than one round of one record per wave keep the static
+// assignment.  (Launches of one to four rounds, the products of mid-sized systems: d = 100 CGD-15 0.119 -> 0.1155 s, d = 150
+// 0.215 -> 0.205, d = 200 and the 32-bit d = 300 within 1 %, Cholesky d = 250 1.956 -> 1.920.)
+static constexpr unsigned kMacChunk = 32, kMacChunkMinRounds = 1;
 static inline unsigned gc_mac_per_wg(uint32_t nrec, unsigned waves) {
     const uint64_t cus = gc_num_cus();
     if ((uint64_t)nrec < (uint64_t)kMacChunkMinRounds * cus * waves) return waves;
