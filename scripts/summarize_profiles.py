@@ -21,7 +21,7 @@ for src, dst in (("stats/**/*_kernel_stats.csv", "bench_kernel_stats.csv"), ("st
         shutil.copy(f, os.path.join(P, tag + "_" + dst))
 for name in ("bench_line.json", "bench_detail.json", "launch_profile_d500_cgd15.txt", "launch_profile_d100_cgd15.txt", "launch_profile_d20_cholesky.txt",
              "launch_profile_d500_cgd20_w32.txt", "probe.txt", "ot_probe.txt", "phase1_probe.txt", "phase1_baseline.jsonl",
-             "startup_timeline.json", "startup_timeline.txt", "valu_issue.txt", "split_trace.txt", "hip_init.txt", "hip_exit.txt"):
+             "big_factorisations.txt", "startup_timeline.json", "startup_timeline.txt", "valu_issue.txt", "split_trace.txt", "hip_init.txt", "hip_exit.txt"):
     if os.path.exists(os.path.join(O, name)):
         shutil.copy(os.path.join(O, name), os.path.join(P, tag + "_" + name))
 
@@ -72,5 +72,5 @@ for dirs, name, what in ((["pmc_sq1", "pmc_sq2"], "mac_sq_counters.json", "pytho
     json.dump({"command": "rocprofv3 --pmc <SQ counters, two passes> -- " + what, "note": "averages per launch; SQ_* summed over the chip",
                "kernels": keep}, open(os.path.join(P, tag + "_" + name), "w"), indent=1)
 for k in hbm:
-    if "mac_kernel" in k:
+    if "mac_kernel" in k or "mack_kernel" in k:
         print(k, json.dumps(hbm[k]))
