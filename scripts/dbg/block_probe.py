@@ -7,9 +7,6 @@ import torch
 import linreg_gc as lgc
 import sweep
 d, it = 100, 15
-if len(sys.argv) > 1:
-    lgc.set_gate_hash(sys.argv[1])
-print("gate hash:", lgc.gate_hash(), flush=True)
 rng = np.random.default_rng(5)
 T = d * (d + 1) // 2
 shares = rng.integers(0, 2**62, size=(2, T + d), dtype=np.uint64)
