@@ -1,8 +1,8 @@
 """Randomised parity sweep on the GPU (not part of the pytest suite; run through gpurun):
 random dimension, algorithm, width, precision, share count, input path, lambda and seed; every
 result (beta, trace, revealed inputs) is compared bit for bit with the CPU oracle.
-    python tests/tools/gpu_fuzz.py [cases] [seed] [big|small] [aes128|chaskey12]     (big: dimensions that reach the MAC and wide
-    kernels; last argument: the gate hash, lgc_set_gate_hash)"""
+    python tests/tools/gpu_fuzz.py [cases] [seed] [big|small|huge]     (big: dimensions that reach the MAC and wide kernels;
+    huge: matrix-vector launches of several rounds -- the MAC kernels' record queue with chunks of many records per wave)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "linreg-mpc_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,9 +13,8 @@ from helpers import oracle_solve, split_shares, sx, synth_system
 oracle = orc.load()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
-BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
-if len(sys.argv) > 4:
-    lgc.set_gate_hash(sys.argv[4])
+BIG = len(sys.argv) > 3 and sys.argv[3] in ("big", "huge")
+HUGE = len(sys.argv) > 3 and sys.argv[3] == "huge"
 t0 = time.time()
 bad = 0
 for c in range(cases):
@@ -25,6 +24,8 @@ for c in range(cases):
     d = int(rng.integers(1, 48)) if alg == "cgd" else int(rng.integers(1, 28))
     if BIG:
         d = int(rng.integers(48, 220)) if alg == "cgd" else int(rng.integers(28, 72))
+    if HUGE:
+        d = int(rng.integers(220, 420)) if alg == "cgd" else int(rng.integers(72, 130))
     n = int(rng.integers(d + 2, 4 * d + 10))
     normalize = int(rng.integers(0, 2))
     nsh = int(rng.integers(1, 6)) if normalize else 2
