@@ -57,7 +57,7 @@ extern "C" void lgc_trace_mark(const char *what) {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     fprintf(stderr, "LGCT %s %.6f %s\n", g_trace_tag, (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec, what ? what : "");
 }
-extern "C" const char *lgc_version(void) { return "linreg-mpc_amd gc engine r5 (gfx950, half-gates, LDS T-table AES, Karatsuba MAC, Sklansky adders, byte table ring)"; }
+extern "C" const char *lgc_version(void) { return "linreg-mpc_amd gc engine r6 (gfx950, half-gates, LDS T-table AES, Karatsuba MAC, Sklansky adders, byte table ring, MAC record queue)"; }
 extern "C" int lgc_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
