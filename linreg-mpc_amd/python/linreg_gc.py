@@ -622,6 +622,15 @@ def set_table_ring_slack(nbytes):
 
 
 
+def devices_preflight(devices):
+    """lgc_devices_preflight (linreg_gc_sweep.h): every index exists and distinct devices can reach each other; raises LgcError
+    with the index or the pair in the message otherwise"""
+    arr = (C.c_int * len(devices))(*[int(v) for v in devices])
+    L = lib()
+    L.lgc_devices_preflight.argtypes = [C.c_void_p, C.c_size_t]; L.lgc_devices_preflight.restype = C.c_int
+    _chk(L.lgc_devices_preflight(arr, len(devices)))
+
+
 def gate_hash_eval(labels, tweaks, device=0):
     """the gate hash H(x, t) on the device: labels (n, 16) uint8, tweaks (n,) uint64 -> (n, 16) uint8"""
     x = np.ascontiguousarray(labels, dtype=np.uint8).reshape(-1, 16)

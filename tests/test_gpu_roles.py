@@ -204,3 +204,18 @@ def test_ti_ring_messages_are_truncated_to_32_bits(lgc, oracle):
     for ptr in (dV, dIn, dOut):
         L.lgc_dev_free(ptr)
     ph.close()
+
+
+@pytest.mark.gpu
+def test_devices_preflight_names_the_missing_index(lgc):
+    """bin/linreg --devices / bench.py --gpus N check their device list before anything is allocated (lgc_devices_preflight)"""
+    n = lgc.device_count()
+    lgc.devices_preflight([0])
+    lgc.devices_preflight([0, 0, 0])                    # an index may repeat: several blocks on one GPU
+    with pytest.raises(lgc.LgcError) as e:
+        lgc.devices_preflight([0, n])
+    assert "device index %d does not exist" % n in str(e.value) and e.value.code == -1
+    with pytest.raises(lgc.LgcError):
+        lgc.devices_preflight([])
+    if n >= 2:
+        lgc.devices_preflight(list(range(n)))           # one xGMI hive: every pair reachable

@@ -372,6 +372,9 @@ def test_library_exports_and_fails_loudly_without_gpu(lgc):
         with pytest.raises(lgc.LgcError) as e:
             lgc.Solver(lgc.make_system(3))
         assert e.value.code == -2     # LGC_ENODEVICE: no CPU fallback
+        with pytest.raises(lgc.LgcError) as e:
+            lgc.devices_preflight([0])
+        assert e.value.code == -2
     with pytest.raises(lgc.LgcError):
         lgc.Program(lgc.make_system(3, width=48))
     with pytest.raises(lgc.LgcError):
