@@ -69,6 +69,8 @@ for dirs, name, what in ((["pmc_sq1", "pmc_sq2"], "mac_sq_counters.json", "pytho
                          (["pmc_quad1", "pmc_quad2"], "quad_sq_counters.json", "python3 scripts/gpu_probe.py chol (d=20 Cholesky x3: 4-wave latency kernels)")):
     c = counters(dirs)
     keep = {k: dict(v, **derived(v)) for k, v in c.items() if "gc_" in k}
+    if not keep:
+        continue                      # this pass was not part of the run (scripts/profile_bench.sh)
     json.dump({"command": "rocprofv3 --pmc <SQ counters, two passes> -- " + what, "note": "averages per launch; SQ_* summed over the chip",
                "kernels": keep}, open(os.path.join(P, tag + "_" + name), "w"), indent=1)
 for k in hbm:
