@@ -169,6 +169,17 @@ __device__ __forceinline__ Lbl ld_lbl_global(const Lbl *p) {
     Lbl r = {v.x, v.y, v.z, v.w};
     return r;
 }
+// garbled-table rows are written once and read once, a launch (tens of GiB) later: non-temporal, so that they do not push the
+// word file and the scratch lines out of L2 on their way through
+__device__ __forceinline__ void st_lbl_global_nt(Lbl *p, Lbl v) {
+    gc_u32x4 d = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(d, (__attribute__((address_space(1))) gc_u32x4 *)p);
+}
+__device__ __forceinline__ Lbl ld_lbl_global_nt(const Lbl *p) {
+    gc_u32x4 v = __builtin_nontemporal_load((const __attribute__((address_space(1))) gc_u32x4 *)p);
+    Lbl r = {v.x, v.y, v.z, v.w};
+    return r;
+}
 __device__ __forceinline__ void st_lbl_lds(Lbl *p, Lbl v) {
     gc_u32x4 d = {v.x, v.y, v.z, v.w};
     *(__attribute__((address_space(3))) gc_u32x4 *)p = d;
@@ -284,10 +295,10 @@ struct GpuBackend {
             if (GARBLER) {
                 Lbl TG, TE;
                 c = garble_and(lt, c_aes.rk, R, a, b, gid, TG, TE, c_aes.rk24);
-                st_lbl_global(slot, TG);
-                st_lbl_global(slot + 64, TE);
+                st_lbl_global_nt(slot, TG);
+                st_lbl_global_nt(slot + 64, TE);
             } else {
-                Lbl TG = ld_lbl_global(slot), TE = ld_lbl_global(slot + 64);
+                Lbl TG = ld_lbl_global_nt(slot), TE = ld_lbl_global_nt(slot + 64);
                 c = eval_and(lt, c_aes.rk, a, b, gid, TG, TE, c_aes.rk24);
             }
         }
@@ -625,8 +636,8 @@ gc_tabfill_kernel(const Lbl *stash, Lbl *tab, uint32_t nsteps, uint64_t launch_s
             const uint64_t gid = (launch_step0 + row) * 64 + (uint64_t)lane;
             (void)garble_and(lt, c_aes.rk, R, a0, b0, gid, TG, TE, c_aes.rk24);
         }
-        st_lbl(slot, TG);
-        st_lbl(slot + 64, TE);
+        st_lbl_global_nt(slot, TG);
+        st_lbl_global_nt(slot + 64, TE);
     }
 }
 
